@@ -1,0 +1,148 @@
+/*
+ * pt_oracle.h -- CPU ORACLE for the path-tracing hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a plain-C restatement of the reference's `render Inline` path
+ * (robbert-vdh/haskell-path-tracer: src/Scene/Trace.hs, src/Scene/Intersection.hs,
+ * src/Util.hs, src/Scene/Objects.hs, src/Scene/World.hs).  It is the checker the
+ * HIP product is compared against.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's `cpu_baseline` leg may load it; nothing under
+ * haskell-path-tracer_amd/ links, imports or calls it.
+ *
+ * PARITY STATUS
+ *   - distanceTo / hit / normal for Sphere and Plane: PINNED by the reference's
+ *     own 8 Hedgehog properties (test/Scene/Intersection/Tests.hs:32-121),
+ *     restated in tests/test_oracle_intersection.py.
+ *   - everything else on the path (render, primaryRays, traceInline, checkHit
+ *     selection, calcNextRay, anglesToQuaternion, genVec, SFC32): PARITY UNPINNED.
+ *     The reference holds no test, fixture or golden image for them, the GHC /
+ *     Accelerate toolchain is absent here, and the RNG lives in an un-vendored
+ *     dependency (robbert-vdh/sfc-random-accelerate @ 16fe36ec, cabal.project:61-65)
+ *     whose algorithm is restated from the published PractRand sfc32.
+ *
+ * Arithmetic contract (must be honoured by the compiler flags in the Makefile):
+ * IEEE-754 binary32, every operation rounded on its own (-ffp-contract=off, no
+ * fast-math), IEEE sqrt and division, sinf/cosf = restatement of glibc 2.35's
+ * (ARM optimized-routines) algorithm so that host and device agree bit for bit.
+ */
+#ifndef PT_ORACLE_H
+#define PT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- types: field order follows src/Scene/Objects.hs ---------------------- */
+typedef struct { float x, y, z; } ora_v3;                 /* Objects.hs:40-42  V3 Float        */
+typedef struct { float w; ora_v3 v; } ora_quat;           /* linear: Quaternion s (V3 i j k)   */
+typedef struct { uint32_t a, b, c, counter; } ora_sfc32;  /* sfc-random-accelerate (L0)        */
+typedef struct { ora_v3 origin, direction; } ora_ray;     /* Objects.hs:114-123 (also NormalP) */
+
+enum { ORA_MATTE = 0, ORA_GLOSSY = 1 };                   /* Objects.hs:77-87 constructor tags */
+
+/* Flat records, 10 and 12 32-bit words; identical in layout to ptmi_sphere /
+ * ptmi_plane of include/ptmi.h so tests can hand the same bytes to both. */
+typedef struct {
+    float   position[3];    /* Objects.hs:127 */
+    float   radius;         /* Objects.hs:128 */
+    float   color[3];       /* Objects.hs:95  */
+    float   illuminance;    /* Objects.hs:97  */
+    int32_t brdf_tag;       /* Objects.hs:82/86 */
+    float   brdf_param;
+} ora_sphere;
+
+typedef struct {
+    float   position[3];    /* Objects.hs:104 */
+    float   direction[3];   /* Objects.hs:105 */
+    float   color[3];
+    float   illuminance;
+    int32_t brdf_tag;
+    float   brdf_param;
+} ora_plane;
+
+typedef struct {
+    float   position[3];    /* Objects.hs:68 */
+    float   rotation[3];    /* Objects.hs:70  (roll, pitch, yaw) */
+    int64_t fov;            /* Objects.hs:72  Int = 64-bit       */
+} ora_camera;
+
+typedef struct {
+    const ora_sphere *spheres; int n_spheres;   /* Objects.hs:61 */
+    const ora_plane  *planes;  int n_planes;    /* Objects.hs:62 */
+} ora_scene;
+
+typedef struct { int is_just; float value; } ora_maybe_float;
+
+typedef struct {
+    ora_v3 color; float illuminance; int32_t brdf_tag; float brdf_param;
+} ora_material;
+
+typedef struct {
+    int is_just;
+    ora_ray normal_p;       /* (hit position, normal) */
+    ora_material material;
+} ora_maybe_hit;
+
+/* ---- scalar functions ------------------------------------------------------ */
+float ora_sinf(float y);                       /* glibc 2.35 sinf algorithm */
+float ora_cosf(float y);                       /* glibc 2.35 cosf algorithm */
+
+uint32_t ora_sfc32_next(ora_sfc32 *s);         /* PractRand sfc32 raw step  */
+float    ora_random_float(ora_sfc32 *s);       /* random @Float, (0,1]      */
+ora_sfc32 ora_sfc32_seed3(uint32_t a, uint32_t b, uint32_t c);  /* createWith */
+void     ora_seed_words(uint64_t seed0, uint64_t index, uint32_t out[3]);
+
+ora_v3   ora_gen_vec(ora_sfc32 *s);                              /* Util.hs:114-118 */
+ora_quat ora_angles_to_quaternion(ora_v3 angles);                /* Util.hs:55-67   */
+ora_v3   ora_rotate(ora_quat q, ora_v3 v);                       /* linear: rotate  */
+ora_v3   ora_normalize(ora_v3 v);                                /* linear: normalize */
+int      ora_near_zero_v3(ora_v3 v);                             /* linear: nearZero  */
+
+ora_maybe_float ora_distance_to_sphere(ora_ray r, const ora_sphere *s);  /* Intersection.hs:39-48 */
+ora_maybe_float ora_distance_to_plane (ora_ray r, const ora_plane  *p);  /* Intersection.hs:57-62 */
+ora_maybe_hit   ora_hit_sphere(ora_ray r, float t, const ora_sphere *s); /* Intersection.hs:29-32,50 */
+ora_maybe_hit   ora_hit_plane (ora_ray r, float t, const ora_plane  *p); /* Intersection.hs:29-32,64 */
+ora_maybe_hit   ora_check_hit(const ora_scene *scene, ora_ray r);        /* Trace.hs:443-447 */
+
+void ora_calc_next_ray(const ora_material *m, ora_ray normal_p, ora_ray ray, ora_sfc32 seed,
+                       ora_ray *next_ray, ora_v3 *throughput_mod, ora_sfc32 *seed_out); /* Trace.hs:394-435 */
+
+void ora_trace_inline(int limit, const ora_scene *scene, ora_ray primary, ora_sfc32 seed,
+                      ora_v3 *color_out, ora_sfc32 *seed_out, int *live_bounces); /* Trace.hs:344-383 */
+
+/* per-launch uniforms of primaryRays (Trace.hs:205-242) */
+typedef struct { ora_v3 pos, center, right, top; float inv_w_dummy; } ora_primary_uniforms;
+ora_primary_uniforms ora_primary_setup(const ora_camera *cam, int width, int height);
+ora_ray ora_primary_ray(const ora_primary_uniforms *u, int64_t x, int64_t y, int width, int height); /* Trace.hs:244-262 */
+
+/* ---- array level ----------------------------------------------------------- */
+/* One call of `render Inline` (Trace.hs:193-200) repeated n_spp times on the same
+ * state.  Planes are row-major [height][width]; in-place.  screen_x/screen_y may be
+ * NULL (then x = column, y = row as Util.hs:209-210) or int64 planes.  n_threads<=1
+ * runs the scalar loop on the calling thread; >1 uses OpenMP over rows.  Returns the
+ * number of live path-bounces (iterations that took the computeRay branch). */
+int64_t ora_render_inline(const ora_scene *scene, const ora_camera *cam,
+                          int width, int height, int bounce_limit, int n_spp,
+                          const int64_t *screen_x, const int64_t *screen_y,
+                          float *r, float *g, float *b,
+                          uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr,
+                          int n_threads);
+
+/* `render Streams` (Trace.hs:141-191, 272-331), one sample per call, n_spp calls. */
+int64_t ora_render_streams(const ora_scene *scene, const ora_camera *cam,
+                           int width, int height, int max_iterations, int n_spp,
+                           float *r, float *g, float *b,
+                           uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr);
+
+/* genSeeds / createWith (Util.hs:122-127) made deterministic: word triple k of pixel i
+ * from ora_seed_words(seed0, i), then sfc32 3-word seeding. */
+void ora_gen_seeds(uint64_t seed0, int64_t first_index, int64_t n,
+                   uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr);
+
+int ora_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
