@@ -1,0 +1,46 @@
+"""Builds libptmi.so (HIP kernels + C ABI) for gfx950, in-tree, with hipcc.
+
+The flags are part of the arithmetic contract (DESIGN.md "numerics"): -ffp-contract=off keeps
+every f32/f64 operation separately rounded on host and device; hipcc's default correctly
+rounded sqrt/division stays on; no fast-math.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libptmi.so")
+SOURCES = ["ptmi_api.cpp", "ptmi_kernels.hip"]
+HEADERS = ["ptmi_core.h", "ptmi_kernels.h", os.path.join("..", "..", "include", "ptmi.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-fno-fast-math", "-Wall"]
+
+
+def hipcc_path():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found; libptmi.so cannot be built")
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force=False, verbose=False, extra_flags=()):
+    """Compile the shared library if sources are newer than it. Returns its path."""
+    if not force and not is_stale():
+        return LIB
+    cmd = [hipcc_path()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB

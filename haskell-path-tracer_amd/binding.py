@@ -1,0 +1,270 @@
+"""ctypes binding of include/ptmi.h -- the Python face of the C ABI used by tests and bench.py.
+
+This is a thin mirror: one method per entry point, numpy arrays for host planes, optional
+torch tensors for caller-owned device planes (torch is plumbing for device memory, streams and
+torch.distributed only).  There is no fallback: if libptmi.so is missing or no GPU is present
+the calls raise PtmiError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+from .world import CAMERA_DTYPE, PLANE_DTYPE, SPHERE_DTYPE, INLINE, STREAMS
+
+PTMI_OK, PTMI_EINVAL, PTMI_ENODEVICE, PTMI_EHIP, PTMI_ENOMEM, PTMI_ESTATE, PTMI_ELIMIT = 0, -1, -2, -3, -4, -5, -6
+
+# every symbol include/ptmi.h declares: name -> (restype, argtypes)
+_f32p, _u32p, _i32p, _i64p, _vp = (C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int64), C.c_void_p)
+
+
+class Stats(C.Structure):
+    _fields_ = [("live_bounces", C.c_uint64), ("nominal_bounces", C.c_uint64), ("samples", C.c_uint64),
+                ("last_render_ms", C.c_float), ("stream_iterations", C.c_uint32)]
+
+
+SYMBOLS = {
+    "ptmi_version": (C.c_int, []),
+    "ptmi_strerror": (C.c_char_p, [C.c_int]),
+    "ptmi_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "ptmi_destroy": (None, [_vp]),
+    "ptmi_last_error": (C.c_char_p, [_vp]),
+    "ptmi_set_scene": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int]),
+    "ptmi_resize": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "ptmi_set_partition": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
+    "ptmi_local_rows": (C.c_int, [_vp]),
+    "ptmi_global_row": (C.c_int, [_vp, C.c_int]),
+    "ptmi_bind_planes": (C.c_int, [_vp] + [_vp] * 7),
+    "ptmi_set_stream": (C.c_int, [_vp, _vp]),
+    "ptmi_set_timing": (C.c_int, [_vp, C.c_int]),
+    "ptmi_set_variant": (C.c_int, [_vp, C.c_int]),
+    "ptmi_init_output": (C.c_int, [_vp, C.c_uint64]),
+    "ptmi_reseed": (C.c_int, [_vp, C.c_uint64]),
+    "ptmi_create_with": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "ptmi_upload_state": (C.c_int, [_vp] + [_vp] * 7),
+    "ptmi_download_state": (C.c_int, [_vp] + [_vp] * 7),
+    "ptmi_download_color": (C.c_int, [_vp] + [_vp] * 3),
+    "ptmi_render": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
+    "ptmi_synchronize": (C.c_int, [_vp]),
+    "ptmi_render1": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp] + [_vp] * 14),
+    "ptmi_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "ptmi_reset_stats": (C.c_int, [_vp]),
+    "ptmi_eval_distance_to_sphere": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
+    "ptmi_eval_distance_to_plane": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
+    "ptmi_eval_sincos": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
+}
+
+
+class PtmiError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libptmi error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libptmi.so (building nothing: see _build.build_lib) and type every symbol."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or _build.LIB
+    if not os.path.exists(path):
+        raise PtmiError(PTMI_ESTATE, "libptmi.so not built (%s); run __graft_entry__.build()" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export it
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def _host(a, dtype, n=None, name="array"):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if n is not None and a.size != n:
+        raise ValueError("%s has %d elements, expected %d" % (name, a.size, n))
+    return a
+
+
+class Context:
+    """One ptmi_ctx.  Methods map 1:1 onto include/ptmi.h."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        h = _vp()
+        rc = self._lib.ptmi_create(C.byref(h), int(device))
+        if rc != PTMI_OK:
+            raise PtmiError(rc, (self._lib.ptmi_last_error(None) or b"").decode())
+        self._h = h
+        self.width = self.height = 0
+        self._keep = []   # keeps bound tensors alive
+
+    # -- plumbing --------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != PTMI_OK:
+            raise PtmiError(rc, (self._lib.ptmi_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ptmi_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration ---------------------------------------------------------------
+    def set_scene(self, spheres, planes):
+        s = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
+        p = np.ascontiguousarray(planes, dtype=PLANE_DTYPE)
+        self._check(self._lib.ptmi_set_scene(self._h, _ptr(s) if s.size else None, s.size,
+                                             _ptr(p) if p.size else None, p.size))
+
+    def set_partition(self, stripe_rows, n_parts, part):
+        self._check(self._lib.ptmi_set_partition(self._h, stripe_rows, n_parts, part))
+
+    def resize(self, width, height):
+        self._check(self._lib.ptmi_resize(self._h, width, height))
+        self.width, self.height = width, height
+        self._keep = []
+
+    @property
+    def local_rows(self):
+        rc = self._lib.ptmi_local_rows(self._h)
+        if rc < 0:
+            self._check(rc)
+        return rc
+
+    def global_row(self, local_row):
+        rc = self._lib.ptmi_global_row(self._h, local_row)
+        if rc < 0:
+            raise PtmiError(rc, "ptmi_global_row")
+        return rc
+
+    def global_rows(self):
+        return np.array([self.global_row(i) for i in range(self.local_rows)], dtype=np.int64)
+
+    @property
+    def n_local(self):
+        return self.local_rows * self.width
+
+    def bind_torch(self, color, state):
+        """color: float32 CUDA tensor [3, rows, W]; state: int32 CUDA tensor [4, rows, W] (uint32 bits)."""
+        assert color.is_cuda and state.is_cuda and color.is_contiguous() and state.is_contiguous()
+        assert tuple(color.shape) == (3, self.local_rows, self.width), color.shape
+        assert tuple(state.shape) == (4, self.local_rows, self.width), state.shape
+        assert color.element_size() == 4 and state.element_size() == 4
+        ptrs = [color[i].data_ptr() for i in range(3)] + [state[i].data_ptr() for i in range(4)]
+        self._check(self._lib.ptmi_bind_planes(self._h, *[_vp(p) for p in ptrs]))
+        self._keep = [color, state]
+
+    def unbind(self):
+        self._check(self._lib.ptmi_bind_planes(self._h, *([None] * 7)))
+        self._keep = []
+
+    def set_stream(self, hip_stream):
+        self._check(self._lib.ptmi_set_stream(self._h, _vp(hip_stream) if hip_stream else None))
+
+    def set_timing(self, enabled):
+        self._check(self._lib.ptmi_set_timing(self._h, int(bool(enabled))))
+
+    def set_variant(self, variant):
+        self._check(self._lib.ptmi_set_variant(self._h, int(variant)))
+
+    # -- state -----------------------------------------------------------------------
+    def init_output(self, seed0):
+        self._check(self._lib.ptmi_init_output(self._h, C.c_uint64(seed0)))
+
+    def reseed(self, seed0):
+        self._check(self._lib.ptmi_reseed(self._h, C.c_uint64(seed0)))
+
+    def create_with(self, w0, w1, w2):
+        n = self.n_local
+        ws = [_host(w, np.uint32, n, "word plane") for w in (w0, w1, w2)]
+        self._check(self._lib.ptmi_create_with(self._h, *[_ptr(w) for w in ws]))
+
+    def upload_state(self, r=None, g=None, b=None, sa=None, sb=None, sc=None, sctr=None):
+        n = self.n_local
+        arrs = [None if a is None else _host(a, np.float32, n) for a in (r, g, b)] + \
+               [None if a is None else _host(a, np.uint32, n) for a in (sa, sb, sc, sctr)]
+        self._check(self._lib.ptmi_upload_state(self._h, *[_ptr(a) for a in arrs]))
+
+    def download_state(self):
+        shape = (self.local_rows, self.width)
+        out = [np.empty(shape, np.float32) for _ in range(3)] + [np.empty(shape, np.uint32) for _ in range(4)]
+        self._check(self._lib.ptmi_download_state(self._h, *[_ptr(a) for a in out]))
+        return tuple(out)
+
+    def download_color(self):
+        shape = (self.local_rows, self.width)
+        out = [np.empty(shape, np.float32) for _ in range(3)]
+        self._check(self._lib.ptmi_download_color(self._h, *[_ptr(a) for a in out]))
+        return tuple(out)
+
+    # -- hot path --------------------------------------------------------------------
+    def render(self, camera, bounce_limit, n_spp, algorithm=INLINE):
+        cam = np.ascontiguousarray(camera, dtype=CAMERA_DTYPE)
+        self._check(self._lib.ptmi_render(self._h, _ptr(cam), algorithm, bounce_limit, n_spp))
+
+    def synchronize(self):
+        self._check(self._lib.ptmi_synchronize(self._h))
+
+    def render1(self, camera, bounce_limit, width, height, planes_in, algorithm=INLINE, screen=None):
+        """compileFor's closure (app/Main.hs:188-191): 7 host planes in -> 7 new host planes out."""
+        cam = np.ascontiguousarray(camera, dtype=CAMERA_DTYPE)
+        n = width * height
+        ins = [_host(a, np.float32, n) for a in planes_in[:3]] + [_host(a, np.uint32, n) for a in planes_in[3:]]
+        outs = [np.empty((height, width), np.float32) for _ in range(3)] + \
+               [np.empty((height, width), np.uint32) for _ in range(4)]
+        sx = sy = None
+        if screen is not None:
+            sx, sy = _host(screen[0], np.int64, n), _host(screen[1], np.int64, n)
+        self._check(self._lib.ptmi_render1(self._h, _ptr(cam), algorithm, bounce_limit, width, height,
+                                           _ptr(sx), _ptr(sy), *[_ptr(a) for a in ins], *[_ptr(a) for a in outs]))
+        return tuple(outs)
+
+    def stats(self):
+        st = Stats()
+        self._check(self._lib.ptmi_get_stats(self._h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in Stats._fields_}
+
+    def reset_stats(self):
+        self._check(self._lib.ptmi_reset_stats(self._h))
+
+    # -- point queries ---------------------------------------------------------------
+    def eval_distance_to_sphere(self, spheres, rays):
+        s = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
+        r = _host(rays, np.float32, s.size * 6, "rays")
+        n = s.size
+        just, t, nrm = np.empty(n, np.int32), np.empty(n, np.float32), np.empty((n, 6), np.float32)
+        self._check(self._lib.ptmi_eval_distance_to_sphere(self._h, _ptr(s), _ptr(r), n, _ptr(just), _ptr(t), _ptr(nrm)))
+        return just, t, nrm
+
+    def eval_distance_to_plane(self, planes, rays):
+        p = np.ascontiguousarray(planes, dtype=PLANE_DTYPE)
+        r = _host(rays, np.float32, p.size * 6, "rays")
+        n = p.size
+        just, t, nrm = np.empty(n, np.int32), np.empty(n, np.float32), np.empty((n, 6), np.float32)
+        self._check(self._lib.ptmi_eval_distance_to_plane(self._h, _ptr(p), _ptr(r), n, _ptr(just), _ptr(t), _ptr(nrm)))
+        return just, t, nrm
+
+    def eval_sincos(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        s, c = np.empty_like(x), np.empty_like(x)
+        self._check(self._lib.ptmi_eval_sincos(self._h, _ptr(x), x.size, _ptr(s), _ptr(c)))
+        return s, c

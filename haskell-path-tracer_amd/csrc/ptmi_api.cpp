@@ -1,0 +1,593 @@
+// ptmi_api.cpp -- the C ABI of include/ptmi.h: context, device planes, scene packing, launches.
+// Compiled with hipcc together with ptmi_kernels.hip into libptmi.so.  There is no CPU
+// fallback here: without a HIP device ptmi_create fails with PTMI_ENODEVICE.
+#include "../../include/ptmi.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ptmi_kernels.h"
+
+using namespace ptmi;
+
+struct ptmi_ctx {
+    std::mutex mu;
+    int device = 0;
+    std::string err;
+
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+
+    int width = 0, height = 0;
+    int stripe_rows = 0, n_parts = 1, part = 0;   // stripe_rows == 0: one part holds everything
+    int rows_local = 0;
+
+    Planes owned{};          // seven planes carved from owned_block
+    void *owned_block = nullptr;
+    Planes bound{};
+    bool use_bound = false;
+
+    float4 *d_scene = nullptr;
+    int n_spheres = 0, n_planes = 0;
+
+    unsigned long long *d_live = nullptr;
+    unsigned int *d_work = nullptr;
+    unsigned int *d_iters = nullptr;
+    uint64_t nominal = 0, samples = 0;
+
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    int variant = 0;
+
+    // scratch for ptmi_render1 / point queries
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+int fail(ptmi_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define PTMI_HIP(c, call)                                                                  \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail((c), e_ == hipErrorOutOfMemory ? PTMI_ENOMEM : PTMI_EHIP,           \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+int effective_stripe(const ptmi_ctx *c) { return c->stripe_rows > 0 ? c->stripe_rows : (c->height > 0 ? c->height : 1); }
+
+int rows_of_part(int height, int stripe, int n_parts, int part)
+{
+    const long long cycle = (long long)stripe * n_parts;
+    long long rows = (height / cycle) * stripe;
+    long long rem = height % cycle - (long long)part * stripe;
+    if (rem > stripe) rem = stripe;
+    if (rem > 0) rows += rem;
+    return (int)rows;
+}
+
+Planes carve(void *block, size_t n)
+{
+    Planes p;
+    char *b = static_cast<char *>(block);
+    const size_t plane = ((n * 4 + 255) / 256) * 256;
+    p.r = reinterpret_cast<float *>(b);
+    p.g = reinterpret_cast<float *>(b + plane);
+    p.b = reinterpret_cast<float *>(b + 2 * plane);
+    p.sa = reinterpret_cast<uint32_t *>(b + 3 * plane);
+    p.sb = reinterpret_cast<uint32_t *>(b + 4 * plane);
+    p.sc = reinterpret_cast<uint32_t *>(b + 5 * plane);
+    p.sctr = reinterpret_cast<uint32_t *>(b + 6 * plane);
+    return p;
+}
+size_t planes_bytes(size_t n) { return 7 * (((n * 4 + 255) / 256) * 256); }
+
+Planes &active(ptmi_ctx *c) { return c->use_bound ? c->bound : c->owned; }
+
+int ensure_scratch(ptmi_ctx *c, size_t bytes)
+{
+    if (bytes <= c->scratch_bytes) return PTMI_OK;
+    if (c->scratch) { (void)hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
+    PTMI_HIP(c, hipMalloc(&c->scratch, bytes));
+    c->scratch_bytes = bytes;
+    return PTMI_OK;
+}
+
+// primaryRays' per-launch values (src/Scene/Trace.hs:205-242), evaluated on the host with
+// the same arithmetic definitions as the device code (ptmi_core.h); tan is the host libm's.
+PrimaryUniforms make_uniforms(const ptmi_camera &cam, int width, int height)
+{
+    PrimaryUniforms u;
+    const float c_fov = (float)cam.fov;
+    const float screen_angle = (c_fov * kPi / 180.0f) / 2.0f;
+    const float screen_distance = 1.0f / tanf(screen_angle);
+    const float screen_half_width = tanf(screen_angle) * screen_distance;
+    const V3 c_pos = mk(cam.position[0], cam.position[1], cam.position[2]);
+    const V3 c_rot = mk(cam.rotation[0], cam.rotation[1], cam.rotation[2]);
+    const V3 c_dir = rotate(angles_to_quaternion(c_rot), mk(0.0f, 0.0f, -1.0f));   // Util.hs:48-50, :96-97
+    const float screen_aspect = (float)width / (float)height;                        // Util.hs:192-193
+    const V3 center = c_pos + scale_r(c_dir, screen_distance);
+    const V3 center_offset = center - c_pos;
+    const V3 right = div_r(normalize(cross(center_offset, mk(0.0f, 1.0f, 0.0f))), screen_half_width);
+    const V3 top = div_r(cross(c_dir, right), screen_aspect);
+    u.pos = c_pos; u.center = center; u.right = right; u.top = top;
+    u.size_x = (float)width; u.size_y = (float)(-height);                            // Util.hs:198-200
+    return u;
+}
+
+void pack_scene(const ptmi_sphere *sph, int ns, const ptmi_plane *pl, int np, std::vector<float4> &out)
+{
+    out.assign((size_t)ns + 2 * (size_t)np + 2 * ((size_t)ns + np), float4{0, 0, 0, 0});
+    size_t k = 0;
+    for (int i = 0; i < ns; ++i)
+        out[k++] = float4{sph[i].position[0], sph[i].position[1], sph[i].position[2], sph[i].radius * sph[i].radius};
+    for (int j = 0; j < np; ++j) {
+        out[k++] = float4{pl[j].position[0], pl[j].position[1], pl[j].position[2], 0.0f};
+        out[k++] = float4{pl[j].direction[0], pl[j].direction[1], pl[j].direction[2], 0.0f};
+    }
+    auto mat = [&](const float *color, float illum, int32_t tag, float p) {
+        out[k++] = float4{color[0], color[1], color[2], illum};
+        out[k++] = float4{u2f((uint32_t)tag), p, p / kPi, 1.0f - p};
+    };
+    for (int i = 0; i < ns; ++i) mat(sph[i].color, sph[i].illuminance, sph[i].brdf_tag, sph[i].brdf_param);
+    for (int j = 0; j < np; ++j) mat(pl[j].color, pl[j].illuminance, pl[j].brdf_tag, pl[j].brdf_param);
+}
+
+int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, int algorithm,
+                  int bounce_limit, int n_spp, int width, int height, int rows_local,
+                  int stripe_rows, int n_parts, int part, const int64_t *sx, const int64_t *sy)
+{
+    RenderArgs a{};
+    a.cam = make_uniforms(*camera, width, height);
+    a.scene.packed = c->d_scene; a.scene.n_spheres = c->n_spheres; a.scene.n_planes = c->n_planes;
+    a.planes = planes;
+    a.screen_x = sx; a.screen_y = sy;
+    a.width = width; a.height = height; a.rows_local = rows_local;
+    a.stripe_rows = stripe_rows; a.n_parts = n_parts; a.part = part;
+    a.bounce_limit = bounce_limit; a.n_spp = n_spp;
+    a.live_counter = c->d_live; a.work_counter = c->d_work; a.stream_iterations = c->d_iters;
+    if (c->timing) { PTMI_HIP(c, hipEventRecord(c->ev0, c->stream)); }
+    if (algorithm == PTMI_INLINE) {
+        PTMI_HIP(c, launch_render_inline(a, c->variant, c->stream));
+    } else {
+        PTMI_HIP(c, launch_render_streams(a, c->variant, c->stream));
+    }
+    if (c->timing) { PTMI_HIP(c, hipEventRecord(c->ev1, c->stream)); c->ev_valid = true; }
+    const uint64_t px = (uint64_t)rows_local * (uint64_t)width;
+    c->samples += px * (uint64_t)(n_spp > 0 ? n_spp : 0);
+    c->nominal += px * (uint64_t)(n_spp > 0 ? n_spp : 0) * (uint64_t)(bounce_limit > 0 ? bounce_limit : 0);
+    return PTMI_OK;
+}
+
+int check_render_args(ptmi_ctx *c, const ptmi_camera *camera, int algorithm, int bounce_limit, int n_spp)
+{
+    if (!camera) return fail(c, PTMI_EINVAL, "camera is NULL");
+    if (algorithm != PTMI_INLINE && algorithm != PTMI_STREAMS) return fail(c, PTMI_EINVAL, "unknown algorithm");
+    if (bounce_limit < 0) return fail(c, PTMI_EINVAL, "bounce_limit < 0");
+    if (n_spp < 0) return fail(c, PTMI_EINVAL, "n_spp < 0");
+    if (!c->d_scene) return fail(c, PTMI_ESTATE, "ptmi_set_scene has not been called");
+    return PTMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptmi_version(void) { return PTMI_VERSION; }
+
+const char *ptmi_strerror(int code)
+{
+    switch (code) {
+    case PTMI_OK: return "ok";
+    case PTMI_EINVAL: return "invalid argument";
+    case PTMI_ENODEVICE: return "no usable HIP device";
+    case PTMI_EHIP: return "HIP runtime error";
+    case PTMI_ENOMEM: return "out of memory";
+    case PTMI_ESTATE: return "call order violated";
+    case PTMI_ELIMIT: return "scene exceeds PTMI_MAX_PRIMITIVES";
+    default: return "unknown error";
+    }
+}
+
+const char *ptmi_last_error(const ptmi_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int ptmi_create(ptmi_ctx **out, int device)
+{
+    if (!out) return fail(nullptr, PTMI_EINVAL, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, PTMI_ENODEVICE, std::string("hipGetDeviceCount: ") +
+                    (e != hipSuccess ? hipGetErrorString(e) : "0 devices") + " (libptmi has no CPU path)");
+    if (device < 0 || device >= count) return fail(nullptr, PTMI_ENODEVICE, "device index out of range");
+    ptmi_ctx *c = new (std::nothrow) ptmi_ctx;
+    if (!c) return fail(nullptr, PTMI_ENOMEM, "host allocation failed");
+    c->device = device;
+    auto bail = [&](hipError_t err, const char *what) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+        ptmi_destroy(c);
+        return PTMI_EHIP;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    c->stream = c->own_stream;
+    if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipMalloc(&c->d_live, sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc(&c->d_work, 64 * sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc(&c->d_iters, sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMemset(c->d_live, 0, sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = hipMemset(c->d_work, 0, 64 * sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = hipMemset(c->d_iters, 0, sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMemset");
+    *out = c;
+    return PTMI_OK;
+}
+
+void ptmi_destroy(ptmi_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    if (c->owned_block) (void)hipFree(c->owned_block);
+    if (c->d_scene) (void)hipFree(c->d_scene);
+    if (c->d_live) (void)hipFree(c->d_live);
+    if (c->d_work) (void)hipFree(c->d_work);
+    if (c->d_iters) (void)hipFree(c->d_iters);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int ptmi_set_scene(ptmi_ctx *c, const ptmi_sphere *spheres, int n_spheres, const ptmi_plane *planes, int n_planes)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (n_spheres < 0 || n_planes < 0 || (n_spheres > 0 && !spheres) || (n_planes > 0 && !planes))
+        return fail(c, PTMI_EINVAL, "bad scene arguments");
+    // expMinWith _ [] = error "Invalid call to 'expMinWith'"   (src/Util.hs:172)
+    if (n_spheres + n_planes == 0) return fail(c, PTMI_EINVAL, "empty scene (expMinWith on an empty list)");
+    if (n_spheres + n_planes > PTMI_MAX_PRIMITIVES) return fail(c, PTMI_ELIMIT, "too many primitives");
+    for (int i = 0; i < n_spheres; ++i)
+        if (spheres[i].brdf_tag != PTMI_MATTE && spheres[i].brdf_tag != PTMI_GLOSSY)
+            return fail(c, PTMI_EINVAL, "sphere with unknown brdf_tag");
+    for (int j = 0; j < n_planes; ++j)
+        if (planes[j].brdf_tag != PTMI_MATTE && planes[j].brdf_tag != PTMI_GLOSSY)
+            return fail(c, PTMI_EINVAL, "plane with unknown brdf_tag");
+    PTMI_HIP(c, hipSetDevice(c->device));
+    std::vector<float4> packed;
+    pack_scene(spheres, n_spheres, planes, n_planes, packed);
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->d_scene) { (void)hipFree(c->d_scene); c->d_scene = nullptr; }
+    PTMI_HIP(c, hipMalloc(&c->d_scene, packed.size() * sizeof(float4)));
+    PTMI_HIP(c, hipMemcpy(c->d_scene, packed.data(), packed.size() * sizeof(float4), hipMemcpyHostToDevice));
+    c->n_spheres = n_spheres; c->n_planes = n_planes;
+    return PTMI_OK;
+}
+
+int ptmi_set_partition(ptmi_ctx *c, int stripe_rows, int n_parts, int part)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (stripe_rows <= 0 || n_parts <= 0 || part < 0 || part >= n_parts)
+        return fail(c, PTMI_EINVAL, "bad partition");
+    if (c->owned_block) return fail(c, PTMI_ESTATE, "ptmi_set_partition must precede ptmi_resize");
+    c->stripe_rows = stripe_rows; c->n_parts = n_parts; c->part = part;
+    return PTMI_OK;
+}
+
+int ptmi_resize(ptmi_ctx *c, int width, int height)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (width <= 0 || height <= 0) return fail(c, PTMI_EINVAL, "width and height must be positive");
+    PTMI_HIP(c, hipSetDevice(c->device));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->owned_block) { (void)hipFree(c->owned_block); c->owned_block = nullptr; }
+    c->width = width; c->height = height;
+    c->rows_local = rows_of_part(height, effective_stripe(c), c->n_parts, c->part);
+    c->use_bound = false;
+    const size_t n = (size_t)c->rows_local * (size_t)width;
+    const size_t bytes = planes_bytes(n > 0 ? n : 1);
+    PTMI_HIP(c, hipMalloc(&c->owned_block, bytes));
+    PTMI_HIP(c, hipMemset(c->owned_block, 0, bytes));
+    c->owned = carve(c->owned_block, n > 0 ? n : 1);
+    return PTMI_OK;
+}
+
+int ptmi_local_rows(const ptmi_ctx *c)
+{
+    if (!c) return PTMI_EINVAL;
+    if (c->width <= 0) return PTMI_ESTATE;
+    return c->rows_local;
+}
+
+int ptmi_global_row(const ptmi_ctx *c, int local_row)
+{
+    if (!c) return PTMI_EINVAL;
+    if (c->width <= 0) return PTMI_ESTATE;
+    if (local_row < 0 || local_row >= c->rows_local) return PTMI_EINVAL;
+    const int s = effective_stripe(c);
+    return ((local_row / s) * c->n_parts + c->part) * s + local_row % s;
+}
+
+int ptmi_bind_planes(ptmi_ctx *c, float *r, float *g, float *b, uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (c->width <= 0) return fail(c, PTMI_ESTATE, "ptmi_resize has not been called");
+    const int n_null = !r + !g + !b + !sa + !sb + !sc + !sctr;
+    if (n_null == 7) { c->use_bound = false; return PTMI_OK; }
+    if (n_null != 0) return fail(c, PTMI_EINVAL, "bind either all seven planes or none");
+    c->bound = Planes{r, g, b, sa, sb, sc, sctr};
+    c->use_bound = true;
+    return PTMI_OK;
+}
+
+int ptmi_set_stream(ptmi_ctx *c, void *hip_stream)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    PTMI_HIP(c, hipSetDevice(c->device));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    c->ev_valid = false;
+    return PTMI_OK;
+}
+
+int ptmi_set_timing(ptmi_ctx *c, int enabled)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    c->timing = enabled != 0;
+    c->ev_valid = false;
+    return PTMI_OK;
+}
+
+int ptmi_set_variant(ptmi_ctx *c, int variant)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (variant < 0 || variant > 15) return fail(c, PTMI_EINVAL, "unknown variant");
+    c->variant = variant;
+    return PTMI_OK;
+}
+
+static int seed_common(ptmi_ctx *c, uint64_t seed0, bool clear)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (c->width <= 0) return fail(c, PTMI_ESTATE, "ptmi_resize has not been called");
+    PTMI_HIP(c, hipSetDevice(c->device));
+    PTMI_HIP(c, launch_seed(active(c), c->width, c->rows_local, effective_stripe(c), c->n_parts, c->part,
+                            seed0, clear, c->stream));
+    return PTMI_OK;
+}
+
+int ptmi_init_output(ptmi_ctx *c, uint64_t seed0) { return seed_common(c, seed0, true); }
+int ptmi_reseed(ptmi_ctx *c, uint64_t seed0) { return seed_common(c, seed0, false); }
+
+int ptmi_create_with(ptmi_ctx *c, const uint32_t *w0, const uint32_t *w1, const uint32_t *w2)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (c->width <= 0) return fail(c, PTMI_ESTATE, "ptmi_resize has not been called");
+    if (!w0 || !w1 || !w2) return fail(c, PTMI_EINVAL, "word planes are NULL");
+    PTMI_HIP(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->rows_local * c->width;
+    if (int rc = ensure_scratch(c, 3 * n * 4)) return rc;
+    uint32_t *d = static_cast<uint32_t *>(c->scratch);
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    PTMI_HIP(c, hipMemcpy(d, w0, n * 4, hipMemcpyHostToDevice));
+    PTMI_HIP(c, hipMemcpy(d + n, w1, n * 4, hipMemcpyHostToDevice));
+    PTMI_HIP(c, hipMemcpy(d + 2 * n, w2, n * 4, hipMemcpyHostToDevice));
+    PTMI_HIP(c, launch_create_with(active(c), d, d + n, d + 2 * n, (int64_t)n, c->stream));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    return PTMI_OK;
+}
+
+int ptmi_upload_state(ptmi_ctx *c, const float *r, const float *g, const float *b,
+                      const uint32_t *sa, const uint32_t *sb, const uint32_t *sc, const uint32_t *sctr)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (c->width <= 0) return fail(c, PTMI_ESTATE, "ptmi_resize has not been called");
+    PTMI_HIP(c, hipSetDevice(c->device));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t bytes = (size_t)c->rows_local * c->width * 4;
+    Planes &p = active(c);
+    const void *src[7] = {r, g, b, sa, sb, sc, sctr};
+    void *dst[7] = {p.r, p.g, p.b, p.sa, p.sb, p.sc, p.sctr};
+    for (int i = 0; i < 7; ++i)
+        if (src[i] && bytes) PTMI_HIP(c, hipMemcpy(dst[i], src[i], bytes, hipMemcpyHostToDevice));
+    return PTMI_OK;
+}
+
+int ptmi_download_state(ptmi_ctx *c, float *r, float *g, float *b,
+                        uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (c->width <= 0) return fail(c, PTMI_ESTATE, "ptmi_resize has not been called");
+    PTMI_HIP(c, hipSetDevice(c->device));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t bytes = (size_t)c->rows_local * c->width * 4;
+    Planes &p = active(c);
+    void *dst[7] = {r, g, b, sa, sb, sc, sctr};
+    const void *src[7] = {p.r, p.g, p.b, p.sa, p.sb, p.sc, p.sctr};
+    for (int i = 0; i < 7; ++i)
+        if (dst[i] && bytes) PTMI_HIP(c, hipMemcpy(dst[i], src[i], bytes, hipMemcpyDeviceToHost));
+    return PTMI_OK;
+}
+
+int ptmi_download_color(ptmi_ctx *c, float *r, float *g, float *b)
+{
+    return ptmi_download_state(c, r, g, b, nullptr, nullptr, nullptr, nullptr);
+}
+
+int ptmi_render(ptmi_ctx *c, const ptmi_camera *camera, int algorithm, int bounce_limit, int n_spp)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (int rc = check_render_args(c, camera, algorithm, bounce_limit, n_spp)) return rc;
+    if (c->width <= 0) return fail(c, PTMI_ESTATE, "ptmi_resize has not been called");
+    PTMI_HIP(c, hipSetDevice(c->device));
+    return launch_render(c, active(c), camera, algorithm, bounce_limit, n_spp, c->width, c->height,
+                         c->rows_local, effective_stripe(c), c->n_parts, c->part, nullptr, nullptr);
+}
+
+int ptmi_synchronize(ptmi_ctx *c)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    PTMI_HIP(c, hipSetDevice(c->device));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    return PTMI_OK;
+}
+
+int ptmi_render1(ptmi_ctx *c, const ptmi_camera *camera, int algorithm, int bounce_limit,
+                 int width, int height, const int64_t *screen_x, const int64_t *screen_y,
+                 const float *r_in, const float *g_in, const float *b_in,
+                 const uint32_t *sa_in, const uint32_t *sb_in, const uint32_t *sc_in, const uint32_t *sctr_in,
+                 float *r_out, float *g_out, float *b_out,
+                 uint32_t *sa_out, uint32_t *sb_out, uint32_t *sc_out, uint32_t *sctr_out)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (int rc = check_render_args(c, camera, algorithm, bounce_limit, 1)) return rc;
+    if (width <= 0 || height <= 0) return fail(c, PTMI_EINVAL, "width and height must be positive");
+    if (!r_in || !g_in || !b_in || !sa_in || !sb_in || !sc_in || !sctr_in ||
+        !r_out || !g_out || !b_out || !sa_out || !sb_out || !sc_out || !sctr_out)
+        return fail(c, PTMI_EINVAL, "a plane pointer is NULL");
+    if ((screen_x == nullptr) != (screen_y == nullptr)) return fail(c, PTMI_EINVAL, "give both screen planes or neither");
+    if (screen_x && algorithm == PTMI_STREAMS) return fail(c, PTMI_EINVAL, "Streams takes the implicit screen only");
+    PTMI_HIP(c, hipSetDevice(c->device));
+    const size_t n = (size_t)width * height;
+    const size_t pb = planes_bytes(n);
+    const size_t sb = screen_x ? 2 * n * sizeof(int64_t) : 0;
+    if (int rc = ensure_scratch(c, pb + sb)) return rc;
+    Planes p = carve(c->scratch, n);
+    int64_t *dsx = screen_x ? reinterpret_cast<int64_t *>(static_cast<char *>(c->scratch) + pb) : nullptr;
+    int64_t *dsy = screen_x ? dsx + n : nullptr;
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    const void *src[7] = {r_in, g_in, b_in, sa_in, sb_in, sc_in, sctr_in};
+    void *dev[7] = {p.r, p.g, p.b, p.sa, p.sb, p.sc, p.sctr};
+    void *dst[7] = {r_out, g_out, b_out, sa_out, sb_out, sc_out, sctr_out};
+    for (int i = 0; i < 7; ++i) PTMI_HIP(c, hipMemcpy(dev[i], src[i], n * 4, hipMemcpyHostToDevice));
+    if (screen_x) {
+        PTMI_HIP(c, hipMemcpy(dsx, screen_x, n * sizeof(int64_t), hipMemcpyHostToDevice));
+        PTMI_HIP(c, hipMemcpy(dsy, screen_y, n * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    if (int rc = launch_render(c, p, camera, algorithm, bounce_limit, 1, width, height, height, height, 1, 0, dsx, dsy)) return rc;
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 7; ++i) PTMI_HIP(c, hipMemcpy(dst[i], dev[i], n * 4, hipMemcpyDeviceToHost));
+    return PTMI_OK;
+}
+
+int ptmi_get_stats(ptmi_ctx *c, ptmi_stats *out)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!out) return fail(c, PTMI_EINVAL, "out is NULL");
+    PTMI_HIP(c, hipSetDevice(c->device));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    unsigned long long live = 0; unsigned int iters = 0;
+    PTMI_HIP(c, hipMemcpy(&live, c->d_live, sizeof live, hipMemcpyDeviceToHost));
+    PTMI_HIP(c, hipMemcpy(&iters, c->d_iters, sizeof iters, hipMemcpyDeviceToHost));
+    out->live_bounces = live; out->nominal_bounces = c->nominal; out->samples = c->samples;
+    out->stream_iterations = iters;
+    out->last_render_ms = 0.0f;
+    if (c->timing && c->ev_valid) PTMI_HIP(c, hipEventElapsedTime(&out->last_render_ms, c->ev0, c->ev1));
+    return PTMI_OK;
+}
+
+int ptmi_reset_stats(ptmi_ctx *c)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    PTMI_HIP(c, hipSetDevice(c->device));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    PTMI_HIP(c, hipMemset(c->d_live, 0, sizeof(unsigned long long)));
+    PTMI_HIP(c, hipMemset(c->d_iters, 0, sizeof(unsigned int)));
+    c->nominal = 0; c->samples = 0;
+    return PTMI_OK;
+}
+
+static int eval_prims(ptmi_ctx *c, const void *prims, int words, const float *rays, int n,
+                      int32_t *is_just, float *t, float *normalp, bool sphere)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (n < 0 || (n > 0 && (!prims || !rays || !is_just || !t))) return fail(c, PTMI_EINVAL, "bad point-query arguments");
+    if (n == 0) return PTMI_OK;
+    PTMI_HIP(c, hipSetDevice(c->device));
+    const size_t nb = (size_t)n;
+    const size_t bytes = nb * (words * 4 + 6 * 4 + 4 + 4 + 6 * 4);
+    if (int rc = ensure_scratch(c, bytes)) return rc;
+    float *d_prims = static_cast<float *>(c->scratch);
+    float *d_rays = d_prims + nb * words;
+    int32_t *d_just = reinterpret_cast<int32_t *>(d_rays + nb * 6);
+    float *d_t = reinterpret_cast<float *>(d_just + nb);
+    float *d_np = d_t + nb;
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    PTMI_HIP(c, hipMemcpy(d_prims, prims, nb * words * 4, hipMemcpyHostToDevice));
+    PTMI_HIP(c, hipMemcpy(d_rays, rays, nb * 6 * 4, hipMemcpyHostToDevice));
+    if (sphere) PTMI_HIP(c, launch_eval_sphere(d_prims, d_rays, n, d_just, d_t, d_np, c->stream));
+    else        PTMI_HIP(c, launch_eval_plane(d_prims, d_rays, n, d_just, d_t, d_np, c->stream));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    PTMI_HIP(c, hipMemcpy(is_just, d_just, nb * 4, hipMemcpyDeviceToHost));
+    PTMI_HIP(c, hipMemcpy(t, d_t, nb * 4, hipMemcpyDeviceToHost));
+    if (normalp) PTMI_HIP(c, hipMemcpy(normalp, d_np, nb * 24, hipMemcpyDeviceToHost));
+    return PTMI_OK;
+}
+
+int ptmi_eval_distance_to_sphere(ptmi_ctx *c, const ptmi_sphere *spheres, const float *rays, int n,
+                                 int32_t *is_just, float *t, float *hit_normalp)
+{
+    return eval_prims(c, spheres, 10, rays, n, is_just, t, hit_normalp, true);
+}
+
+int ptmi_eval_distance_to_plane(ptmi_ctx *c, const ptmi_plane *planes, const float *rays, int n,
+                                int32_t *is_just, float *t, float *hit_normalp)
+{
+    return eval_prims(c, planes, 12, rays, n, is_just, t, hit_normalp, false);
+}
+
+int ptmi_eval_sincos(ptmi_ctx *c, const float *x, int n, float *sin_out, float *cos_out)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (n < 0 || (n > 0 && (!x || !sin_out || !cos_out))) return fail(c, PTMI_EINVAL, "bad sincos arguments");
+    if (n == 0) return PTMI_OK;
+    PTMI_HIP(c, hipSetDevice(c->device));
+    const size_t nb = (size_t)n;
+    if (int rc = ensure_scratch(c, nb * 12)) return rc;
+    float *dx = static_cast<float *>(c->scratch), *ds = dx + nb, *dc = ds + nb;
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    PTMI_HIP(c, hipMemcpy(dx, x, nb * 4, hipMemcpyHostToDevice));
+    PTMI_HIP(c, launch_eval_sincos(dx, n, ds, dc, c->stream));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    PTMI_HIP(c, hipMemcpy(sin_out, ds, nb * 4, hipMemcpyDeviceToHost));
+    PTMI_HIP(c, hipMemcpy(cos_out, dc, nb * 4, hipMemcpyDeviceToHost));
+    return PTMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// ptmi_kernels.h -- launch interface between the C ABI (ptmi_api.cpp) and the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ptmi_core.h"
+
+namespace ptmi {
+
+// Scene as staged into LDS, one float4 stream (see pack_scene in ptmi_api.cpp):
+//   [0, ns)                 sphere geometry   (cx, cy, cz, r*r)
+//   [ns, ns + 2 np)         plane geometry    (px, py, pz, 0) (nx, ny, nz, 0)
+//   [geom, geom + 2 (ns+np)) material         (cr, cg, cb, illuminance) (tag bits, p, p/pi, 1-p)
+struct SceneView {
+    const float4 *packed;      // device memory
+    int n_spheres, n_planes;
+    __host__ __device__ int geom_f4() const { return n_spheres + 2 * n_planes; }
+    __host__ __device__ int total_f4() const { return geom_f4() + 2 * (n_spheres + n_planes); }
+};
+
+struct Planes {
+    float *r, *g, *b;
+    uint32_t *sa, *sb, *sc, *sctr;
+};
+
+struct RenderArgs {
+    PrimaryUniforms cam;
+    SceneView scene;
+    Planes planes;
+    const int64_t *screen_x, *screen_y;   // optional explicit Matrix (V2 Int); NULL = implicit
+    int width, height;                    // whole image (screenWidth/Height)
+    int rows_local;                       // rows held by this context
+    int stripe_rows, n_parts, part;       // row-stripe partition
+    int bounce_limit, n_spp;
+    unsigned long long *live_counter;     // device counter, += live bounces
+    unsigned int *work_counter;           // device counter for dynamic pixel hand-out (variants)
+    unsigned int *stream_iterations;      // Streams: steps taken by the last sample (max over waves)
+};
+
+hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t stream);
+hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t stream);
+hipError_t launch_seed(Planes p, int width, int rows_local, int stripe_rows, int n_parts, int part,
+                       uint64_t seed0, bool clear_color, hipStream_t stream);
+hipError_t launch_create_with(Planes p, const uint32_t *w0, const uint32_t *w1, const uint32_t *w2,
+                              int64_t n, hipStream_t stream);
+hipError_t launch_eval_sphere(const float *spheres10, const float *rays, int n,
+                              int32_t *is_just, float *t, float *normalp, hipStream_t stream);
+hipError_t launch_eval_plane(const float *planes12, const float *rays, int n,
+                             int32_t *is_just, float *t, float *normalp, hipStream_t stream);
+hipError_t launch_eval_sincos(const float *x, int n, float *s, float *c, hipStream_t stream);
+
+}  // namespace ptmi

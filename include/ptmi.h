@@ -1,0 +1,190 @@
+/*
+ * ptmi.h -- C ABI of libptmi, the MI355X-native replacement for the one compute
+ * call of robbert-vdh/haskell-path-tracer:
+ *
+ *     dewit = runN (render config) screenPixels            (app/Main.hs:190)
+ *     \c (it, acc) -> (it + 1, dewit (scalar c) acc)        (app/Main.hs:191)
+ *
+ * plus the two array programs that create / replace the RNG planes
+ * (`run <$> initialOutput` app/Main.hs:155,306 ; `run <$> reseed ...` :231).
+ *
+ * The reference has no FFI for this path (the boundary is a Haskell closure,
+ * `type CompiledFunction`, app/Main.hs:83-84); these entry points are what a
+ * `foreign import ccall` module replacing line 190 binds (INTEGRATION.md shows it).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 (PTMI_OK) or a negative
+ *     PTMI_E* code; ptmi_last_error(ctx) holds the message.  Nothing throws or aborts.
+ *     (The reference surfaces failures as Haskell exceptions out of runN; the Haskell
+ *     wrapper turns a non-zero code into throwIO.)
+ *   - A RenderResult = Matrix (Color, SFC32) (src/Scene/Objects.hs:36) is SEVEN planes,
+ *     row-major [rows][width], x fastest (src/Util.hs:213-214): r, g, b (binary32) and
+ *     the SFC32 state a, b, c, counter (uint32) -- Accelerate's struct-of-arrays layout
+ *     as seen through A.toVectors (app/Main.hs:350).
+ *   - The colour planes hold a SUM over samples; averaging is the presenter's job
+ *     (app/assets/fs.glsl:12).
+ *   - A context may be entered from any OS thread (app/Main.hs:178-180 forks two bound
+ *     threads); calls on one context are serialised by an internal mutex.
+ */
+#ifndef PTMI_H
+#define PTMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTMI_VERSION 100   /* 0.1.0 */
+
+/* ---- error codes ------------------------------------------------------------ */
+enum {
+    PTMI_OK        =  0,
+    PTMI_EINVAL    = -1,   /* bad argument (null pointer, empty scene, size <= 0 ...)        */
+    PTMI_ENODEVICE = -2,   /* no HIP device / device index out of range                       */
+    PTMI_EHIP      = -3,   /* a HIP runtime call failed; message in ptmi_last_error          */
+    PTMI_ENOMEM    = -4,   /* device or host allocation failed                                */
+    PTMI_ESTATE    = -5,   /* call order violated (render before set_scene / resize ...)     */
+    PTMI_ELIMIT    = -6    /* scene larger than PTMI_MAX_PRIMITIVES                           */
+};
+
+/* data Algorithm = Streams | Inline                       (src/Scene/Trace.hs:68) */
+enum { PTMI_STREAMS = 0, PTMI_INLINE = 1 };
+
+/* data Brdf = Matte Float | Glossy Float                 (src/Scene/Objects.hs:77-87) */
+enum { PTMI_MATTE = 0, PTMI_GLOSSY = 1 };
+
+#define PTMI_MAX_PRIMITIVES 1024   /* spheres + planes staged in LDS per workgroup */
+
+/* ---- scene types: field order = src/Scene/Objects.hs ------------------------ */
+typedef struct ptmi_sphere {       /* data Sphere   Objects.hs:126-131, Material :90-100 */
+    float   position[3];
+    float   radius;
+    float   color[3];
+    float   illuminance;
+    int32_t brdf_tag;              /* PTMI_MATTE | PTMI_GLOSSY */
+    float   brdf_param;
+} ptmi_sphere;                     /* 10 words */
+
+typedef struct ptmi_plane {        /* data Plane    Objects.hs:103-108 */
+    float   position[3];
+    float   direction[3];          /* the normal; used as stored (Intersection.hs:64) */
+    float   color[3];
+    float   illuminance;
+    int32_t brdf_tag;
+    float   brdf_param;
+} ptmi_plane;                      /* 12 words */
+
+typedef struct ptmi_camera {       /* data Camera   Objects.hs:67-74 */
+    float   position[3];
+    float   rotation[3];           /* (roll, pitch, yaw) Euler angles */
+    int64_t fov;                   /* horizontal field of view, degrees; Haskell Int */
+} ptmi_camera;
+
+typedef struct ptmi_stats {
+    uint64_t live_bounces;         /* iterations that took computeRay (Trace.hs:374) since the last reset */
+    uint64_t nominal_bounces;      /* pixels x samples x bounce_limit since the last reset                  */
+    uint64_t samples;              /* pixels x samples                                                       */
+    float    last_render_ms;       /* device time of the last ptmi_render launch(es); 0 unless timing is on */
+    uint32_t stream_iterations;    /* Streams: steps of the last sample's awhile loop                        */
+} ptmi_stats;
+
+typedef struct ptmi_ctx ptmi_ctx;
+
+/* ---- lifetime ---------------------------------------------------------------- */
+int         ptmi_version(void);
+const char *ptmi_strerror(int code);
+/* Create a context on HIP device `device` (>= 0).  Fails with PTMI_ENODEVICE when the
+ * machine has no usable GPU: there is NO CPU fallback in this library. */
+int         ptmi_create(ptmi_ctx **out, int device);
+void        ptmi_destroy(ptmi_ctx *ctx);
+const char *ptmi_last_error(const ptmi_ctx *ctx);   /* ctx may be NULL: error of the last failed ptmi_create */
+
+/* ---- configuration ----------------------------------------------------------- */
+/* mainScene (src/Scene/World.hs:15-77) as run-time data.  Order is kept: checkHit folds
+ * over spheres then planes (src/Util.hs:156-158) and ties keep the earlier primitive. */
+int ptmi_set_scene(ptmi_ctx *ctx, const ptmi_sphere *spheres, int n_spheres,
+                   const ptmi_plane *planes, int n_planes);
+
+/* screenWidth / screenHeight (src/Util.hs:186-188) as run-time values.  Allocates the
+ * seven device planes the context owns (for the rows of its partition, see below) and
+ * zero-fills them. */
+int ptmi_resize(ptmi_ctx *ctx, int width, int height);
+
+/* Row-stripe partition for multi-GPU runs: the image is cut into stripes of `stripe_rows`
+ * rows dealt round-robin to `n_parts` contexts; this context is number `part`.  The context
+ * then holds ptmi_local_rows() rows, stored contiguously in ascending global order.
+ * Must be called before ptmi_resize.  Default: one part (the whole image). */
+int ptmi_set_partition(ptmi_ctx *ctx, int stripe_rows, int n_parts, int part);
+int ptmi_local_rows(const ptmi_ctx *ctx);                    /* rows held, or a negative code */
+int ptmi_global_row(const ptmi_ctx *ctx, int local_row);     /* image row of a held row       */
+
+/* Use caller-owned DEVICE planes (e.g. torch tensors) of ptmi_local_rows() x width elements
+ * instead of the context's own; pass all NULL to return to the owned planes. */
+int ptmi_bind_planes(ptmi_ctx *ctx, float *r, float *g, float *b,
+                     uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr);
+/* Launch on this HIP stream (a hipStream_t cast to void*; NULL = the context's own). */
+int ptmi_set_stream(ptmi_ctx *ctx, void *hip_stream);
+/* Record HIP events around every ptmi_render on the launch stream (ptmi_stats.last_render_ms). */
+int ptmi_set_timing(ptmi_ctx *ctx, int enabled);
+/* Kernel variant selection for measurements: 0 = default.  See DESIGN.md "kernel variants". */
+int ptmi_set_variant(ptmi_ctx *ctx, int variant);
+
+/* ---- state: initialOutput / genSeeds / reseed -------------------------------- */
+/* initialOutput (src/Util.hs:204-205): colour := 0, RNG := genSeeds.  genSeeds draws three
+ * words per pixel from OS entropy (src/Util.hs:122-127); here they come from a counter-based
+ * hash of (seed0, global pixel index) so that "the same RNG seed" is meaningful, then go
+ * through createWith (3-word sfc32 seeding).  Runs on the device. */
+int ptmi_init_output(ptmi_ctx *ctx, uint64_t seed0);
+/* reseed (src/Util.hs:134-135): keep colour, replace every RNG state. */
+int ptmi_reseed(ptmi_ctx *ctx, uint64_t seed0);
+/* createWith . use (src/Util.hs:125): three host word planes -> RNG states (colour untouched). */
+int ptmi_create_with(ptmi_ctx *ctx, const uint32_t *w0, const uint32_t *w1, const uint32_t *w2);
+/* Host <-> device copies of the held rows (synchronous). NULL plane pointers are skipped. */
+int ptmi_upload_state(ptmi_ctx *ctx, const float *r, const float *g, const float *b,
+                      const uint32_t *sa, const uint32_t *sb, const uint32_t *sc, const uint32_t *sctr);
+int ptmi_download_state(ptmi_ctx *ctx, float *r, float *g, float *b,
+                        uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr);
+int ptmi_download_color(ptmi_ctx *ctx, float *r, float *g, float *b);   /* what graphicsLoop reads, Main.hs:350 */
+
+/* ---- the hot path ------------------------------------------------------------- */
+/* Resident form: equivalent to n_spp successive applications of
+ *     render algorithm screenPixels camera            (src/Scene/Trace.hs:135-200)
+ * to the planes held by the context.  `bounce_limit` is the `15` of Trace.hs:200 /
+ * maxIterations (:80-81) made a parameter.  Asynchronous on the launch stream. */
+int ptmi_render(ptmi_ctx *ctx, const ptmi_camera *camera, int algorithm,
+                int bounce_limit, int n_spp);
+int ptmi_synchronize(ptmi_ctx *ctx);
+
+/* Compatibility form = exactly one call of the closure built by compileFor: host planes in,
+ * host planes out, one sample.  screen_x / screen_y are the two Int planes of the
+ * Matrix (V2 Int) argument (src/Util.hs:209-210) or NULL for the implicit x = column,
+ * y = row.  Pointers are borrowed for the duration of the call; in and out may alias.
+ * Ignores any partition: the whole width x height image is rendered. */
+int ptmi_render1(ptmi_ctx *ctx, const ptmi_camera *camera, int algorithm, int bounce_limit,
+                 int width, int height,
+                 const int64_t *screen_x, const int64_t *screen_y,
+                 const float *r_in, const float *g_in, const float *b_in,
+                 const uint32_t *sa_in, const uint32_t *sb_in, const uint32_t *sc_in, const uint32_t *sctr_in,
+                 float *r_out, float *g_out, float *b_out,
+                 uint32_t *sa_out, uint32_t *sb_out, uint32_t *sc_out, uint32_t *sctr_out);
+
+int ptmi_get_stats(ptmi_ctx *ctx, ptmi_stats *out);   /* synchronises the launch stream */
+int ptmi_reset_stats(ptmi_ctx *ctx);
+
+/* ---- point queries (the reference's unit-test surface) ------------------------ */
+/* Evaluates distanceTo / hit (src/Scene/Intersection.hs:16-64) on the DEVICE for n independent
+ * cases -- ray i against primitive i -- the way test/Scene/Intersection/Tests.hs:122-123
+ * evaluates single expressions through the backend.  rays: n x 6 floats (origin, direction).
+ * Outputs (host): is_just[n], t[n], hit_normalp[n x 6] (position, normal); the last may be NULL. */
+int ptmi_eval_distance_to_sphere(ptmi_ctx *ctx, const ptmi_sphere *spheres, const float *rays, int n,
+                                 int32_t *is_just, float *t, float *hit_normalp);
+int ptmi_eval_distance_to_plane(ptmi_ctx *ctx, const ptmi_plane *planes, const float *rays, int n,
+                                int32_t *is_just, float *t, float *hit_normalp);
+/* sin/cos of the device math used by anglesToQuaternion, for pinning against libm. */
+int ptmi_eval_sincos(ptmi_ctx *ctx, const float *x, int n, float *sin_out, float *cos_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTMI_H */
