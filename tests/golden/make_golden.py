@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz.
+
+PROVENANCE: "self-oracle".  The reference (Haskell + Accelerate + LLVM 9) cannot be built or run in
+this environment and holds no golden images or vectors for the render path, so these planes come
+from the repo's own CPU oracle (oracle/pt_oracle.c) at the commit that introduced them.  They pin
+the oracle (and through it the HIP path) against silent drift; they do NOT pin it against GHC.
+The intersection path IS pinned against the reference's own tests (tests/refprops.py).
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import __graft_entry__ as graft  # noqa: E402
+
+CASES = {
+    # name: (scene, width, height, bounce_limit, n_spp, algorithm)
+    "main_64x48_l4_s1": ("main", 64, 48, 4, 1, "inline"),
+    "main_64x48_l15_s2": ("main", 64, 48, 15, 2, "inline"),
+    "s16_80x45_l8_s4": ("s16", 80, 45, 8, 4, "inline"),
+    "main_64x48_streams_s2": ("main", 64, 48, 1 << 16, 2, "streams"),
+}
+SEED0 = 0x5EED1234
+
+
+def main():
+    pkg, ora = graft.load_package(), graft.load_oracle()
+    cam = pkg.world.initial_camera()
+    for name, (scene, w, h, limit, spp, alg) in CASES.items():
+        sp, pl = pkg.world.main_scene() if scene == "main" else pkg.world.scene16()
+        seeds = ora.gen_seeds(SEED0, 0, w * h)
+        start = [np.zeros((h, w), np.float32)] * 3 + [s.reshape(h, w) for s in seeds]
+        if alg == "inline":
+            out, live = ora.render_inline(sp, pl, cam, w, h, limit, spp, start)
+        else:
+            out, live = ora.render_streams(sp, pl, cam, w, h, limit, spp, start)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), scene=scene, width=w, height=h, limit=limit,
+                            spp=spp, algorithm=alg, seed0=SEED0, live=live,
+                            spheres=sp, planes=pl, camera=cam,
+                            **{"in_%d" % i: a for i, a in enumerate(start)},
+                            **{"out_%d" % i: a for i, a in enumerate(out)})
+        print(name, "live bounces", live)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,66 @@
+"""The C-ABI library loads and exports every symbol include/ptmi.h declares (no compute calls
+without a GPU); the binding, the header and the library agree on the symbol set."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "ptmi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ptmi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    syms = header_symbols()
+    for must in ("ptmi_create", "ptmi_destroy", "ptmi_set_scene", "ptmi_resize", "ptmi_render", "ptmi_render1",
+                 "ptmi_init_output", "ptmi_reseed", "ptmi_download_color", "ptmi_last_error"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = ctypes.CDLL(pkg._build.LIB)
+    for name in header_symbols():
+        assert hasattr(lib, name), "libptmi.so does not export %s" % name
+
+
+def test_binding_covers_exactly_the_header(pkg):
+    assert sorted(pkg.SYMBOLS) == header_symbols()
+    pkg.load_library()          # types every symbol; AttributeError if one is missing
+
+
+def test_version_and_strerror(pkg):
+    lib = pkg.load_library()
+    assert lib.ptmi_version() == 100
+    assert lib.ptmi_strerror(0) == b"ok" and lib.ptmi_strerror(-2) == b"no usable HIP device"
+
+
+def test_struct_layouts_match_header(pkg):
+    w = pkg.world
+    assert w.SPHERE_DTYPE.itemsize == 40 and w.PLANE_DTYPE.itemsize == 48 and w.CAMERA_DTYPE.itemsize == 32
+    assert w.CAMERA_DTYPE.fields["fov"][1] == 24 and w.PLANE_DTYPE.fields["direction"][1] == 12
+    assert w.SPHERE_DTYPE.fields["brdf_tag"][1] == 32
+
+
+def test_no_gpu_means_loud_failure_not_fallback(pkg):
+    """Without a device the product refuses to work (PTMI_ENODEVICE); it never computes on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.PtmiError) as e:
+        pkg.Context(0)
+    assert e.value.code == -2
+
+
+def test_product_does_not_reference_the_oracle():
+    """oracle/ is test infrastructure: nothing under the package may import, link or call it."""
+    pkg_dir = os.path.join(ROOT, "haskell-path-tracer_amd")
+    for dirpath, _dirs, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", ".hs")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "import oracle" not in text and "pt_oracle" not in text and "libptoracle" not in text, f

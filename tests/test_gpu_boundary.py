@@ -1,0 +1,219 @@
+"""The drop-in boundary on the device: compat entry (= the closure compileFor builds, app/Main.hs:188-191),
+resident entry, state programs (initialOutput / reseed / createWith), partitions, error behaviour."""
+import numpy as np
+import pytest
+
+from conftest import assert_planes_equal, initial_planes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def fresh(pkg):
+    c = pkg.Context(0)
+    yield c
+    c.close()
+
+
+def test_render1_is_one_application_of_render(ctx, pkg, ora):
+    """host planes in -> new host planes out, one sample; inputs are not modified."""
+    sp, pl = pkg.world.main_scene()
+    cam = pkg.world.initial_camera()
+    w, h = 100, 75
+    start = initial_planes(ora, w, h)
+    keep = [a.copy() for a in start]
+    ctx.set_scene(sp, pl)
+    out1 = ctx.render1(cam, 15, w, h, start)
+    assert_planes_equal(start, keep, "inputs untouched")
+    want1, _ = ora.render_inline(sp, pl, cam, w, h, 15, 1, start)
+    assert_planes_equal(out1, want1, "render1 #1")
+    out2 = ctx.render1(cam, 15, w, h, out1)                       # (it + 1, dewit (scalar c) acc)
+    want2, _ = ora.render_inline(sp, pl, cam, w, h, 15, 2, start)
+    assert_planes_equal(out2, want2, "render1 #2")
+
+
+def test_render1_with_explicit_screen_pixels(ctx, pkg, ora):
+    """The Matrix (V2 Int) argument (Util.hs:209-210): screenPixels gives the implicit result; a flipped
+    matrix renders the mirrored image with the un-mirrored seeds (generality of render's first argument)."""
+    sp, pl = pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    w, h = 64, 40
+    start = initial_planes(ora, w, h)
+    ctx.set_scene(sp, pl)
+    sx, sy = pkg.world.screen_pixels(w, h)
+    implicit = ctx.render1(cam, 8, w, h, start)
+    explicit = ctx.render1(cam, 8, w, h, start, screen=(sx, sy))
+    assert_planes_equal(explicit, implicit, "screenPixels")
+    flipped = (np.ascontiguousarray(sx[:, ::-1]), sy)
+    got = ctx.render1(cam, 8, w, h, start, screen=flipped)
+    want, _ = ora.render_inline(sp, pl, cam, w, h, 8, 1, start, screen=flipped)
+    assert_planes_equal(got, want, "flipped screen")
+
+
+def test_resident_render_equals_repeated_render1(ctx, pkg, ora):
+    sp, pl = pkg.world.main_scene()
+    cam = pkg.world.initial_camera()
+    w, h = 80, 50
+    start = initial_planes(ora, w, h)
+    ctx.set_scene(sp, pl)
+    ctx.resize(w, h)
+    ctx.upload_state(*start)
+    ctx.render(cam, 15, 3)
+    resident = ctx.download_state()
+    acc = start
+    for _ in range(3):
+        acc = ctx.render1(cam, 15, w, h, acc)
+    assert_planes_equal(resident, acc, "render(n_spp=3) vs 3 x render1")
+    # and split launches compose: 1 + 2
+    ctx.upload_state(*start)
+    ctx.render(cam, 15, 1)
+    ctx.render(cam, 15, 2)
+    assert_planes_equal(ctx.download_state(), acc, "1 + 2 spp")
+
+
+def test_init_output_reseed_create_with(ctx, pkg, ora):
+    """initialOutput / reseed (Util.hs:134-135, :204-205) and createWith (Util.hs:125) on the device."""
+    w, h = 70, 33
+    ctx.set_scene(*pkg.world.main_scene())
+    ctx.resize(w, h)
+    ctx.init_output(0xABCDEF0123)
+    got = ctx.download_state()
+    seeds = ora.gen_seeds(0xABCDEF0123, 0, w * h)
+    assert all(np.all(p == 0) for p in got[:3])
+    for a, b in zip(got[3:], seeds):
+        assert np.array_equal(a.reshape(-1), b)
+    ctx.render(pkg.world.initial_camera(), 4, 1)
+    col = ctx.download_color()
+    ctx.reseed(77)
+    got = ctx.download_state()
+    assert_planes_equal(got[:3], col, "reseed keeps colour")
+    for a, b in zip(got[3:], ora.gen_seeds(77, 0, w * h)):
+        assert np.array_equal(a.reshape(-1), b)
+    r = np.random.default_rng(3)
+    words = [r.integers(0, 2 ** 32, w * h, dtype=np.uint32) for _ in range(3)]
+    ctx.create_with(*words)
+    got = ctx.download_state()
+    for i in (0, 1, 1234, w * h - 1):
+        assert tuple(int(p.reshape(-1)[i]) for p in got[3:]) == ora.sfc32_seed3(words[0][i], words[1][i], words[2][i])
+
+
+@pytest.mark.parametrize("n_parts,stripe,h", [(2, 8, 64), (3, 4, 50), (8, 8, 61)])
+def test_row_stripe_partitions_reproduce_the_whole_image(pkg, ora, n_parts, stripe, h):
+    """Every part renders only its rows, from seeds of the GLOBAL pixel index; stitched = unpartitioned."""
+    sp, pl = pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    w = 48
+    start = initial_planes(ora, w, h)
+    want, _ = ora.render_inline(sp, pl, cam, w, h, 8, 2, start)
+    stitched = [np.zeros_like(p) for p in want]
+    for part in range(n_parts):
+        with pkg.Context(0) as c:
+            c.set_scene(sp, pl)
+            c.set_partition(stripe, n_parts, part)
+            c.resize(w, h)
+            rows = c.global_rows()
+            c.init_output(0x5EED1234)
+            seeded = c.download_state()
+            for a, b in zip(seeded[3:], start[3:]):
+                assert np.array_equal(a, b[rows])
+            c.render(cam, 8, 2)
+            for dst, src in zip(stitched, c.download_state()):
+                dst[rows] = src
+    assert_planes_equal(stitched, want, "%d stripes" % n_parts)
+
+
+def test_edge_sizes_and_degenerate_counts(ctx, pkg, ora):
+    sp, pl = pkg.world.main_scene()
+    cam = pkg.world.initial_camera()
+    ctx.set_scene(sp, pl)
+    for (w, h, limit, spp) in [(1, 1, 15, 1), (3, 2, 0, 4), (5, 7, 15, 0), (257, 3, 1, 1)]:
+        start = initial_planes(ora, w, h)
+        start[1][:] = 0.25
+        ctx.resize(w, h)
+        ctx.upload_state(*start)
+        ctx.render(cam, limit, spp)
+        want, _ = ora.render_inline(sp, pl, cam, w, h, limit, spp, start)
+        assert_planes_equal(ctx.download_state(), want, str((w, h, limit, spp)))
+
+
+def test_single_primitive_and_planes_only_scenes(ctx, pkg, ora):
+    """expMinWith's one-element case (Util.hs:173) and a scene without spheres."""
+    sp, pl = pkg.world.main_scene()
+    cam = pkg.world.initial_camera()
+    w, h = 40, 30
+    start = initial_planes(ora, w, h)
+    for s, p in [(sp[:1], pl[:0]), (sp[:0], pl), (sp[:0], pl[:1]), (sp[3:5], pl[:0])]:
+        ctx.set_scene(s, p)
+        ctx.resize(w, h)
+        ctx.upload_state(*start)
+        ctx.render(cam, 6, 2)
+        want, _ = ora.render_inline(s, p, cam, w, h, 6, 2, start)
+        assert_planes_equal(ctx.download_state(), want, "scene %d+%d" % (len(s), len(p)))
+
+
+def test_other_cameras(ctx, pkg, ora):
+    sp, pl = pkg.world.scene16()
+    ctx.set_scene(sp, pl)
+    w, h = 64, 36
+    start = initial_planes(ora, w, h)
+    for cam in [pkg.world.camera((0, 0, 0), (0, 0, 0), 90), pkg.world.camera((3, 1, 2), (1.0, 2.5, -0.7), 60),
+                pkg.world.camera((1, -1.6, -4.8), (250.0, -130.0, 999.0), 120)]:       # sin/cos beyond |x| = 120
+        ctx.resize(w, h)
+        ctx.upload_state(*start)
+        ctx.render(cam, 8, 1)
+        want, _ = ora.render_inline(sp, pl, cam, w, h, 8, 1, start)
+        assert_planes_equal(ctx.download_state(), want, "camera %s" % cam)
+
+
+def test_error_behaviour(fresh, pkg):
+    """0 / negative codes + message, nothing throws across the ABI, no abort (SURVEY.md 8b 'Errors')."""
+    c, cam = fresh, pkg.world.initial_camera()
+    sp, pl = pkg.world.main_scene()
+    with pytest.raises(pkg.PtmiError) as e:
+        c.render(cam, 8, 1)
+    assert e.value.code == -5                      # PTMI_ESTATE: no scene
+    with pytest.raises(pkg.PtmiError) as e:
+        c.set_scene(sp[:0], pl[:0])
+    assert e.value.code == -1                      # empty scene = expMinWith [] (Util.hs:172)
+    c.set_scene(sp, pl)
+    with pytest.raises(pkg.PtmiError) as e:
+        c.render(cam, 8, 1)
+    assert e.value.code == -5                      # no resize yet
+    with pytest.raises(pkg.PtmiError) as e:
+        c.resize(0, 10)
+    assert e.value.code == -1
+    c.resize(8, 8)
+    with pytest.raises(pkg.PtmiError) as e:
+        c.render(cam, -1, 1)
+    assert e.value.code == -1
+    bad = sp.copy()
+    bad["brdf_tag"][0] = 7
+    with pytest.raises(pkg.PtmiError) as e:
+        c.set_scene(bad, pl)
+    assert e.value.code == -1
+    with pytest.raises(pkg.PtmiError) as e:
+        pkg.Context(10 ** 6)
+    assert e.value.code == -2
+    c.render(cam, 8, 1)                            # still usable after errors
+    c.synchronize()
+
+
+def test_context_is_usable_from_other_threads(ctx, pkg, ora):
+    """The closure may be forced on any of three OS threads (app/Main.hs:178-180)."""
+    import threading
+    sp, pl = pkg.world.main_scene()
+    cam = pkg.world.initial_camera()
+    w, h = 32, 32
+    start = initial_planes(ora, w, h)
+    ctx.set_scene(sp, pl)
+    want, _ = ora.render_inline(sp, pl, cam, w, h, 8, 1, start)
+    results = {}
+
+    def work(i):
+        results[i] = ctx.render1(cam, 8, w, h, start)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for i in range(4):
+        assert_planes_equal(results[i], want, "thread %d" % i)

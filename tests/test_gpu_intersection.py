@@ -1,0 +1,115 @@
+"""The reference's 8 intersection properties (test/Scene/Intersection/Tests.hs:32-121) evaluated on
+the DEVICE through ptmi_eval_distance_to_{sphere,plane}, the way the reference evaluates single
+expressions through its backend (Tests.hs:122-123) -- and bit-compared with the CPU oracle."""
+import numpy as np
+import pytest
+
+import refprops as rp
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def _rays(cases):
+    return np.array([list(c["origin"]) + list(c["direction"]) for c in cases], F)
+
+
+def eval_spheres(ctx, pkg, cases):
+    sph = np.array([rp.make_sphere(pkg.world.SPHERE_DTYPE, c["pos"], c["radius"]) for c in cases])
+    return sph, ctx.eval_distance_to_sphere(sph, _rays(cases))
+
+
+def eval_planes(ctx, pkg, cases):
+    pl = np.array([rp.make_plane(pkg.world.PLANE_DTYPE, c["pos"], c["nor"]) for c in cases])
+    return pl, ctx.eval_distance_to_plane(pl, _rays(cases))
+
+
+def test_sphere_intersection_position(ctx, pkg):
+    cases = list(rp.sphere_intersection_cases())
+    _, (just, t, nrm) = eval_spheres(ctx, pkg, cases)
+    assert np.all(just == 1)
+    for c, hp in zip(cases, nrm[:, :3]):
+        assert tuple(rp.round_to(3, v) for v in hp) == c["expect_hit_pos_3dp"], c
+
+
+def test_sphere_distance(ctx, pkg):
+    cases = list(rp.sphere_distance_cases())
+    _, (just, t, _) = eval_spheres(ctx, pkg, cases)
+    assert np.all(just == 1)
+    for c, tt in zip(cases, t):
+        assert rp.round_to(1, tt) == c["expect_t_1dp"], (c, tt)
+
+
+@pytest.mark.parametrize("gen", [rp.sphere_backface_cases, rp.sphere_backwards_cases])
+def test_sphere_nothing(ctx, pkg, gen):
+    _, (just, _, _) = eval_spheres(ctx, pkg, list(gen()))
+    assert np.all(just == 0)
+
+
+@pytest.mark.parametrize("gen", [rp.plane_straight_cases, rp.plane_angle_cases])
+def test_plane_continuous(ctx, pkg, gen):
+    cases = list(gen())
+    _, (just, t, _) = eval_planes(ctx, pkg, cases)
+    for c, j, tt in zip(cases, just, t):
+        assert bool(j) == (c["expect"] is not None), c
+        if j:
+            assert tt == c["expect"], (c, tt)          # exact, as the reference's `===`
+
+
+@pytest.mark.parametrize("gen", [rp.plane_straight_backface_cases, rp.plane_angle_backface_cases])
+def test_plane_backface(ctx, pkg, gen):
+    _, (just, _, _) = eval_planes(ctx, pkg, list(gen()))
+    assert np.all(just == 0)
+
+
+def test_device_equals_oracle_bitwise_on_random_rays(ctx, pkg, ora):
+    """distanceTo + hit for random rays/primitives: device == oracle, bit for bit (incl. Nothing)."""
+    r = np.random.default_rng(99)
+    n = 3000
+    o = r.uniform(-20, 20, (n, 3)).astype(F)
+    d = r.normal(0, 1, (n, 3)).astype(F)
+    d = np.array([rp.l_normalize(v) for v in d], F)
+    rays = np.concatenate([o, d], 1)
+    sph = np.array([rp.make_sphere(pkg.world.SPHERE_DTYPE, p, rad) for p, rad in
+                    zip(r.uniform(-20, 20, (n, 3)).astype(F), r.uniform(0.1, 15, n).astype(F))])
+    just, t, nrm = ctx.eval_distance_to_sphere(sph, rays)
+    hits = 0
+    for i in range(n):
+        want = ora.distance_to_sphere(o[i], d[i], sph[i])
+        assert bool(just[i]) == (want is not None)
+        if want is not None:
+            hits += 1
+            assert t[i].view(np.uint32) == want.view(np.uint32)
+            pos, nor, _ = ora.hit_sphere(o[i], d[i], want, sph[i])
+            assert np.array_equal(nrm[i, :3].view(np.uint32), pos.view(np.uint32))
+            assert np.array_equal(nrm[i, 3:].view(np.uint32), nor.view(np.uint32))
+    assert hits > 50
+    pl = np.array([rp.make_plane(pkg.world.PLANE_DTYPE, p, nn) for p, nn in
+                   zip(r.uniform(-20, 20, (n, 3)).astype(F), r.normal(0, 1, (n, 3)).astype(F))])
+    just, t, nrm = ctx.eval_distance_to_plane(pl, rays)
+    for i in range(n):
+        want = ora.distance_to_plane(o[i], d[i], pl[i])
+        assert bool(just[i]) == (want is not None)
+        if want is not None:
+            assert t[i].view(np.uint32) == want.view(np.uint32)
+            assert np.array_equal(nrm[i, 3:], pl[i]["direction"])
+
+
+def test_device_sincos_equals_oracle_and_libm(ctx, ora):
+    """The device's sin/cos (binary64 evaluation of glibc's algorithm) == oracle == host libm, bitwise."""
+    r = np.random.default_rng(5)
+    x = np.concatenate([
+        r.uniform(-np.pi / 2, np.pi / 2, 200000), r.uniform(-130, 130, 50000), r.normal(0, 1e5, 20000),
+        10.0 ** r.uniform(-38, 38, 20000), -(10.0 ** r.uniform(-38, 38, 20000)),
+        [0.0, -0.0, 0.75, 0.7499999, 2.0 ** -12, 119.99999, 120.0, 1e30, 3.4e38, np.inf, -np.inf, np.nan],
+    ]).astype(F)
+    s, c = ctx.eval_sincos(x)
+    sub = r.choice(x.size - 3, 20000, replace=False)
+    so, co = ora.sincos_array(x[sub])
+    assert np.array_equal(s[sub].view(np.uint32), so.view(np.uint32))
+    assert np.array_equal(c[sub].view(np.uint32), co.view(np.uint32))
+    with np.errstate(invalid="ignore"):
+        # numpy's float32 sin/cos are not glibc's; compare through the oracle only, plus sanity vs float64
+        assert np.nanmax(np.abs(s[:-3] - np.sin(x[:-3].astype(np.float64)))) < 1e-6
+        assert np.nanmax(np.abs(c[:-3] - np.cos(x[:-3].astype(np.float64)))) < 1e-6
+    assert np.all(np.isnan(s[-3:])) and np.all(np.isnan(c[-3:]))
