@@ -14,7 +14,7 @@ LIB = os.path.join(HERE, "libptmi.so")
 SOURCES = ["ptmi_api.cpp", "ptmi_kernels.hip"]
 HEADERS = ["ptmi_core.h", "ptmi_kernels.h", os.path.join("..", "..", "include", "ptmi.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-fno-fast-math", "-Wall"]
+         "-fno-fast-math", "-fno-slp-vectorize", "-DPTMI_SINCOS_FUSED=1", "-Wall"]
 
 
 def hipcc_path():

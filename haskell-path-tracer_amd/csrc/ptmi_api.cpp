@@ -143,7 +143,7 @@ void pack_scene(const ptmi_sphere *sph, int ns, const ptmi_plane *pl, int np, st
     }
     auto mat = [&](const float *color, float illum, int32_t tag, float p) {
         out[k++] = float4{color[0], color[1], color[2], illum};
-        out[k++] = float4{u2f((uint32_t)tag), p, p / kPi, 1.0f - p};
+        out[k++] = float4{u2f((uint32_t)tag), p, p / kPi, 0.5f * (1.0f - p)};
     };
     for (int i = 0; i < ns; ++i) mat(sph[i].color, sph[i].illuminance, sph[i].brdf_tag, sph[i].brdf_param);
     for (int j = 0; j < np; ++j) mat(pl[j].color, pl[j].illuminance, pl[j].brdf_tag, pl[j].brdf_param);

@@ -96,7 +96,15 @@ __host__ __device__ __noinline__ inline Reduced sincos_reduce_large(uint32_t xi)
 // the reduction (n, x) and differ only in which of the two polynomials they return; for
 // |y| < 0.75 glibc skips the reduction, which is the n = 0 case of the general path
 // (x - 0*hpi == x exactly), so one code path serves both.
-PTMI_HD void sincos(float y, float &sn, float &cs)
+//
+// FUSED = false is the literal restatement (every binary64 operation rounded on its own, like
+// glibc's non-FMA build).  FUSED = true contracts the a*b+c of the two POLYNOMIALS into binary64
+// FMAs (15 instead of 22 f64 operations; the argument reduction stays unfused); it is used by the kernels only because tools/verify_sincos.hip has compared the
+// two on the device for ALL 2^32 binary32 arguments and found them bit-identical after the final
+// rounding to binary32 (profiles/r01_verify_sincos.txt) -- glibc's own FMA build (`__sinf_fma`,
+// the variant x86-64 hosts with FMA dispatch to) is the same kind of contraction.
+template <bool FUSED>
+PTMI_HD void sincos_t(float y, float &sn, float &cs)
 {
     const uint32_t bits = f2u(y);
     const uint32_t top = (bits >> 20) & 0x7ff;          // abstop12
@@ -105,7 +113,7 @@ PTMI_HD void sincos(float y, float &sn, float &cs)
     if (top < 0x42f) {                                   // |y| < 120: reduce_fast
         double r = x * 0x1.45F306DC9C883p+23;
         n = ((int32_t)r + 0x800000) >> 24;
-        x = x - (double)n * 0x1.921FB54442D18p0;
+        x = x - (double)n * 0x1.921FB54442D18p0;        // never contracted: a fused reduction changes 34 results
         m = n;
     } else if (top < 0x7f8) {
         const Reduced red = sincos_reduce_large(bits);
@@ -118,38 +126,64 @@ PTMI_HD void sincos(float y, float &sn, float &cs)
     const double x2 = x * x;
     // x * sign[m & 3], sign = {1,-1,-1,1}: an exact sign flip
     const double xs = ((m + 1) & 2) ? -x : x;
-    // sine-type polynomial (identical coefficients in both table rows)
-    const double x3 = xs * x2;
-    const double s1 = 0x1.1107605230bc4p-7 + x2 * -0x1.994eb3774cf24p-13;
-    const double x7 = x3 * x2;
-    const double s = xs + x3 * -0x1.555545995a603p-3;
-    const float S = (float)(s + x7 * s1);
-    // cosine-type polynomial; table row 1 (m & 2) negates every coefficient = negates the result
-    const double x4 = x2 * x2;
-    const double c2 = -0x1.6c087e89a359dp-10 + x2 * 0x1.99343027bf8c3p-16;
-    const double c1 = 0x1p0 + x2 * -0x1.ffffffd0c621cp-2;
-    const double x6 = x4 * x2;
-    const double c = c1 + x4 * 0x1.55553e1068f19p-5;
-    const float Cp = (float)(c + x6 * c2);
+    float S, Cp;
+    if (FUSED) {
+        const double x3 = xs * x2;
+        const double s1 = __builtin_fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+        const double x7 = x3 * x2;
+        const double s = __builtin_fma(x3, -0x1.555545995a603p-3, xs);
+        S = (float)__builtin_fma(x7, s1, s);
+        const double x4 = x2 * x2;
+        const double c2 = __builtin_fma(x2, 0x1.99343027bf8c3p-16, -0x1.6c087e89a359dp-10);
+        const double c1 = __builtin_fma(x2, -0x1.ffffffd0c621cp-2, 0x1p0);
+        const double x6 = x4 * x2;
+        const double c = __builtin_fma(x4, 0x1.55553e1068f19p-5, c1);
+        Cp = (float)__builtin_fma(x6, c2, c);
+    } else {
+        // sine-type polynomial (identical coefficients in both table rows)
+        const double x3 = xs * x2;
+        const double s1 = 0x1.1107605230bc4p-7 + x2 * -0x1.994eb3774cf24p-13;
+        const double x7 = x3 * x2;
+        const double s = xs + x3 * -0x1.555545995a603p-3;
+        S = (float)(s + x7 * s1);
+        // cosine-type polynomial; table row 1 (m & 2) negates every coefficient = negates the result
+        const double x4 = x2 * x2;
+        const double c2 = -0x1.6c087e89a359dp-10 + x2 * 0x1.99343027bf8c3p-16;
+        const double c1 = 0x1p0 + x2 * -0x1.ffffffd0c621cp-2;
+        const double x6 = x4 * x2;
+        const double c = c1 + x4 * 0x1.55553e1068f19p-5;
+        Cp = (float)(c + x6 * c2);
+    }
     const float C = (m & 2) ? -Cp : Cp;
     sn = (n & 1) ? C : S;
     cs = (n & 1) ? S : C;
     if (top < 0x398) { sn = y; cs = 1.0f; }              // |y| < 2^-12
 }
 
-// src/Util.hs:55-67
-PTMI_HD Quat angles_to_quaternion(V3 angles)
+#ifndef PTMI_SINCOS_FUSED
+#define PTMI_SINCOS_FUSED 0
+#endif
+PTMI_HD void sincos(float y, float &sn, float &cs) { sincos_t<PTMI_SINCOS_FUSED != 0>(y, sn, cs); }
+
+// anglesToQuaternion (src/Util.hs:55-67) from the three HALF angles (yaw*0.5 etc. already formed)
+PTMI_HD Quat quaternion_from_half_angles(float half_roll, float half_pitch, float half_yaw)
 {
     float sr, cr, sp, cp, sy, cy;
-    sincos(angles.x * 0.5f, sr, cr);    // roll
-    sincos(angles.y * 0.5f, sp, cp);    // pitch
-    sincos(angles.z * 0.5f, sy, cy);    // yaw
+    sincos(half_roll, sr, cr);
+    sincos(half_pitch, sp, cp);
+    sincos(half_yaw, sy, cy);
     Quat q;
     q.w   = cy * cp * cr + sy * sp * sr;
     q.v.x = cy * cp * sr - sy * sp * cr;
     q.v.y = sy * cp * sr + cy * sp * cr;
     q.v.z = sy * cp * cr - cy * sp * sr;
     return q;
+}
+
+// src/Util.hs:55-67
+PTMI_HD Quat angles_to_quaternion(V3 angles)
+{
+    return quaternion_from_half_angles(angles.x * 0.5f, angles.y * 0.5f, angles.z * 0.5f);
 }
 
 // ---- SFC32 (sfc-random-accelerate; PractRand sfc32) ---------------------------------

@@ -11,7 +11,7 @@ namespace ptmi {
 // Scene as staged into LDS, one float4 stream (see pack_scene in ptmi_api.cpp):
 //   [0, ns)                 sphere geometry   (cx, cy, cz, r*r)
 //   [ns, ns + 2 np)         plane geometry    (px, py, pz, 0) (nx, ny, nz, 0)
-//   [geom, geom + 2 (ns+np)) material         (cr, cg, cb, illuminance) (tag bits, p, p/pi, 1-p)
+//   [geom, geom + 2 (ns+np)) material         (cr, cg, cb, illuminance) (tag bits, p, p/pi, (1-p)/2)
 struct SceneView {
     const float4 *packed;      // device memory
     int n_spheres, n_planes;

@@ -21,43 +21,74 @@ constexpr int kBlock = 256;
 
 struct HitSel { float t; int idx; bool just; };
 
+// Correctly rounded binary32 square root (== IEEE sqrtf, which is what the reference's `sqrt`
+// lowers to) without the compiler's always-on denormal scaling: v_sqrt_f32 is within 1 ulp, two
+// exact FMA residuals pick the neighbour.  The residual test needs x == 0 or x >= 2^-96; if ANY
+// lane of the wave holds a smaller positive x the whole wave takes the compiler's scaled sequence.
+__device__ __forceinline__ float sqrt_rn(float x)
+{
+    const bool tiny = (f2u(x) - 1u) < (0x0f800000u - 1u);          // 0 < x < 2^-96
+    if (__builtin_expect(__any(tiny), 0)) return __builtin_sqrtf(x);
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = u2f(f2u(s) - 1u), s_up = u2f(f2u(s) + 1u);
+    const float e_dn = __builtin_fmaf(-s_dn, s, x);
+    const float e_up = __builtin_fmaf(-s_up, s, x);
+    float r = (e_dn <= 0.0f) ? s_dn : s;
+    r = (e_up > 0.0f) ? s_up : r;
+    return r;
+}
+
 // checkHit (Trace.hs:443-447): mapScene over spheres ++ planes (Util.hs:156-158), then
 // expMinWith (Util.hs:171-178): left fold keeping the accumulated element iff keyA <= keyB.
 // The reference builds every hit record and selects; selecting the index first and building
 // one record afterwards gives the same value.
+//
+// Shape for the SIMD: the cheap part of every test (16 f32 operations for a sphere) runs for all
+// lanes; the square root / division and the fold update run only when some lane of the wave can
+// still be hit (wave-uniform branches on __any), which is the common case to skip once rays are
+// incoherent and primitives are small.  best_key starts as NaN so that element 0 always replaces
+// the accumulator (`NaN <= key` is false), which is expMinWith seeding the fold with its head.
 template <typename ScenePtr>
 __device__ __forceinline__ HitSel check_hit(ScenePtr S, int ns, int np, V3 o, V3 d)
 {
-    HitSel best; best.t = kInfinite; best.idx = 0; best.just = false;
-    float best_key = 0.0f;
+    HitSel best; best.t = 0.0f; best.idx = 0; best.just = false;
+    float best_key = __builtin_nanf("");
+    float4 g = S[0];
     for (int i = 0; i < ns; ++i) {
+        const float4 g_next = S[i + 1];                      // prefetch; S has a readable tail element
         // distanceTo @Sphere (Intersection.hs:39-48)
-        const float4 g = S[i];
         const V3 l = mk(g.x, g.y, g.z) - o;
         const float tca = dot(l, d);
         const float d2 = dot(l, l) - (tca * tca);
-        const float r2 = g.w;                                // rad ** 2, squared at upload
-        bool just = false; float t = 0.0f;
-        if (!(tca < 0.0f || d2 > r2)) {
-            const float thc = __builtin_sqrtf(r2 - d2);
-            t = tca - thc;                                   // min t0 t1 == t0 (thc >= 0 or NaN)
-            just = !(t < 0.0f);
+        const float x = g.w - d2;                            // rad ** 2 - d2 (rad ** 2 squared at upload)
+        // Nothing iff tca < 0 || d2 > rad**2 || t < 0;  d2 > r2 <=> r2 - d2 < 0 (exact: gradual underflow)
+        const bool cand = !(tca < 0.0f) && !(x < 0.0f);
+        if (__any(cand)) {
+            const float t = tca - sqrt_rn(x);                // min t0 t1 == t0 (thc >= 0 or NaN)
+            const bool just = cand && !(t < 0.0f);
+            const float key = just ? t : kInfinite;          // maybe infinite fst
+            if (!(best_key <= key)) { best_key = key; best.t = t; best.idx = i; best.just = just; }
+        } else if (__any(!(best_key <= kInfinite))) {        // a Nothing still replaces a NaN / +inf key
+            if (!(best_key <= kInfinite)) { best_key = kInfinite; best.t = 0.0f; best.idx = i; best.just = false; }
         }
-        const float key = just ? t : kInfinite;              // maybe infinite fst
-        if (i == 0 || !(best_key <= key)) { best_key = key; best.t = t; best.idx = i; best.just = just; }
+        g = g_next;
     }
     for (int j = 0; j < np; ++j) {
-        // distanceTo @Plane (Intersection.hs:57-62)
-        const float4 gp = S[ns + 2 * j], gn = S[ns + 2 * j + 1];
+        // distanceTo @Plane (Intersection.hs:57-62); g holds (px, py, pz, 0)
+        const float4 gn = S[ns + 2 * j + 1];
+        const float4 g_next = S[ns + 2 * j + 2];
         const V3 nor = mk(gn.x, gn.y, gn.z);
         const float denom = dot(d, nor);
-        bool just = false; float t = 0.0f;
-        if (!(denom > 1e-6f)) {
-            t = dot(mk(gp.x, gp.y, gp.z) - o, nor) / denom;
-            just = !(t < 0.0f);
+        const bool cand = !(denom > 1e-6f);
+        if (__any(cand)) {
+            const float t = dot(mk(g.x, g.y, g.z) - o, nor) / denom;
+            const bool just = cand && !(t < 0.0f);
+            const float key = just ? t : kInfinite;
+            if (!(best_key <= key)) { best_key = key; best.t = t; best.idx = ns + j; best.just = just; }
+        } else if (__any(!(best_key <= kInfinite))) {
+            if (!(best_key <= kInfinite)) { best_key = kInfinite; best.t = 0.0f; best.idx = ns + j; best.just = false; }
         }
-        const float key = just ? t : kInfinite;
-        if ((ns == 0 && j == 0) || !(best_key <= key)) { best_key = key; best.t = t; best.idx = ns + j; best.just = just; }
+        g = g_next;
     }
     return best;
 }
@@ -77,6 +108,16 @@ __device__ __forceinline__ void hit_record(ScenePtr S, int ns, int idx, V3 o, V3
     }
 }
 
+// genVec (Util.hs:114-118) for the device: component = (random * 2.0) - 1.0 with
+// random = (float(int32 w) * 2^-32 + 0.5) + 2^-33.  Doubling is exact and commutes with rounding
+// here (no value leaves the normal range), so the doubled form below is the same binary32 value
+// with one multiplication less: ((I * 2^-31 + 1.0) + 2^-32) - 1.0.
+__device__ __forceinline__ float gen_component(Sfc32 &seed)
+{
+    const float i = (float)(int32_t)sfc32_next(seed);
+    return ((i * 4.656612873077392578125e-10f + 1.0f) + 2.3283064365386962890625e-10f) - 1.0f;
+}
+
 // computeRay (Trace.hs:374-383) + calcNextRay (Trace.hs:394-435), both BRDF arms evaluated
 // through selects so that Matte and Glossy lanes of one wave do not serialise.
 template <typename ScenePtr>
@@ -87,18 +128,20 @@ __device__ __forceinline__ void shade(ScenePtr M, int idx, V3 hit_pos, V3 normal
     const V3 color = mk(ma.x, ma.y, ma.z);
     const float illuminance = ma.w;
     const bool matte = f2u(mb.x) == 0u;
-    const float p_over_pi = mb.z;          // p / pi      (Trace.hs:411), divided at upload
-    const float one_minus_p = mb.w;        // 1 - p       (Trace.hs:424)
+    const float p_over_pi = mb.z;          // p / pi            (Trace.hs:411), divided at upload
+    const float half_k_glossy = mb.w;      // 0.5 * (1 - p)     (Trace.hs:424 and Util.hs:62-67), exact halving
 
     const V3 emittance = scale_r(color, illuminance);
-    const V3 rv = gen_vec(seed);
+    V3 rv;
+    rv.x = gen_component(seed); rv.y = gen_component(seed); rv.z = gen_component(seed);
     // Matte:  rotate (anglesToQuaternion $ pi *^ rv) iNormal
     // Glossy: rotate (anglesToQuaternion $ (1 - p) *^ rv) reflection
+    // anglesToQuaternion halves every angle; (k * rv) * 0.5 == (0.5 k) * rv bit for bit (power-of-two scaling).
     const float ia = dot(d, normal);
     const V3 reflection = d - scale_l(2.0f * ia, normal);
     const V3 axis = matte ? normal : reflection;
-    const float k = matte ? kPi : one_minus_p;
-    const V3 next = rotate(angles_to_quaternion(scale_l(k, rv)), axis);
+    const float hk = matte ? 0.5f * kPi : half_k_glossy;
+    const V3 next = rotate(quaternion_from_half_angles(hk * rv.x, hk * rv.y, hk * rv.z), axis);
     const float nd = dot(next, axis);
     const float brdf = matte ? p_over_pi * nd : __builtin_fmaxf(0.0f, nd);
     constexpr float next_ray_prob = 1.0f / (kPi * 2.0f);
@@ -247,15 +290,16 @@ __global__ void __launch_bounds__(kBlock) eval_sphere_kernel(const float *sph, c
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float *s = sph + 10 * (size_t)i;
-    float4 g; g.x = s[0]; g.y = s[1]; g.z = s[2]; g.w = s[3] * s[3];
+    float4 g[2]; g[0].x = s[0]; g[0].y = s[1]; g[0].z = s[2]; g[0].w = s[3] * s[3];
+    g[1] = g[0];                                             // check_hit prefetches one element ahead
     const V3 o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
     const V3 d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
-    const HitSel h = check_hit(&g, 1, 0, o, d);
+    const HitSel h = check_hit(g, 1, 0, o, d);
     is_just[i] = h.just ? 1 : 0;
     t_out[i] = h.just ? h.t : 0.0f;
     if (normalp) {
         V3 hp = mk(0, 0, 0), nr = mk(0, 0, 0);
-        if (h.just) hit_record(&g, 1, 0, o, d, h.t, hp, nr);
+        if (h.just) hit_record(g, 1, 0, o, d, h.t, hp, nr);
         float *q = normalp + 6 * (size_t)i;
         q[0] = hp.x; q[1] = hp.y; q[2] = hp.z; q[3] = nr.x; q[4] = nr.y; q[5] = nr.z;
     }
@@ -267,9 +311,10 @@ __global__ void __launch_bounds__(kBlock) eval_plane_kernel(const float *pl, con
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float *s = pl + 12 * (size_t)i;
-    float4 g[2];
+    float4 g[3];
     g[0].x = s[0]; g[0].y = s[1]; g[0].z = s[2]; g[0].w = 0.0f;
     g[1].x = s[3]; g[1].y = s[4]; g[1].z = s[5]; g[1].w = 0.0f;
+    g[2] = g[0];                                             // check_hit prefetches one element ahead
     const V3 o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
     const V3 d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
     const HitSel h = check_hit(g, 0, 1, o, d);
