@@ -167,10 +167,14 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned int v)
 
 // ---------------------------------------------------------------------------------------
 // render Inline.  LDS_SCENE: primitives staged in LDS (default) or read straight from
-// global memory (ablation).  REGENERATE: lanes start their next sample as soon as a path ends
-// (default) or all lanes of the wave run the samples in lock step (ablation).
+// global memory through scalar loads (ablation).  MODE selects the loop shape:
+//   kCached      (default) primary hit evaluated once per pixel, two shade rounds per trace round
+//   kRegenerate  lanes start their next sample as soon as a path ends, one shade per trace
+//   kLockstep    all lanes of the wave run sample s together (what a per-sample launch would do)
 // ---------------------------------------------------------------------------------------
-template <bool LDS_SCENE, bool REGENERATE>
+enum { kCached = 0, kRegenerate = 1, kLockstep = 2 };
+
+template <bool LDS_SCENE, int MODE>
 __global__ void __launch_bounds__(kBlock) render_inline_kernel(const RenderArgs a)
 {
     extern __shared__ float4 lds_scene[];
@@ -205,7 +209,60 @@ __global__ void __launch_bounds__(kBlock) render_inline_kernel(const RenderArgs 
         if (limit <= 0) {
             // iterate 0: every sample returns (0, seed); new + old
             if (n_spp > 0) acc = mk(0.0f, 0.0f, 0.0f) + acc;
-        } else if (REGENERATE) {
+        } else if (MODE == kCached) {
+            // primaryRays has no sub-pixel jitter (Trace.hs:244-262): every sample of a pixel shoots the
+            // same primary ray, so its checkHit + hit are evaluated ONCE per pixel and every sample starts
+            // from that record.  A sample then costs k shades and k-1 traces (k = its live bounces).
+            // Loop shape: [shade][shade again for lanes whose sample just ended][trace].  A lane that
+            // ends a sample in the first shade round starts the next one in the second, so all lanes
+            // enter the trace round with a ray and the expensive round runs at full occupancy.
+            const HitSel h0 = check_hit(S, ns, np, origin, primary);
+            if (!h0.just) {
+                if (n_spp > 0) acc = mk(0.0f, 0.0f, 0.0f) + acc;     // every sample: result 0, seed untouched
+            } else {
+                V3 p0, n0;
+                hit_record(S, ns, h0.idx, origin, primary, h0.t, p0, n0);
+                const int idx0 = h0.idx;
+                int s = 0, it = 0, idx = idx0;
+                V3 hit_pos = p0, normal = n0;                         // the hit waiting to be shaded
+                V3 o = origin, d = primary;                           // the ray that produced it / the next ray
+                V3 throughput = mk(1.0f, 1.0f, 1.0f), result = mk(0.0f, 0.0f, 0.0f);
+                bool pending = n_spp > 0, has_ray = false;
+                while (pending) {
+                    for (int round = 0; round < 2; ++round) {
+                        if (pending && !has_ray) {
+                            shade(M, idx, hit_pos, normal, o, d, throughput, result, seed);
+                            ++it; ++live;
+                            // the next prepareRay would freeze the path (Trace.hs:364-365)
+                            if (it >= limit || near_zero(throughput)) {
+                                acc = result + acc;                   // \(new, seed') (old, _) -> (new + old, seed')
+                                ++s; it = 0;
+                                throughput = mk(1.0f, 1.0f, 1.0f); result = mk(0.0f, 0.0f, 0.0f);
+                                hit_pos = p0; normal = n0; idx = idx0; d = primary;
+                                pending = s < n_spp;
+                            } else {
+                                pending = false; has_ray = true;
+                            }
+                        }
+                    }
+                    if (has_ray) {
+                        const HitSel h = check_hit(S, ns, np, o, d);
+                        has_ray = false;
+                        if (h.just) {
+                            hit_record(S, ns, h.idx, o, d, h.t, hit_pos, normal);
+                            idx = h.idx;
+                            pending = true;
+                        } else {
+                            acc = result + acc;
+                            ++s; it = 0;
+                            throughput = mk(1.0f, 1.0f, 1.0f); result = mk(0.0f, 0.0f, 0.0f);
+                            hit_pos = p0; normal = n0; idx = idx0; d = primary;
+                            pending = s < n_spp;
+                        }
+                    }
+                }
+            }
+        } else if (MODE == kRegenerate) {
             int s = 0, it = 0;
             V3 o = origin, d = primary;
             V3 throughput = mk(1.0f, 1.0f, 1.0f), result = mk(0.0f, 0.0f, 0.0f);
@@ -348,9 +405,10 @@ hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t st
     const dim3 grid(blocks_for(n_local)), block(kBlock);
     const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
     switch (variant) {
-    case 1:  hipLaunchKernelGGL((render_inline_kernel<false, true>), grid, block, 0, stream, a); break;
-    case 2:  hipLaunchKernelGGL((render_inline_kernel<true, false>), grid, block, lds, stream, a); break;
-    default: hipLaunchKernelGGL((render_inline_kernel<true, true>), grid, block, lds, stream, a); break;
+    case 1:  hipLaunchKernelGGL((render_inline_kernel<false, kCached>), grid, block, 0, stream, a); break;
+    case 2:  hipLaunchKernelGGL((render_inline_kernel<true, kLockstep>), grid, block, lds, stream, a); break;
+    case 3:  hipLaunchKernelGGL((render_inline_kernel<true, kRegenerate>), grid, block, lds, stream, a); break;
+    default: hipLaunchKernelGGL((render_inline_kernel<true, kCached>), grid, block, lds, stream, a); break;
     }
     return hipGetLastError();
 }
