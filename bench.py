@@ -69,6 +69,7 @@ def load_traffic():
 
 
 def main():
+    global WIDTH, HEIGHT, SPP_PER_GPU
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -76,7 +77,12 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (DESIGN.md); 0 = default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stripe-rows", type=int, default=8)
+    ap.add_argument("--width", type=int, default=WIDTH, help="experiments only: the headline number is the default C2 workload")
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--spp", type=int, default=SPP_PER_GPU)
+    ap.add_argument("--scene", choices=["s16", "main"], default="s16")
     args = ap.parse_args()
+    WIDTH, HEIGHT, SPP_PER_GPU = args.width, args.height, args.spp
 
     import torch
     import torch.distributed as dist
@@ -98,7 +104,7 @@ def main():
     pkg._build.build_lib()
     from haskell_path_tracer_amd.parallel import StripePartition, gather_color
 
-    spheres, planes = pkg.world.scene16()
+    spheres, planes = pkg.world.scene16() if args.scene == "s16" else pkg.world.main_scene()
     cam = pkg.world.initial_camera()
     spp = SPP_PER_GPU * world
 
@@ -173,8 +179,10 @@ def main():
             "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: 1920x1080, 64 spp per step per GPU, bounce limit 8, scene S16 "
-                                   "(14 spheres + 2 planes), render Inline, seeds from seed0=0x5EED1234",
+            "config": {"workload": "%s: %dx%d, %d spp per step per GPU, bounce limit 8, scene %s "
+                                   "(%d spheres + %d planes), render Inline, seeds from seed0=0x5EED1234"
+                                   % ("C2" if (WIDTH, HEIGHT, SPP_PER_GPU, args.scene) == (1920, 1080, 64, "s16") else "experiment",
+                                      WIDTH, HEIGHT, SPP_PER_GPU, args.scene.upper(), len(spheres), len(planes)),
                        "width": WIDTH, "height": HEIGHT, "spp_per_step": spp, "bounce_limit": BOUNCE_LIMIT,
                        "primitives": int(len(spheres) + len(planes)),
                        "parallelism": "row stripes of %d rows over %d GPU(s)%s"

@@ -233,9 +233,11 @@ int ptmi_create(ptmi_ctx **out, int device)
     if ((e = hipMalloc(&c->d_live, sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc(&c->d_work, 64 * sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc(&c->d_iters, sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipMemset(c->d_live, 0, sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset");
-    if ((e = hipMemset(c->d_work, 0, 64 * sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMemset");
-    if ((e = hipMemset(c->d_iters, 0, sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMemset");
+    // stream-ordered fills: the context's stream is non-blocking, so a NULL-stream hipMemset would race with it
+    if ((e = hipMemsetAsync(c->d_live, 0, sizeof(unsigned long long), c->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
+    if ((e = hipMemsetAsync(c->d_work, 0, 64 * sizeof(unsigned int), c->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
+    if ((e = hipMemsetAsync(c->d_iters, 0, sizeof(unsigned int), c->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
     *out = c;
     return PTMI_OK;
 }
@@ -278,7 +280,8 @@ int ptmi_set_scene(ptmi_ctx *c, const ptmi_sphere *spheres, int n_spheres, const
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
     if (c->d_scene) { (void)hipFree(c->d_scene); c->d_scene = nullptr; }
     PTMI_HIP(c, hipMalloc(&c->d_scene, packed.size() * sizeof(float4)));
-    PTMI_HIP(c, hipMemcpy(c->d_scene, packed.data(), packed.size() * sizeof(float4), hipMemcpyHostToDevice));
+    PTMI_HIP(c, hipMemcpyAsync(c->d_scene, packed.data(), packed.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));               // `packed` dies at return
     c->n_spheres = n_spheres; c->n_planes = n_planes;
     return PTMI_OK;
 }
@@ -308,7 +311,8 @@ int ptmi_resize(ptmi_ctx *c, int width, int height)
     const size_t n = (size_t)c->rows_local * (size_t)width;
     const size_t bytes = planes_bytes(n > 0 ? n : 1);
     PTMI_HIP(c, hipMalloc(&c->owned_block, bytes));
-    PTMI_HIP(c, hipMemset(c->owned_block, 0, bytes));
+    PTMI_HIP(c, hipMemsetAsync(c->owned_block, 0, bytes, c->stream));   // ordered before anything launched on the stream
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
     c->owned = carve(c->owned_block, n > 0 ? n : 1);
     return PTMI_OK;
 }
@@ -396,9 +400,9 @@ int ptmi_create_with(ptmi_ctx *c, const uint32_t *w0, const uint32_t *w1, const 
     if (int rc = ensure_scratch(c, 3 * n * 4)) return rc;
     uint32_t *d = static_cast<uint32_t *>(c->scratch);
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
-    PTMI_HIP(c, hipMemcpy(d, w0, n * 4, hipMemcpyHostToDevice));
-    PTMI_HIP(c, hipMemcpy(d + n, w1, n * 4, hipMemcpyHostToDevice));
-    PTMI_HIP(c, hipMemcpy(d + 2 * n, w2, n * 4, hipMemcpyHostToDevice));
+    PTMI_HIP(c, hipMemcpyAsync(d, w0, n * 4, hipMemcpyHostToDevice, c->stream));
+    PTMI_HIP(c, hipMemcpyAsync(d + n, w1, n * 4, hipMemcpyHostToDevice, c->stream));
+    PTMI_HIP(c, hipMemcpyAsync(d + 2 * n, w2, n * 4, hipMemcpyHostToDevice, c->stream));
     PTMI_HIP(c, launch_create_with(active(c), d, d + n, d + 2 * n, (int64_t)n, c->stream));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
     return PTMI_OK;
@@ -417,7 +421,8 @@ int ptmi_upload_state(ptmi_ctx *c, const float *r, const float *g, const float *
     const void *src[7] = {r, g, b, sa, sb, sc, sctr};
     void *dst[7] = {p.r, p.g, p.b, p.sa, p.sb, p.sc, p.sctr};
     for (int i = 0; i < 7; ++i)
-        if (src[i] && bytes) PTMI_HIP(c, hipMemcpy(dst[i], src[i], bytes, hipMemcpyHostToDevice));
+        if (src[i] && bytes) PTMI_HIP(c, hipMemcpyAsync(dst[i], src[i], bytes, hipMemcpyHostToDevice, c->stream));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
     return PTMI_OK;
 }
 
@@ -434,7 +439,8 @@ int ptmi_download_state(ptmi_ctx *c, float *r, float *g, float *b,
     void *dst[7] = {r, g, b, sa, sb, sc, sctr};
     const void *src[7] = {p.r, p.g, p.b, p.sa, p.sb, p.sc, p.sctr};
     for (int i = 0; i < 7; ++i)
-        if (dst[i] && bytes) PTMI_HIP(c, hipMemcpy(dst[i], src[i], bytes, hipMemcpyDeviceToHost));
+        if (dst[i] && bytes) PTMI_HIP(c, hipMemcpyAsync(dst[i], src[i], bytes, hipMemcpyDeviceToHost, c->stream));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
     return PTMI_OK;
 }
 
@@ -491,14 +497,15 @@ int ptmi_render1(ptmi_ctx *c, const ptmi_camera *camera, int algorithm, int boun
     const void *src[7] = {r_in, g_in, b_in, sa_in, sb_in, sc_in, sctr_in};
     void *dev[7] = {p.r, p.g, p.b, p.sa, p.sb, p.sc, p.sctr};
     void *dst[7] = {r_out, g_out, b_out, sa_out, sb_out, sc_out, sctr_out};
-    for (int i = 0; i < 7; ++i) PTMI_HIP(c, hipMemcpy(dev[i], src[i], n * 4, hipMemcpyHostToDevice));
+    for (int i = 0; i < 7; ++i) PTMI_HIP(c, hipMemcpyAsync(dev[i], src[i], n * 4, hipMemcpyHostToDevice, c->stream));
     if (screen_x) {
-        PTMI_HIP(c, hipMemcpy(dsx, screen_x, n * sizeof(int64_t), hipMemcpyHostToDevice));
-        PTMI_HIP(c, hipMemcpy(dsy, screen_y, n * sizeof(int64_t), hipMemcpyHostToDevice));
+        PTMI_HIP(c, hipMemcpyAsync(dsx, screen_x, n * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        PTMI_HIP(c, hipMemcpyAsync(dsy, screen_y, n * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     }
     if (int rc = launch_render(c, p, camera, algorithm, bounce_limit, 1, width, height, height, height, 1, 0, dsx, dsy)) return rc;
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 7; ++i) PTMI_HIP(c, hipMemcpy(dst[i], dev[i], n * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 7; ++i) PTMI_HIP(c, hipMemcpyAsync(dst[i], dev[i], n * 4, hipMemcpyDeviceToHost, c->stream));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
     return PTMI_OK;
 }
 
@@ -510,8 +517,9 @@ int ptmi_get_stats(ptmi_ctx *c, ptmi_stats *out)
     PTMI_HIP(c, hipSetDevice(c->device));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
     unsigned long long live = 0; unsigned int iters = 0;
-    PTMI_HIP(c, hipMemcpy(&live, c->d_live, sizeof live, hipMemcpyDeviceToHost));
-    PTMI_HIP(c, hipMemcpy(&iters, c->d_iters, sizeof iters, hipMemcpyDeviceToHost));
+    PTMI_HIP(c, hipMemcpyAsync(&live, c->d_live, sizeof live, hipMemcpyDeviceToHost, c->stream));
+    PTMI_HIP(c, hipMemcpyAsync(&iters, c->d_iters, sizeof iters, hipMemcpyDeviceToHost, c->stream));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
     out->live_bounces = live; out->nominal_bounces = c->nominal; out->samples = c->samples;
     out->stream_iterations = iters;
     out->last_render_ms = 0.0f;
@@ -525,8 +533,8 @@ int ptmi_reset_stats(ptmi_ctx *c)
     std::lock_guard<std::mutex> lock(c->mu);
     PTMI_HIP(c, hipSetDevice(c->device));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
-    PTMI_HIP(c, hipMemset(c->d_live, 0, sizeof(unsigned long long)));
-    PTMI_HIP(c, hipMemset(c->d_iters, 0, sizeof(unsigned int)));
+    PTMI_HIP(c, hipMemsetAsync(c->d_live, 0, sizeof(unsigned long long), c->stream));
+    PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, sizeof(unsigned int), c->stream));
     c->nominal = 0; c->samples = 0;
     return PTMI_OK;
 }
@@ -548,14 +556,15 @@ static int eval_prims(ptmi_ctx *c, const void *prims, int words, const float *ra
     float *d_t = reinterpret_cast<float *>(d_just + nb);
     float *d_np = d_t + nb;
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
-    PTMI_HIP(c, hipMemcpy(d_prims, prims, nb * words * 4, hipMemcpyHostToDevice));
-    PTMI_HIP(c, hipMemcpy(d_rays, rays, nb * 6 * 4, hipMemcpyHostToDevice));
+    PTMI_HIP(c, hipMemcpyAsync(d_prims, prims, nb * words * 4, hipMemcpyHostToDevice, c->stream));
+    PTMI_HIP(c, hipMemcpyAsync(d_rays, rays, nb * 6 * 4, hipMemcpyHostToDevice, c->stream));
     if (sphere) PTMI_HIP(c, launch_eval_sphere(d_prims, d_rays, n, d_just, d_t, d_np, c->stream));
     else        PTMI_HIP(c, launch_eval_plane(d_prims, d_rays, n, d_just, d_t, d_np, c->stream));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
-    PTMI_HIP(c, hipMemcpy(is_just, d_just, nb * 4, hipMemcpyDeviceToHost));
-    PTMI_HIP(c, hipMemcpy(t, d_t, nb * 4, hipMemcpyDeviceToHost));
-    if (normalp) PTMI_HIP(c, hipMemcpy(normalp, d_np, nb * 24, hipMemcpyDeviceToHost));
+    PTMI_HIP(c, hipMemcpyAsync(is_just, d_just, nb * 4, hipMemcpyDeviceToHost, c->stream));
+    PTMI_HIP(c, hipMemcpyAsync(t, d_t, nb * 4, hipMemcpyDeviceToHost, c->stream));
+    if (normalp) PTMI_HIP(c, hipMemcpyAsync(normalp, d_np, nb * 24, hipMemcpyDeviceToHost, c->stream));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
     return PTMI_OK;
 }
 
@@ -582,11 +591,12 @@ int ptmi_eval_sincos(ptmi_ctx *c, const float *x, int n, float *sin_out, float *
     if (int rc = ensure_scratch(c, nb * 12)) return rc;
     float *dx = static_cast<float *>(c->scratch), *ds = dx + nb, *dc = ds + nb;
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
-    PTMI_HIP(c, hipMemcpy(dx, x, nb * 4, hipMemcpyHostToDevice));
+    PTMI_HIP(c, hipMemcpyAsync(dx, x, nb * 4, hipMemcpyHostToDevice, c->stream));
     PTMI_HIP(c, launch_eval_sincos(dx, n, ds, dc, c->stream));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
-    PTMI_HIP(c, hipMemcpy(sin_out, ds, nb * 4, hipMemcpyDeviceToHost));
-    PTMI_HIP(c, hipMemcpy(cos_out, dc, nb * 4, hipMemcpyDeviceToHost));
+    PTMI_HIP(c, hipMemcpyAsync(sin_out, ds, nb * 4, hipMemcpyDeviceToHost, c->stream));
+    PTMI_HIP(c, hipMemcpyAsync(cos_out, dc, nb * 4, hipMemcpyDeviceToHost, c->stream));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
     return PTMI_OK;
 }
 

@@ -18,6 +18,7 @@ namespace ptmi {
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kChunk = 64;      // pixels a wave takes from the global counter per atomic (persistent kernel)
 
 struct HitSel { float t; int idx; bool just; };
 
@@ -43,19 +44,55 @@ __device__ __forceinline__ float sqrt_rn(float x)
 // The reference builds every hit record and selects; selecting the index first and building
 // one record afterwards gives the same value.
 //
-// Shape for the SIMD: the cheap part of every test (16 f32 operations for a sphere) runs for all
-// lanes; the square root / division and the fold update run only when some lane of the wave can
-// still be hit (wave-uniform branches on __any), which is the common case to skip once rays are
-// incoherent and primitives are small.  best_key starts as NaN so that element 0 always replaces
-// the accumulator (`NaN <= key` is false), which is expMinWith seeding the fold with its head.
+// check_hit_exact is the fold written out literally (every primitive, every lane, no shortcuts).
+template <typename ScenePtr>
+__device__ __noinline__ HitSel check_hit_exact(ScenePtr S, int ns, int np, V3 o, V3 d)
+{
+    HitSel best; best.t = 0.0f; best.idx = 0; best.just = false;
+    float best_key = 0.0f;
+    for (int i = 0; i < ns + np; ++i) {
+        bool just; float t;
+        if (i < ns) {                                        // distanceTo @Sphere (Intersection.hs:39-48)
+            const float4 g = S[i];
+            const V3 l = mk(g.x, g.y, g.z) - o;
+            const float tca = dot(l, d);
+            const float d2 = dot(l, l) - (tca * tca);
+            const float thc = __builtin_sqrtf(g.w - d2);
+            t = tca - thc;                                   // min t0 t1 == t0
+            just = !(tca < 0.0f || d2 > g.w || t < 0.0f);
+        } else {                                             // distanceTo @Plane (Intersection.hs:57-62)
+            const float4 gp = S[ns + 2 * (i - ns)], gn = S[ns + 2 * (i - ns) + 1];
+            const V3 nor = mk(gn.x, gn.y, gn.z);
+            const float denom = dot(d, nor);
+            t = dot(mk(gp.x, gp.y, gp.z) - o, nor) / denom;
+            just = !(denom > 1e-6f || t < 0.0f);
+        }
+        const float key = just ? t : kInfinite;              // maybe infinite fst
+        if (i == 0 || !(best_key <= key)) { best_key = key; best.t = t; best.idx = i; best.just = just; }
+    }
+    return best;
+}
+
+// check_hit is the same fold shaped for the SIMD:
+//   * the cheap part of every test (16 f32 operations for a sphere) runs for all lanes; the square
+//     root / division and the fold update run only when some lane of the wave can still be hit
+//     (wave-uniform branch on __any) -- the common case to skip once rays are incoherent;
+//   * best_key starts as NaN so that the first evaluated element always replaces the accumulator
+//     (`NaN <= key` is false), which is expMinWith seeding the fold with its head;
+//   * a skipped element is a Nothing (key FLT_MAX).  In the literal fold a Nothing replaces the
+//     accumulator only when the accumulated key is NaN or +inf; leaving the accumulator alone instead
+//     can change the outcome only if the FINAL accumulator is a Just whose key is not < FLT_MAX, so that
+//     one case (a ray or primitive with non-finite numbers) is detected at the end and redone literally.
+//   * spheres are walked two per trip with the two register sets swapping roles, so the prefetch of
+//     the next primitive costs no moves.
 template <typename ScenePtr>
 __device__ __forceinline__ HitSel check_hit(ScenePtr S, int ns, int np, V3 o, V3 d)
 {
-    HitSel best; best.t = 0.0f; best.idx = 0; best.just = false;
     float best_key = __builtin_nanf("");
-    float4 g = S[0];
-    for (int i = 0; i < ns; ++i) {
-        const float4 g_next = S[i + 1];                      // prefetch; S has a readable tail element
+    int best_idx = 0;
+    bool best_just = false;
+
+    auto sphere = [&](const float4 g, int i) {
         // distanceTo @Sphere (Intersection.hs:39-48)
         const V3 l = mk(g.x, g.y, g.z) - o;
         const float tca = dot(l, d);
@@ -67,29 +104,41 @@ __device__ __forceinline__ HitSel check_hit(ScenePtr S, int ns, int np, V3 o, V3
             const float t = tca - sqrt_rn(x);                // min t0 t1 == t0 (thc >= 0 or NaN)
             const bool just = cand && !(t < 0.0f);
             const float key = just ? t : kInfinite;          // maybe infinite fst
-            if (!(best_key <= key)) { best_key = key; best.t = t; best.idx = i; best.just = just; }
-        } else if (__any(!(best_key <= kInfinite))) {        // a Nothing still replaces a NaN / +inf key
-            if (!(best_key <= kInfinite)) { best_key = kInfinite; best.t = 0.0f; best.idx = i; best.just = false; }
+            if (!(best_key <= key)) { best_key = key; best_idx = i; best_just = just; }
         }
-        g = g_next;
+    };
+
+    float4 ga = S[0], gb;
+    int i = 0;
+    for (; i + 1 < ns; i += 2) {
+        gb = S[i + 1];
+        sphere(ga, i);
+        ga = S[i + 2];                                       // S has readable elements past the geometry
+        sphere(gb, i + 1);
+    }
+    if (i < ns) {
+        gb = S[i + 1];
+        sphere(ga, i);
+        ga = gb;
     }
     for (int j = 0; j < np; ++j) {
-        // distanceTo @Plane (Intersection.hs:57-62); g holds (px, py, pz, 0)
+        // distanceTo @Plane (Intersection.hs:57-62); ga holds (px, py, pz, 0)
         const float4 gn = S[ns + 2 * j + 1];
         const float4 g_next = S[ns + 2 * j + 2];
         const V3 nor = mk(gn.x, gn.y, gn.z);
         const float denom = dot(d, nor);
         const bool cand = !(denom > 1e-6f);
         if (__any(cand)) {
-            const float t = dot(mk(g.x, g.y, g.z) - o, nor) / denom;
+            const float t = dot(mk(ga.x, ga.y, ga.z) - o, nor) / denom;
             const bool just = cand && !(t < 0.0f);
             const float key = just ? t : kInfinite;
-            if (!(best_key <= key)) { best_key = key; best.t = t; best.idx = ns + j; best.just = just; }
-        } else if (__any(!(best_key <= kInfinite))) {
-            if (!(best_key <= kInfinite)) { best_key = kInfinite; best.t = 0.0f; best.idx = ns + j; best.just = false; }
+            if (!(best_key <= key)) { best_key = key; best_idx = ns + j; best_just = just; }
         }
-        g = g_next;
+        ga = g_next;
     }
+    if (__builtin_expect(__any(best_just && !(best_key < kInfinite)), 0))
+        return check_hit_exact(S, ns, np, o, d);
+    HitSel best; best.t = best_key; best.idx = best_idx; best.just = best_just;
     return best;
 }
 
@@ -101,7 +150,10 @@ __device__ __forceinline__ void hit_record(ScenePtr S, int ns, int idx, V3 o, V3
     hit_pos = o + scale_r(d, t);
     if (idx < ns) {
         const float4 g = S[idx];
-        normal = normalize(hit_pos - mk(g.x, g.y, g.z));
+        // normalize (linear): v unchanged if |v|^2 is within 1e-6 of 0 or 1, else v / sqrt |v|^2
+        const V3 v = hit_pos - mk(g.x, g.y, g.z);
+        const float len2 = dot(v, v);
+        normal = (near_zero(len2) || near_zero(1.0f - len2)) ? v : div_r(v, sqrt_rn(len2));
     } else {
         const float4 gn = S[ns + 2 * (idx - ns) + 1];
         normal = mk(gn.x, gn.y, gn.z);
@@ -313,6 +365,152 @@ __global__ void __launch_bounds__(kBlock) render_inline_kernel(const RenderArgs 
 }
 
 // ---------------------------------------------------------------------------------------
+// render Inline, persistent form (default).  Same per-pixel arithmetic as kCached above, but a lane
+// that finishes its pixel (all n_spp samples) takes the next unprocessed pixel from a global counter
+// instead of idling until the slowest of the wave's 64 pixels is done: the number of trace rounds a
+// pixel needs is a sum over its samples and varies by +-25 % inside a wave at 64 spp (measured:
+// 47.5 of 64 lanes active per VALU instruction with the static mapping).  Pixels are handed out with
+// one atomic per wave: ballot of the lanes that want one, popcount prefix for the rank, the lowest
+// wanting lane adds the count -- so lanes that ask together get consecutive pixels (at start: 64
+// consecutive pixels per wave, fully coalesced plane reads).  A fetched pixel's primary ray joins the
+// wave's next trace round; its hit is cached for the pixel's remaining samples.
+// Requires bounce_limit >= 1 and n_spp >= 1 (the launcher routes the degenerate cases elsewhere).
+// ---------------------------------------------------------------------------------------
+template <bool LDS_SCENE>
+__global__ void __launch_bounds__(kBlock) render_inline_persistent_kernel(const RenderArgs a)
+{
+    extern __shared__ float4 lds_scene[];
+    const int ns = a.scene.n_spheres, np = a.scene.n_planes;
+    if (LDS_SCENE) {
+        const int total = a.scene.total_f4();
+        for (int i = threadIdx.x; i < total; i += kBlock) lds_scene[i] = a.scene.packed[i];
+        __syncthreads();
+    }
+    const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
+    const float4 *M = S + a.scene.geom_f4();
+
+    const unsigned long long n_local = (unsigned long long)a.rows_local * (unsigned long long)a.width;
+    const int limit = a.bounce_limit, n_spp = a.n_spp;
+    const V3 origin = a.cam.pos;
+    const int lane = threadIdx.x & 63;
+    unsigned int live = 0;
+
+    unsigned long long pixel = 0;
+    V3 acc = mk(0, 0, 0), primary = mk(0, 0, 0), p0 = mk(0, 0, 0), n0 = mk(0, 0, 0);
+    V3 hit_pos = p0, normal = n0, o = origin, d = primary;
+    V3 throughput = mk(1.0f, 1.0f, 1.0f), result = mk(0.0f, 0.0f, 0.0f);
+    Sfc32 seed; seed.a = seed.b = seed.c = seed.counter = 0;
+    int s = 0, it = 0, idx = 0, idx0 = 0;
+    bool pending = false, has_ray = false, is_primary = false, finished = false, exhausted = false;
+    unsigned long long pool_next = 0, pool_end = 0;          // wave-uniform
+    bool queue_empty = false;                                // wave-uniform
+
+    for (;;) {
+        // ---- shade: twice, so that a lane whose sample ends in the first round starts the next in the second
+        for (int round = 0; round < 2; ++round) {
+            if (pending && !has_ray) {
+                shade(M, idx, hit_pos, normal, o, d, throughput, result, seed);
+                ++it; ++live;
+                // the next prepareRay would freeze the path (Trace.hs:364-365)
+                if (it >= limit || near_zero(throughput)) {
+                    acc = result + acc;                       // \(new, seed') (old, _) -> (new + old, seed')
+                    ++s; it = 0;
+                    throughput = mk(1.0f, 1.0f, 1.0f); result = mk(0.0f, 0.0f, 0.0f);
+                    hit_pos = p0; normal = n0; idx = idx0; d = primary;
+                    pending = s < n_spp;
+                    finished = !pending;
+                } else {
+                    pending = false; has_ray = true;
+                }
+            }
+        }
+        // ---- retire finished pixels (one store site), then hand out new ones
+        if (finished) {
+            a.planes.r[pixel] = acc.x; a.planes.g[pixel] = acc.y; a.planes.b[pixel] = acc.z;
+            a.planes.sa[pixel] = seed.a; a.planes.sb[pixel] = seed.b;
+            a.planes.sc[pixel] = seed.c; a.planes.sctr[pixel] = seed.counter;
+            finished = false;
+        }
+        const bool want = !pending && !has_ray && !exhausted;
+        const unsigned long long want_mask = __ballot(want);
+        if (want_mask) {                                      // wave-uniform
+            // The wave owns a pool [pool_next, pool_end) of consecutive pixels, refilled kChunk at a time with
+            // ONE atomic on the global counter (a single counter word serves only ~90 requests/us on this chip:
+            // one atomic per fetched pixel made the kernel 3x slower).  Wanting lanes take pool entries by rank.
+            const unsigned int n_want = (unsigned int)__builtin_popcountll(want_mask);
+            const unsigned int rank = (unsigned int)__builtin_popcountll(want_mask & ((1ull << lane) - 1ull));
+            unsigned long long mine = ~0ull;
+            unsigned int avail = (unsigned int)(pool_end - pool_next);
+            unsigned int take = n_want < avail ? n_want : avail;
+            if (want && rank < take) mine = pool_next + rank;
+            pool_next += take;
+            if (take < n_want && !queue_empty) {
+                const int leader = (int)__builtin_ctzll(want_mask);
+                unsigned int base = 0;
+                if (lane == leader) base = atomicAdd(a.work_counter, (unsigned int)kChunk);
+                base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
+                if ((unsigned long long)base >= n_local) {
+                    queue_empty = true;
+                } else {
+                    pool_next = base;
+                    pool_end = (unsigned long long)base + kChunk < n_local ? (unsigned long long)base + kChunk : n_local;
+                    avail = (unsigned int)(pool_end - pool_next);
+                    const unsigned int more = n_want - take < avail ? n_want - take : avail;
+                    if (want && rank >= take && rank - take < more) mine = pool_next + (rank - take);
+                    pool_next += more;
+                }
+            }
+            if (want) {
+                if (mine != ~0ull) {
+                    pixel = mine;
+                    const int local_row = (int)(pixel / (unsigned long long)a.width);
+                    const int col = (int)(pixel - (unsigned long long)local_row * (unsigned long long)a.width);
+                    int64_t px = col, py = global_row(local_row, a.stripe_rows, a.n_parts, a.part);
+                    if (a.screen_x) { px = a.screen_x[pixel]; py = a.screen_y[pixel]; }
+                    primary = primary_direction(a.cam, px, py);
+                    acc = mk(a.planes.r[pixel], a.planes.g[pixel], a.planes.b[pixel]);
+                    seed.a = a.planes.sa[pixel]; seed.b = a.planes.sb[pixel];
+                    seed.c = a.planes.sc[pixel]; seed.counter = a.planes.sctr[pixel];
+                    o = origin; d = primary;
+                    s = 0; it = 0;
+                    throughput = mk(1.0f, 1.0f, 1.0f); result = mk(0.0f, 0.0f, 0.0f);
+                    has_ray = true; is_primary = true;
+                } else if (queue_empty) {
+                    exhausted = true;
+                }
+            }
+        }
+        if (!__any(has_ray || pending)) break;               // nothing left in flight in this wave
+        // ---- trace: every lane that has a ray (next bounce, or the primary ray of a fresh pixel)
+        if (has_ray) {
+            const HitSel h = check_hit(S, ns, np, o, d);
+            has_ray = false;
+            if (h.just) {
+                hit_record(S, ns, h.idx, o, d, h.t, hit_pos, normal);
+                idx = h.idx;
+                pending = true;
+                if (is_primary) { p0 = hit_pos; n0 = normal; idx0 = idx; is_primary = false; }
+            } else if (is_primary) {
+                acc = mk(0.0f, 0.0f, 0.0f) + acc;            // every sample: result 0, seed untouched
+                is_primary = false; finished = true;
+            } else {
+                acc = result + acc;
+                ++s; it = 0;
+                throughput = mk(1.0f, 1.0f, 1.0f); result = mk(0.0f, 0.0f, 0.0f);
+                hit_pos = p0; normal = n0; idx = idx0; d = primary;
+                pending = s < n_spp;
+                finished = !pending;
+            }
+        }
+    }
+
+    if (a.live_counter) {
+        const unsigned long long total = wave_sum(live);
+        if (lane == 0 && total) atomicAdd(a.live_counter, total);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // genSeeds / createWith / initialOutput / reseed  (src/Util.hs:122-135, 204-205)
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) seed_kernel(Planes p, int width, int rows_local, int stripe_rows,
@@ -404,10 +602,32 @@ hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t st
     if (n_local <= 0) return hipSuccess;
     const dim3 grid(blocks_for(n_local)), block(kBlock);
     const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
+    // variants: 0 auto | 1 persistent (LDS scene) | 2 lock step | 3 regenerate | 4 cached, static mapping (LDS scene)
+    //           5 cached, static, scene through scalar loads | 6 persistent, scene through scalar loads
+    if (a.bounce_limit <= 0 || a.n_spp <= 0) variant = 2;   // degenerate counts: the plain loop handles them
+    if (variant == 0)                                        // measured cross-over: hand-out pays from ~2.5e8 pixel-samples
+        variant = (unsigned long long)n_local * (unsigned long long)a.n_spp >= 250000000ull ? 1 : 4;
+    if (variant == 1 || variant == 6) {
+        // persistent grid; more workgroups than fit would only start late and find the queue empty: cap at 8 per CU
+        static int max_blocks = 0;
+        if (!max_blocks) {
+            int dev = 0, cus = 0;
+            hipError_t e = hipGetDevice(&dev);
+            if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            if (e != hipSuccess) return e;
+            max_blocks = (cus > 0 ? cus : 256) * 8;
+        }
+        const unsigned int blocks = grid.x < (unsigned int)max_blocks ? grid.x : (unsigned int)max_blocks;
+        hipError_t e = hipMemsetAsync(a.work_counter, 0, sizeof(unsigned int), stream);
+        if (e != hipSuccess) return e;
+        if (variant == 1) hipLaunchKernelGGL((render_inline_persistent_kernel<true>), dim3(blocks), block, lds, stream, a);
+        else              hipLaunchKernelGGL((render_inline_persistent_kernel<false>), dim3(blocks), block, 0, stream, a);
+        return hipGetLastError();
+    }
     switch (variant) {
-    case 1:  hipLaunchKernelGGL((render_inline_kernel<false, kCached>), grid, block, 0, stream, a); break;
     case 2:  hipLaunchKernelGGL((render_inline_kernel<true, kLockstep>), grid, block, lds, stream, a); break;
     case 3:  hipLaunchKernelGGL((render_inline_kernel<true, kRegenerate>), grid, block, lds, stream, a); break;
+    case 5:  hipLaunchKernelGGL((render_inline_kernel<false, kCached>), grid, block, 0, stream, a); break;
     default: hipLaunchKernelGGL((render_inline_kernel<true, kCached>), grid, block, lds, stream, a); break;
     }
     return hipGetLastError();

@@ -39,3 +39,40 @@ def test_render_inline_matches_oracle(ctx, pkg, ora, w, h, limit, spp, scene_nam
         assert np.all(np.abs(a - b) <= REL_TOL * np.abs(b))
     assert stats["live_bounces"] == live
     assert stats["nominal_bounces"] == w * h * spp * limit
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+def test_every_kernel_variant_matches_oracle(pkg, ora, variant):
+    """All loop shapes (persistent hand-out, lock step, regenerate, cached/static, LDS or scalar-load scene)
+    compute the same seven planes -- they differ only in how lanes are kept busy."""
+    scene = pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    w, h, limit, spp = 150, 90, 8, 5
+    start = initial_planes(ora, w, h)
+    want, live = ora.render_inline(scene[0], scene[1], cam, w, h, limit, spp, start)
+    with pkg.Context(0) as c:
+        c.set_variant(variant)
+        got, stats = run_gpu(c, pkg, scene, cam, w, h, limit, spp, start)
+    assert_planes_equal(got, want, "variant %d" % variant)
+    assert stats["live_bounces"] == live
+
+
+def test_non_finite_inputs_take_the_literal_fold(ctx, pkg, ora):
+    """A camera at infinity makes every key NaN / inf: check_hit must fall back to the literal fold and
+    still agree with the oracle on which pixels count as hits (colour planes: NaN == NaN by position)."""
+    sp, pl = pkg.world.main_scene()
+    cam = pkg.world.camera((np.inf, 0.0, 0.0), (0.0, 0.0, 0.0), 90)
+    w, h = 32, 16
+    start = initial_planes(ora, w, h)
+    ctx.set_scene(sp, pl)
+    ctx.resize(w, h)
+    ctx.upload_state(*start)
+    ctx.render(cam, 4, 1)
+    got = ctx.download_state()
+    with np.errstate(all="ignore"):
+        want, _ = ora.render_inline(sp, pl, cam, w, h, 4, 1, start)
+    for a, b in zip(got[:3], want[:3]):
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        assert np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+    for a, b in zip(got[3:], want[3:]):
+        assert np.array_equal(a, b)          # the RNG planes carry no floating point
