@@ -511,6 +511,110 @@ __global__ void __launch_bounds__(kBlock) render_inline_persistent_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------
+// render Streams (Trace.hs:141-191, 272-331).  The reference keeps one ray per pixel in a stream
+// that `expand` compacts after every step (numNewRays is 0 or 1, Trace.hs:329-331) and scatters the
+// colours back with `permute (+)`; because a pixel never owns more than one ray, the stream is the
+// per-pixel chain below and the compaction becomes "a lane whose ray died starts its pixel's next
+// sample" -- the wave stays dense without moving ray state through memory.  What differs from
+// Inline, and is reproduced literally:
+//   * every hit adds emittance * throughput straight into the accumulator, also in the step where the
+//     throughput is already near zero (computeResult runs for every intersection, Trace.hs:290-293);
+//   * the ray dies when nearZero throughput || miss (Trace.hs:329-331); there is NO bounce limit -- a
+//     non-empty stream is never stopped by the iteration count (Trace.hs:166-170).  kStreamsHardCap only
+//     guarantees that the kernel terminates;
+//   * the pixel keeps its OLD seed while the sample runs (combine, Trace.hs:179-184) and then advances it
+//     by one draw (updateSeed, Trace.hs:151, :190-191); the ray's own seed chain is discarded.
+// ---------------------------------------------------------------------------------------
+constexpr int kStreamsHardCap = 1 << 16;
+
+template <bool LDS_SCENE>
+__global__ void __launch_bounds__(kBlock) render_streams_kernel(const RenderArgs a)
+{
+    extern __shared__ float4 lds_scene[];
+    const int ns = a.scene.n_spheres, np = a.scene.n_planes;
+    if (LDS_SCENE) {
+        const int total = a.scene.total_f4();
+        for (int i = threadIdx.x; i < total; i += kBlock) lds_scene[i] = a.scene.packed[i];
+        __syncthreads();
+    }
+    const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
+    const float4 *M = S + a.scene.geom_f4();
+
+    const long long n_local = (long long)a.rows_local * a.width;
+    const long long pixel = (long long)blockIdx.x * kBlock + threadIdx.x;
+    unsigned int live = 0, longest = 0;
+    if (pixel < n_local) {
+        const int local_row = (int)(pixel / a.width);
+        const int col = (int)(pixel - (long long)local_row * a.width);
+        const int64_t px = col, py = global_row(local_row, a.stripe_rows, a.n_parts, a.part);
+        const V3 origin = a.cam.pos;
+        const V3 primary = primary_direction(a.cam, px, py);
+        V3 acc = mk(a.planes.r[pixel], a.planes.g[pixel], a.planes.b[pixel]);
+        Sfc32 pixel_seed;
+        pixel_seed.a = a.planes.sa[pixel]; pixel_seed.b = a.planes.sb[pixel];
+        pixel_seed.c = a.planes.sc[pixel]; pixel_seed.counter = a.planes.sctr[pixel];
+        const int n_spp = a.n_spp;
+
+        const HitSel h0 = check_hit(S, ns, np, origin, primary);   // same primary ray for every sample
+        if (!h0.just) {
+            for (int s = 0; s < n_spp; ++s) (void)random_float(pixel_seed);     // updateSeed only
+        } else {
+            V3 p0, n0;
+            hit_record(S, ns, h0.idx, origin, primary, h0.t, p0, n0);
+            const int idx0 = h0.idx;
+            int s = 0, idx = idx0;
+            unsigned int steps = 0;
+            V3 hit_pos = p0, normal = n0, o = origin, d = primary;
+            V3 throughput = mk(1.0f, 1.0f, 1.0f);
+            Sfc32 seed = pixel_seed;
+            bool pending = n_spp > 0, has_ray = false;
+            auto end_sample = [&]() {
+                (void)random_float(pixel_seed);                   // updateSeed
+                seed = pixel_seed;
+                ++s; longest = steps > longest ? steps : longest; steps = 0;
+                throughput = mk(1.0f, 1.0f, 1.0f);
+                hit_pos = p0; normal = n0; idx = idx0; d = primary;
+                pending = s < n_spp;
+            };
+            while (pending) {
+                for (int round = 0; round < 2; ++round) {
+                    if (pending && !has_ray) {
+                        const bool dying = near_zero(throughput) || steps + 1u >= (unsigned int)kStreamsHardCap;
+                        // results: colour += emittance * throughput for EVERY hit; then the new ray (if any)
+                        shade(M, idx, hit_pos, normal, o, d, throughput, acc, seed);
+                        ++steps;
+                        if (dying) { end_sample(); }
+                        else { ++live; pending = false; has_ray = true; }
+                    }
+                }
+                if (has_ray) {
+                    const HitSel h = check_hit(S, ns, np, o, d);
+                    has_ray = false;
+                    if (h.just) {
+                        hit_record(S, ns, h.idx, o, d, h.t, hit_pos, normal);
+                        idx = h.idx;
+                        pending = true;
+                    } else {
+                        end_sample();
+                    }
+                }
+            }
+        }
+        a.planes.r[pixel] = acc.x; a.planes.g[pixel] = acc.y; a.planes.b[pixel] = acc.z;
+        a.planes.sa[pixel] = pixel_seed.a; a.planes.sb[pixel] = pixel_seed.b;
+        a.planes.sc[pixel] = pixel_seed.c; a.planes.sctr[pixel] = pixel_seed.counter;
+    }
+    if (a.live_counter) {
+        const unsigned long long total = wave_sum(live);
+        if ((threadIdx.x & 63) == 0 && total) atomicAdd(a.live_counter, total);
+    }
+    if (a.stream_iterations) {
+        for (int off = 32; off > 0; off >>= 1) { const unsigned int other = __shfl_xor(longest, off, 64); longest = other > longest ? other : longest; }
+        if ((threadIdx.x & 63) == 0 && longest) atomicMax(a.stream_iterations, longest);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // genSeeds / createWith / initialOutput / reseed  (src/Util.hs:122-135, 204-205)
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) seed_kernel(Planes p, int width, int rows_local, int stripe_rows,
@@ -633,9 +737,17 @@ hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t st
     return hipGetLastError();
 }
 
-hipError_t launch_render_streams(const RenderArgs &, int, hipStream_t)
+hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t stream)
 {
-    return hipErrorNotSupported;
+    const long long n_local = (long long)a.rows_local * a.width;
+    if (n_local <= 0) return hipSuccess;
+    const dim3 grid(blocks_for(n_local)), block(kBlock);
+    const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
+    hipError_t e = hipMemsetAsync(a.stream_iterations, 0, sizeof(unsigned int), stream);
+    if (e != hipSuccess) return e;
+    if (variant == 5 || variant == 6) hipLaunchKernelGGL((render_streams_kernel<false>), grid, block, 0, stream, a);
+    else                              hipLaunchKernelGGL((render_streams_kernel<true>), grid, block, lds, stream, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_seed(Planes p, int width, int rows_local, int stripe_rows, int n_parts, int part,

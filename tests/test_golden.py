@@ -40,8 +40,6 @@ def test_gpu_reproduces_golden(ctx, pkg, path):
     z, start, want = load(path)
     w, h, limit, spp = int(z["width"]), int(z["height"]), int(z["limit"]), int(z["spp"])
     alg = pkg.INLINE if str(z["algorithm"]) == "inline" else pkg.STREAMS
-    if alg == pkg.STREAMS:
-        pytest.skip("Streams kernel: next row (DESIGN.md), not built yet")
     ctx.set_scene(z["spheres"], z["planes"])
     ctx.resize(w, h)
     ctx.upload_state(*start)
