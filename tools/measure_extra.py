@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Side measurements quoted in DESIGN.md (not the headline bench): the PCIe-inclusive rate of the
+compat entry ptmi_render1 (host planes in/out, one sample), the kernel variants on C2, and C3."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as graft  # noqa: E402
+import numpy as np  # noqa: E402
+
+
+def main():
+    pkg = graft.load_package()
+    pkg._build.build_lib()
+    sp, pl = pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    out = {}
+    with pkg.Context(0) as ctx:
+        ctx.set_scene(sp, pl)
+        # --- compat entry, 1080p, 1 sample, 8 bounces: H2D 58 MB + kernel + D2H 58 MB
+        w, h = 1920, 1080
+        ctx.resize(w, h)
+        ctx.init_output(0x5EED1234)
+        planes = ctx.download_state()
+        for _ in range(2):
+            planes = ctx.render1(cam, 8, w, h, planes)
+        t0 = time.perf_counter()
+        n = 5
+        for _ in range(n):
+            planes = ctx.render1(cam, 8, w, h, planes)
+        dt = (time.perf_counter() - t0) / n
+        out["render1_1080p_ms"] = round(dt * 1e3, 3)
+        out["render1_1080p_Msamples_s"] = round(w * h * 8 / dt / 1e6, 1)
+        out["render1_bytes_moved_MB"] = round(2 * 7 * w * h * 4 / 1e6, 1)
+        # --- variants on C2 (resident), kernel time by host clock around synchronize
+        res = {}
+        for v in (0, 1, 2, 3, 4, 5, 6):
+            ctx.set_variant(v)
+            ctx.init_output(0x5EED1234)
+            ctx.render(cam, 8, 64); ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                ctx.render(cam, 8, 64)
+            ctx.synchronize()
+            res[v] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+        out["c2_ms_by_variant"] = res
+        # --- Streams on C2
+        ctx.set_variant(0)
+        ctx.init_output(0x5EED1234)
+        ctx.render(cam, 8, 64, pkg.STREAMS); ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ctx.render(cam, 8, 64, pkg.STREAMS)
+        ctx.synchronize()
+        out["c2_streams_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+        # --- C3: 3840x2160, 256 spp, 8 bounces
+        w, h = 3840, 2160
+        ctx.resize(w, h)
+        ctx.init_output(0x5EED1234)
+        ctx.render(cam, 8, 16); ctx.synchronize()
+        ctx.reset_stats()
+        t0 = time.perf_counter()
+        ctx.render(cam, 8, 256)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        st = ctx.stats()
+        out["c3_4k_256spp_ms"] = round(dt * 1e3, 2)
+        out["c3_Msamples_s"] = round(w * h * 256 * 8 / dt / 1e6, 1)
+        out["c3_algorithmic_GBs"] = round(w * h * 256 * 56 / dt / 1e9, 1)
+        out["c3_live_fraction"] = round(st["live_bounces"] / st["nominal_bounces"], 4)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
