@@ -95,10 +95,18 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libptmi has no CPU path")
+    # Rehearsal on a one-GPU box (never the measured path): all ranks share cuda:0 and talk over gloo.
+    rehearsal = os.environ.get("PTMI_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    cdev = "cpu" if rehearsal else "cuda"          # where the small reduction tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = graft.load_package()
     pkg._build.build_lib()
@@ -157,10 +165,10 @@ def main():
     stats = ctx.stats()
 
     if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
-        tot = torch.tensor([stats["live_bounces"]], dtype=torch.int64, device="cuda")
+        tot = torch.tensor([stats["live_bounces"]], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot)
         live_total = int(tot[0])
     else:

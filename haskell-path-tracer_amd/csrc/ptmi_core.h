@@ -170,7 +170,14 @@ PTMI_HD Quat quaternion_from_half_angles(float half_roll, float half_pitch, floa
 {
     float sr, cr, sp, cp, sy, cy;
     sincos(half_roll, sr, cr);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // keep the three f64 evaluations from being interleaved: their temporaries are the kernel's VGPR peak
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     sincos(half_pitch, sp, cp);
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     sincos(half_yaw, sy, cy);
     Quat q;
     q.w   = cy * cp * cr + sy * sp * sr;

@@ -227,8 +227,9 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned int v)
 enum { kCached = 0, kRegenerate = 1, kLockstep = 2 };
 
 template <bool LDS_SCENE, int MODE>
-__global__ void __launch_bounds__(kBlock) render_inline_kernel(const RenderArgs a)
+__global__ void __launch_bounds__(kBlock, MODE == kCached ? 6 : 4) render_inline_kernel(const RenderArgs a)
 {
+    __shared__ float pixel_const[MODE == kCached ? 9 : 1][kBlock];   // kCached: per-lane restart record (see below)
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -272,44 +273,49 @@ __global__ void __launch_bounds__(kBlock) render_inline_kernel(const RenderArgs 
             if (!h0.just) {
                 if (n_spp > 0) acc = mk(0.0f, 0.0f, 0.0f) + acc;     // every sample: result 0, seed untouched
             } else {
-                V3 p0, n0;
-                hit_record(S, ns, h0.idx, origin, primary, h0.t, p0, n0);
+                // The per-pixel constants a sample restarts from (primary hit record + primary direction, 10
+                // words) are read once per sample: they live in a lane-private LDS column instead of VGPRs,
+                // which is what lets the kernel fit 80 VGPRs = 6 waves per SIMD.
+                float *mine = &pixel_const[0][threadIdx.x];
+                auto put = [&](int k, float v) { mine[k * kBlock] = v; };
+                auto get = [&](int k) { return mine[k * kBlock]; };
+                V3 pos, normal;                                       // pos: the hit to shade, then the next ray's origin
+                hit_record(S, ns, h0.idx, origin, primary, h0.t, pos, normal);
+                put(0, pos.x); put(1, pos.y); put(2, pos.z);
+                put(3, normal.x); put(4, normal.y); put(5, normal.z);
+                put(6, primary.x); put(7, primary.y); put(8, primary.z);
                 const int idx0 = h0.idx;
                 int s = 0, it = 0, idx = idx0;
-                V3 hit_pos = p0, normal = n0;                         // the hit waiting to be shaded
-                V3 o = origin, d = primary;                           // the ray that produced it / the next ray
+                V3 d = primary;                                       // the ray that produced the hit / the next ray
                 V3 throughput = mk(1.0f, 1.0f, 1.0f), result = mk(0.0f, 0.0f, 0.0f);
                 bool pending = n_spp > 0, has_ray = false;
+                auto restart = [&]() {                                // next sample of this pixel
+                    acc = result + acc;                               // \(new, seed') (old, _) -> (new + old, seed')
+                    ++s; it = 0;
+                    throughput = mk(1.0f, 1.0f, 1.0f); result = mk(0.0f, 0.0f, 0.0f);
+                    pos = mk(get(0), get(1), get(2)); normal = mk(get(3), get(4), get(5));
+                    d = mk(get(6), get(7), get(8)); idx = idx0;
+                    pending = s < n_spp;
+                };
                 while (pending) {
                     for (int round = 0; round < 2; ++round) {
                         if (pending && !has_ray) {
-                            shade(M, idx, hit_pos, normal, o, d, throughput, result, seed);
+                            shade(M, idx, pos, normal, pos, d, throughput, result, seed);
                             ++it; ++live;
                             // the next prepareRay would freeze the path (Trace.hs:364-365)
-                            if (it >= limit || near_zero(throughput)) {
-                                acc = result + acc;                   // \(new, seed') (old, _) -> (new + old, seed')
-                                ++s; it = 0;
-                                throughput = mk(1.0f, 1.0f, 1.0f); result = mk(0.0f, 0.0f, 0.0f);
-                                hit_pos = p0; normal = n0; idx = idx0; d = primary;
-                                pending = s < n_spp;
-                            } else {
-                                pending = false; has_ray = true;
-                            }
+                            if (it >= limit || near_zero(throughput)) restart();
+                            else { pending = false; has_ray = true; }
                         }
                     }
                     if (has_ray) {
-                        const HitSel h = check_hit(S, ns, np, o, d);
+                        const HitSel h = check_hit(S, ns, np, pos, d);
                         has_ray = false;
                         if (h.just) {
-                            hit_record(S, ns, h.idx, o, d, h.t, hit_pos, normal);
+                            hit_record(S, ns, h.idx, pos, d, h.t, pos, normal);
                             idx = h.idx;
                             pending = true;
                         } else {
-                            acc = result + acc;
-                            ++s; it = 0;
-                            throughput = mk(1.0f, 1.0f, 1.0f); result = mk(0.0f, 0.0f, 0.0f);
-                            hit_pos = p0; normal = n0; idx = idx0; d = primary;
-                            pending = s < n_spp;
+                            restart();
                         }
                     }
                 }
@@ -732,6 +738,8 @@ hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t st
     case 2:  hipLaunchKernelGGL((render_inline_kernel<true, kLockstep>), grid, block, lds, stream, a); break;
     case 3:  hipLaunchKernelGGL((render_inline_kernel<true, kRegenerate>), grid, block, lds, stream, a); break;
     case 5:  hipLaunchKernelGGL((render_inline_kernel<false, kCached>), grid, block, 0, stream, a); break;
+    case 7:  hipLaunchKernelGGL((render_inline_kernel<true, kCached>), grid, block, 33 * 1024, stream, a); break;   // 4 waves/SIMD
+    case 8:  hipLaunchKernelGGL((render_inline_kernel<true, kCached>), grid, block, 41 * 1024, stream, a); break;   // 3 waves/SIMD
     default: hipLaunchKernelGGL((render_inline_kernel<true, kCached>), grid, block, lds, stream, a); break;
     }
     return hipGetLastError();

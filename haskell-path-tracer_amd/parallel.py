@@ -59,6 +59,8 @@ def gather_color(color_local, partition, dst=0, group=None):
         full = torch.empty((3, partition.height, width), dtype=color_local.dtype, device=color_local.device)
         full[:, torch.as_tensor(partition.global_rows(), device=color_local.device), :] = color_local
         return full
+    if color_local.is_cuda and dist.get_backend(group) == "gloo":
+        color_local = color_local.cpu()          # CPU rehearsal of the N > 1 path; RCCL takes the device tensor
     max_rows = partition.max_rows()
     send = color_local
     if color_local.shape[1] != max_rows:
