@@ -110,7 +110,7 @@ def main():
 
     pkg = graft.load_package()
     pkg._build.build_lib()
-    from haskell_path_tracer_amd.parallel import StripePartition, gather_color
+    from haskell_path_tracer_amd.parallel import ColorGatherer, StripePartition
 
     spheres, planes = pkg.world.scene16() if args.scene == "s16" else pkg.world.main_scene()
     cam = pkg.world.initial_camera()
@@ -136,10 +136,12 @@ def main():
     ctx.set_variant(args.variant)
     ctx.init_output(SEED0)
 
+    gather = ColorGatherer(part, WIDTH, color.dtype, color.device, dst=0) if world > 1 else None
+
     def step():
         ctx.render(cam, BOUNCE_LIMIT, spp, pkg.INLINE)
         if world > 1:
-            return gather_color(color, part, dst=0)
+            return gather(color)
         return None
 
     def fence():
@@ -158,7 +160,7 @@ def main():
         ctx.render(cam, BOUNCE_LIMIT, spp, pkg.INLINE)
         ev[k][1].record()
         if world > 1:
-            gather_color(color, part, dst=0)
+            gather(color)
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
@@ -174,6 +176,7 @@ def main():
     else:
         live_total = stats["live_bounces"]
 
+    is_c2 = (WIDTH, HEIGHT, SPP_PER_GPU, args.scene) == (1920, 1080, 64, "s16")
     if rank == 0:
         nominal_per_step = WIDTH * HEIGHT * spp * BOUNCE_LIMIT          # whole job, all ranks
         value = nominal_per_step * args.steps / elapsed / 1e6
@@ -189,7 +192,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %dx%d, %d spp per step per GPU, bounce limit 8, scene %s "
                                    "(%d spheres + %d planes), render Inline, seeds from seed0=0x5EED1234"
-                                   % ("C2" if (WIDTH, HEIGHT, SPP_PER_GPU, args.scene) == (1920, 1080, 64, "s16") else "experiment",
+                                   % ("C2" if is_c2 else "experiment",
                                       WIDTH, HEIGHT, SPP_PER_GPU, args.scene.upper(), len(spheres), len(planes)),
                        "width": WIDTH, "height": HEIGHT, "spp_per_step": spp, "bounce_limit": BOUNCE_LIMIT,
                        "primitives": int(len(spheres) + len(planes)),
@@ -199,7 +202,8 @@ def main():
             "live_bounce_fraction": round(live_total / (nominal_per_step * args.steps), 4),
             "live_Mbounces_per_s": round(live_total / elapsed / 1e6, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic(),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": load_traffic() if (world == 1 and is_c2) else None,
                          "kernel": "render_inline_kernel", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "HBM is the bound BASELINE.json names; the kernel is f32/f64 VALU-bound (DESIGN.md)"},

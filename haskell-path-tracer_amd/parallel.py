@@ -42,39 +42,54 @@ class StripePartition:
         return max(self.rows_of(self.height, self.stripe_rows, self.n_parts, p) for p in range(self.n_parts))
 
 
+class ColorGatherer:
+    """The read-out collective with its buffers and row indices allocated once (a bench step or a
+    display loop calls it every frame): gather [3, local_rows, W] from every rank to `dst`, reassemble
+    [3, H, W] there.  Ranks may hold different row counts (H not a multiple of stripe_rows * n_parts):
+    tensors are padded to the largest.  With backend "gloo" and CUDA tensors the data takes a CPU detour
+    (rehearsal of the N > 1 path on a one-GPU box); RCCL takes the device tensors directly."""
+
+    def __init__(self, partition, width, dtype, device, dst=0, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.partition, self.width, self.dst, self.group = partition, width, dst, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        assert self.world == partition.n_parts and self.rank == partition.part
+        self.via_cpu = (self.world > 1 and torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo")
+        dev = "cpu" if self.via_cpu else device
+        self.max_rows = partition.max_rows()
+        self.send = None
+        if self.world > 1 and partition.local_rows != self.max_rows:
+            self.send = torch.zeros((3, self.max_rows, width), dtype=dtype, device=dev)
+        self.bufs, self.full, self.rows = None, None, None
+        if self.rank == dst:
+            self.full = torch.empty((3, partition.height, width), dtype=dtype, device=dev)
+            self.rows = [torch.as_tensor(partition.global_rows(p), device=dev) for p in range(self.world)]
+            if self.world > 1:
+                self.bufs = [torch.empty((3, self.max_rows, width), dtype=dtype, device=dev) for _ in range(self.world)]
+
+    def __call__(self, color_local):
+        import torch.distributed as dist
+
+        if self.world == 1:
+            self.full[:, self.rows[0], :] = color_local
+            return self.full
+        if self.via_cpu:
+            color_local = color_local.cpu()
+        send = color_local
+        if self.send is not None:
+            self.send[:, :color_local.shape[1], :] = color_local
+            send = self.send
+        dist.gather(send.contiguous(), gather_list=self.bufs, dst=self.dst, group=self.group)
+        if self.rank != self.dst:
+            return None
+        for p in range(self.world):
+            self.full[:, self.rows[p], :] = self.bufs[p][:, :self.rows[p].numel(), :]
+        return self.full
+
+
 def gather_color(color_local, partition, dst=0, group=None):
-    """Gather every rank's [3, local_rows, W] colour tensor to `dst` and reassemble [3, H, W].
-
-    Returns the full image on `dst`, None elsewhere.  Ranks may hold different row counts
-    (H not a multiple of stripe_rows * n_parts): tensors are padded to the largest.
-    """
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    assert world == partition.n_parts and rank == partition.part
-    width = color_local.shape[2]
-    if world == 1:
-        full = torch.empty((3, partition.height, width), dtype=color_local.dtype, device=color_local.device)
-        full[:, torch.as_tensor(partition.global_rows(), device=color_local.device), :] = color_local
-        return full
-    if color_local.is_cuda and dist.get_backend(group) == "gloo":
-        color_local = color_local.cpu()          # CPU rehearsal of the N > 1 path; RCCL takes the device tensor
-    max_rows = partition.max_rows()
-    send = color_local
-    if color_local.shape[1] != max_rows:
-        send = torch.zeros((3, max_rows, width), dtype=color_local.dtype, device=color_local.device)
-        send[:, :color_local.shape[1], :] = color_local
-    send = send.contiguous()
-    bufs = None
-    if rank == dst:
-        bufs = [torch.empty_like(send) for _ in range(world)]
-    dist.gather(send, gather_list=bufs, dst=dst, group=group)
-    if rank != dst:
-        return None
-    full = torch.empty((3, partition.height, width), dtype=color_local.dtype, device=color_local.device)
-    for p in range(world):
-        rows = torch.as_tensor(partition.global_rows(p), device=color_local.device)
-        full[:, rows, :] = bufs[p][:, :rows.numel(), :]
-    return full
+    """One-shot form of ColorGatherer: returns the full image on `dst`, None elsewhere."""
+    return ColorGatherer(partition, color_local.shape[2], color_local.dtype, color_local.device, dst, group)(color_local)
