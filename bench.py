@@ -72,8 +72,8 @@ def main():
     global WIDTH, HEIGHT, SPP_PER_GPU
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (DESIGN.md); 0 = default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stripe-rows", type=int, default=8)

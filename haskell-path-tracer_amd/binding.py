@@ -49,6 +49,7 @@ SYMBOLS = {
     "ptmi_render": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
     "ptmi_synchronize": (C.c_int, [_vp]),
     "ptmi_render1": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp] + [_vp] * 14),
+    "ptmi_present": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "ptmi_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "ptmi_reset_stats": (C.c_int, [_vp]),
     "ptmi_eval_distance_to_sphere": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
@@ -237,6 +238,14 @@ class Context:
         self._check(self._lib.ptmi_render1(self._h, _ptr(cam), algorithm, bounce_limit, width, height,
                                            _ptr(sx), _ptr(sy), *[_ptr(a) for a in ins], *[_ptr(a) for a in outs]))
         return tuple(outs)
+
+    def present(self, iterations, rgb32f=True, rgba8=True):
+        """graphicsLoop + fs.glsl: interleaved colour / iterations as float RGB and/or 8-bit RGBA."""
+        shape = (self.local_rows, self.width)
+        rgb = np.empty(shape + (3,), np.float32) if rgb32f else None
+        rgba = np.empty(shape + (4,), np.uint8) if rgba8 else None
+        self._check(self._lib.ptmi_present(self._h, int(iterations), _ptr(rgb), _ptr(rgba)))
+        return rgb, rgba
 
     def stats(self):
         st = Stats()

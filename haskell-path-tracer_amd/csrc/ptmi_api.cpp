@@ -509,6 +509,28 @@ int ptmi_render1(ptmi_ctx *c, const ptmi_camera *camera, int algorithm, int boun
     return PTMI_OK;
 }
 
+int ptmi_present(ptmi_ctx *c, int iterations, float *rgb32f_out, uint8_t *rgba8_out)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (c->width <= 0) return fail(c, PTMI_ESTATE, "ptmi_resize has not been called");
+    if (iterations <= 0) return fail(c, PTMI_EINVAL, "iterations must be positive");
+    if (!rgb32f_out && !rgba8_out) return PTMI_OK;
+    PTMI_HIP(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->rows_local * c->width;
+    if (n == 0) return PTMI_OK;
+    const size_t rgb_bytes = ((n * 12 + 255) / 256) * 256;
+    if (int rc = ensure_scratch(c, rgb_bytes + n * 4)) return rc;
+    float *d_rgb = static_cast<float *>(c->scratch);
+    uint32_t *d_rgba = reinterpret_cast<uint32_t *>(static_cast<char *>(c->scratch) + rgb_bytes);
+    PTMI_HIP(c, launch_present(active(c), (long long)n, iterations, rgb32f_out ? d_rgb : nullptr,
+                               rgba8_out ? d_rgba : nullptr, c->stream));
+    if (rgb32f_out) PTMI_HIP(c, hipMemcpyAsync(rgb32f_out, d_rgb, n * 12, hipMemcpyDeviceToHost, c->stream));
+    if (rgba8_out) PTMI_HIP(c, hipMemcpyAsync(rgba8_out, d_rgba, n * 4, hipMemcpyDeviceToHost, c->stream));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    return PTMI_OK;
+}
+
 int ptmi_get_stats(ptmi_ctx *c, ptmi_stats *out)
 {
     if (!c) return PTMI_EINVAL;

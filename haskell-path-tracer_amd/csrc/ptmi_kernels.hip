@@ -647,6 +647,57 @@ __global__ void __launch_bounds__(kBlock) create_with_kernel(Planes p, const uin
 }
 
 // ---------------------------------------------------------------------------------------
+// present: interleave + divide by the iteration count (app/Main.hs:351, app/assets/fs.glsl:12) and the
+// framebuffer's float -> unorm8 conversion.  HBM-streaming: 12 B read and 12 (+4) B written per pixel.
+// Four pixels per lane: three 16-byte plane loads, three 16-byte interleaved stores, one 16-byte RGBA store.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t unorm8(float c)
+{
+    const float x = c < 0.0f ? 0.0f : (c > 1.0f ? 1.0f : c);    // NaN -> 0, as a GL clamp does
+    return (uint32_t)(x * 255.0f + 0.5f);
+}
+
+__global__ void __launch_bounds__(kBlock) present_kernel(Planes p, long long n, float count, float *rgb, uint32_t *rgba, int aligned16)
+{
+    const long long q = ((long long)blockIdx.x * kBlock + threadIdx.x) * 4;
+    if (q >= n) return;
+    const bool wide = aligned16 && q + 3 < n;               // caller-owned planes need not be 16-byte aligned
+    float r[4], g[4], b[4];
+    if (wide) {
+        const float4 vr = *reinterpret_cast<const float4 *>(p.r + q);
+        const float4 vg = *reinterpret_cast<const float4 *>(p.g + q);
+        const float4 vb = *reinterpret_cast<const float4 *>(p.b + q);
+        r[0] = vr.x; r[1] = vr.y; r[2] = vr.z; r[3] = vr.w;
+        g[0] = vg.x; g[1] = vg.y; g[2] = vg.z; g[3] = vg.w;
+        b[0] = vb.x; b[1] = vb.y; b[2] = vb.z; b[3] = vb.w;
+    } else {
+        for (int k = 0; k < 4; ++k) { const bool in = q + k < n; r[k] = in ? p.r[q + k] : 0.0f; g[k] = in ? p.g[q + k] : 0.0f; b[k] = in ? p.b[q + k] : 0.0f; }
+    }
+    for (int k = 0; k < 4; ++k) { r[k] = r[k] / count; g[k] = g[k] / count; b[k] = b[k] / count; }
+    if (wide) {
+        if (rgb) {
+            float4 *o = reinterpret_cast<float4 *>(rgb + 3 * q);
+            o[0] = float4{r[0], g[0], b[0], r[1]};
+            o[1] = float4{g[1], b[1], r[2], g[2]};
+            o[2] = float4{b[2], r[3], g[3], b[3]};
+        }
+        if (rgba) {
+            uint4 v;
+            v.x = unorm8(r[0]) | unorm8(g[0]) << 8 | unorm8(b[0]) << 16 | 0xff000000u;
+            v.y = unorm8(r[1]) | unorm8(g[1]) << 8 | unorm8(b[1]) << 16 | 0xff000000u;
+            v.z = unorm8(r[2]) | unorm8(g[2]) << 8 | unorm8(b[2]) << 16 | 0xff000000u;
+            v.w = unorm8(r[3]) | unorm8(g[3]) << 8 | unorm8(b[3]) << 16 | 0xff000000u;
+            *reinterpret_cast<uint4 *>(rgba + q) = v;
+        }
+    } else {
+        for (int k = 0; k < 4 && q + k < n; ++k) {
+            if (rgb) { rgb[3 * (q + k)] = r[k]; rgb[3 * (q + k) + 1] = g[k]; rgb[3 * (q + k) + 2] = b[k]; }
+            if (rgba) rgba[q + k] = unorm8(r[k]) | unorm8(g[k]) << 8 | unorm8(b[k]) << 16 | 0xff000000u;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // point queries: the reference's unit-test surface (test/Scene/Intersection/Tests.hs)
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) eval_sphere_kernel(const float *sph, const float *rays, int n,
@@ -789,6 +840,15 @@ hipError_t launch_eval_plane(const float *planes12, const float *rays, int n,
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(eval_plane_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, planes12, rays, n, is_just, t, normalp);
+    return hipGetLastError();
+}
+
+hipError_t launch_present(Planes p, long long n, int iterations, float *rgb, uint32_t *rgba, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    const uintptr_t bits = (uintptr_t)p.r | (uintptr_t)p.g | (uintptr_t)p.b | (uintptr_t)rgb | (uintptr_t)rgba;
+    hipLaunchKernelGGL(present_kernel, dim3(blocks_for((n + 3) / 4)), dim3(kBlock), 0, stream, p, n, (float)iterations, rgb, rgba,
+                       (bits & 15u) == 0 ? 1 : 0);
     return hipGetLastError();
 }
 

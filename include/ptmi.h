@@ -169,6 +169,15 @@ int ptmi_render1(ptmi_ctx *ctx, const ptmi_camera *camera, int algorithm, int bo
                  float *r_out, float *g_out, float *b_out,
                  uint32_t *sa_out, uint32_t *sb_out, uint32_t *sc_out, uint32_t *sctr_out);
 
+/* ---- present (what graphicsLoop + fs.glsl do with the result) ------------------- */
+/* graphicsLoop interleaves the three colour planes (`V.zipWith3 V3 r g b`, app/Main.hs:351), uploads them
+ * as an RGB32F texture (:383-393) and the fragment shader shows `texture.rgb / u_iterations`
+ * (app/assets/fs.glsl:12) into an 8-bit framebuffer.  This does the same on the device for the held rows:
+ *   rgb32f_out : [rows][W][3] float, colour / float(iterations)            (may be NULL)
+ *   rgba8_out  : [rows][W][4] bytes, round(clamp(colour / iterations, 0, 1) * 255), alpha 255   (may be NULL)
+ * The text overlay of the iteration counter (fs.glsl:15) is UI and not reproduced. */
+int ptmi_present(ptmi_ctx *ctx, int iterations, float *rgb32f_out, uint8_t *rgba8_out);
+
 int ptmi_get_stats(ptmi_ctx *ctx, ptmi_stats *out);   /* synchronises the launch stream */
 int ptmi_reset_stats(ptmi_ctx *ctx);
 

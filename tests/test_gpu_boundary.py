@@ -217,3 +217,24 @@ def test_context_is_usable_from_other_threads(ctx, pkg, ora):
     [t.join() for t in ts]
     for i in range(4):
         assert_planes_equal(results[i], want, "thread %d" % i)
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (61, 7), (1, 1)])
+def test_present_matches_graphics_loop_arithmetic(ctx, pkg, ora, w, h):
+    """app/Main.hs:351 (zipWith3 V3 r g b) + fs.glsl:12 (texture.rgb / u_iterations) + unorm8 framebuffer."""
+    sp, pl = pkg.world.main_scene()
+    ctx.set_scene(sp, pl)
+    ctx.resize(w, h)
+    ctx.init_output(5)
+    iters = 7
+    ctx.render(pkg.world.initial_camera(), 15, iters)
+    r, g, b = ctx.download_color()
+    rgb, rgba = ctx.present(iters)
+    want = np.stack([r, g, b], -1) / np.float32(iters)
+    assert np.array_equal(rgb.view(np.uint32), want.astype(np.float32).view(np.uint32))
+    with np.errstate(invalid="ignore"):
+        clamped = np.where(want > 0, np.minimum(want, np.float32(1.0)), np.float32(0.0)).astype(np.float32)
+    want8 = (clamped * np.float32(255.0) + np.float32(0.5)).astype(np.uint32).astype(np.uint8)
+    assert np.array_equal(rgba[..., :3], want8) and np.all(rgba[..., 3] == 255)
+    with pytest.raises(pkg.PtmiError):
+        ctx.present(0)
