@@ -32,8 +32,15 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_lib(force=False, verbose=False, extra_flags=()):
-    """Compile the shared library if sources are newer than it. Returns its path."""
+def build_lib(force=False, verbose=False, extra_flags=(), out=None):
+    """Compile the shared library if sources are newer than it. Returns its path.
+    `out` + `extra_flags` build a differently-flagged copy elsewhere (diagnostic builds)."""
+    if out is not None:
+        cmd = [hipcc_path()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        return out
     if not force and not is_stale():
         return LIB
     cmd = [hipcc_path()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]

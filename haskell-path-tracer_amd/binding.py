@@ -52,6 +52,7 @@ SYMBOLS = {
     "ptmi_present": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "ptmi_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "ptmi_reset_stats": (C.c_int, [_vp]),
+    "ptmi_debug_counters": (C.c_int, [_vp, _vp]),
     "ptmi_eval_distance_to_sphere": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "ptmi_eval_distance_to_plane": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "ptmi_eval_sincos": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
@@ -251,6 +252,11 @@ class Context:
         st = Stats()
         self._check(self._lib.ptmi_get_stats(self._h, C.byref(st)))
         return {f: getattr(st, f) for f, _ in Stats._fields_}
+
+    def debug_counters(self):
+        out = np.zeros(64, np.uint32)
+        self._check(self._lib.ptmi_debug_counters(self._h, _ptr(out)))
+        return out
 
     def reset_stats(self):
         self._check(self._lib.ptmi_reset_stats(self._h))

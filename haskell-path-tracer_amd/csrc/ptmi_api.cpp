@@ -549,6 +549,17 @@ int ptmi_get_stats(ptmi_ctx *c, ptmi_stats *out)
     return PTMI_OK;
 }
 
+int ptmi_debug_counters(ptmi_ctx *c, uint32_t out[64])
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!out) return fail(c, PTMI_EINVAL, "out is NULL");
+    PTMI_HIP(c, hipSetDevice(c->device));
+    PTMI_HIP(c, hipMemcpyAsync(out, c->d_work, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    return PTMI_OK;
+}
+
 int ptmi_reset_stats(ptmi_ctx *c)
 {
     if (!c) return PTMI_EINVAL;
@@ -557,6 +568,7 @@ int ptmi_reset_stats(ptmi_ctx *c)
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
     PTMI_HIP(c, hipMemsetAsync(c->d_live, 0, sizeof(unsigned long long), c->stream));
     PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, sizeof(unsigned int), c->stream));
+    PTMI_HIP(c, hipMemsetAsync(c->d_work, 0, 64 * sizeof(unsigned int), c->stream));
     c->nominal = 0; c->samples = 0;
     return PTMI_OK;
 }

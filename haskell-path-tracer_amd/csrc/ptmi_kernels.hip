@@ -18,6 +18,10 @@ namespace ptmi {
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef PTMI_FETCH_BATCH
+#define PTMI_FETCH_BATCH 1
+#endif
+constexpr int kFetchBatch = PTMI_FETCH_BATCH;   // lanes that must be idle before the wave fetches pixels
 constexpr int kChunk = 64;      // pixels a wave takes from the global counter per atomic (persistent kernel)
 
 struct HitSel { float t; int idx; bool just; };
@@ -297,9 +301,18 @@ __global__ void __launch_bounds__(kBlock, MODE == kCached ? 6 : 4) render_inline
                     d = mk(get(6), get(7), get(8)); idx = idx0;
                     pending = s < n_spp;
                 };
+#ifdef PTMI_PHASE_STATS
+                unsigned int st_iter = 0, st_a = 0, st_b = 0, st_c = 0;   // this lane's participation per round
+#endif
                 while (pending) {
+#ifdef PTMI_PHASE_STATS
+                    ++st_iter;
+#endif
                     for (int round = 0; round < 2; ++round) {
                         if (pending && !has_ray) {
+#ifdef PTMI_PHASE_STATS
+                            if (round == 0) ++st_a; else ++st_b;
+#endif
                             shade(M, idx, pos, normal, pos, d, throughput, result, seed);
                             ++it; ++live;
                             // the next prepareRay would freeze the path (Trace.hs:364-365)
@@ -307,6 +320,9 @@ __global__ void __launch_bounds__(kBlock, MODE == kCached ? 6 : 4) render_inline
                             else { pending = false; has_ray = true; }
                         }
                     }
+#ifdef PTMI_PHASE_STATS
+                    if (has_ray) ++st_c;
+#endif
                     if (has_ray) {
                         const HitSel h = check_hit(S, ns, np, pos, d);
                         has_ray = false;
@@ -319,6 +335,18 @@ __global__ void __launch_bounds__(kBlock, MODE == kCached ? 6 : 4) render_inline
                         }
                     }
                 }
+#ifdef PTMI_PHASE_STATS
+                // diagnostic build only: [1] lane-iterations, [2..4] lane participations in rounds A, B, C,
+                // [5] max lane-iterations of the wave x lanes that had work (what the wave paid for)
+                {
+                    const unsigned long long m = __ballot(1);
+                    unsigned int mx = st_iter;
+                    for (int off = 32; off > 0; off >>= 1) { const unsigned int o2 = __shfl_xor(mx, off, 64); mx = o2 > mx ? o2 : mx; }
+                    atomicAdd(a.work_counter + 1, st_iter); atomicAdd(a.work_counter + 2, st_a);
+                    atomicAdd(a.work_counter + 3, st_b); atomicAdd(a.work_counter + 4, st_c);
+                    if ((threadIdx.x & 63) == (int)__builtin_ctzll(m)) atomicAdd(a.work_counter + 5, mx * 64u);
+                }
+#endif
             }
         } else if (MODE == kRegenerate) {
             int s = 0, it = 0;
@@ -411,10 +439,19 @@ __global__ void __launch_bounds__(kBlock) render_inline_persistent_kernel(const 
     unsigned long long pool_next = 0, pool_end = 0;          // wave-uniform
     bool queue_empty = false;                                // wave-uniform
 
+#ifdef PTMI_PHASE_STATS
+    unsigned int st_iter = 0, st_a = 0, st_b = 0, st_c = 0;
+#endif
     for (;;) {
+#ifdef PTMI_PHASE_STATS
+        ++st_iter;
+#endif
         // ---- shade: twice, so that a lane whose sample ends in the first round starts the next in the second
         for (int round = 0; round < 2; ++round) {
             if (pending && !has_ray) {
+#ifdef PTMI_PHASE_STATS
+                if (round == 0) ++st_a; else ++st_b;
+#endif
                 shade(M, idx, hit_pos, normal, o, d, throughput, result, seed);
                 ++it; ++live;
                 // the next prepareRay would freeze the path (Trace.hs:364-365)
@@ -439,7 +476,9 @@ __global__ void __launch_bounds__(kBlock) render_inline_persistent_kernel(const 
         }
         const bool want = !pending && !has_ray && !exhausted;
         const unsigned long long want_mask = __ballot(want);
-        if (want_mask) {                                      // wave-uniform
+        // The hand-out block (index arithmetic, seven plane loads, primary ray set-up) runs for the whole wave
+        // whenever it runs, so lanes wait until kFetchBatch of them want a pixel -- or nothing else is in flight.
+        if (want_mask && (__builtin_popcountll(want_mask) >= kFetchBatch || !__any(has_ray || pending))) {   // wave-uniform
             // The wave owns a pool [pool_next, pool_end) of consecutive pixels, refilled kChunk at a time with
             // ONE atomic on the global counter (a single counter word serves only ~90 requests/us on this chip:
             // one atomic per fetched pixel made the kernel 3x slower).  Wanting lanes take pool entries by rank.
@@ -487,6 +526,9 @@ __global__ void __launch_bounds__(kBlock) render_inline_persistent_kernel(const 
             }
         }
         if (!__any(has_ray || pending)) break;               // nothing left in flight in this wave
+#ifdef PTMI_PHASE_STATS
+        if (has_ray) ++st_c;
+#endif
         // ---- trace: every lane that has a ray (next bounce, or the primary ray of a fresh pixel)
         if (has_ray) {
             const HitSel h = check_hit(S, ns, np, o, d);
@@ -514,6 +556,11 @@ __global__ void __launch_bounds__(kBlock) render_inline_persistent_kernel(const 
         const unsigned long long total = wave_sum(live);
         if (lane == 0 && total) atomicAdd(a.live_counter, total);
     }
+#ifdef PTMI_PHASE_STATS
+    // diagnostic build only: [1] wave-iterations x 64, [2..4] lane participations in rounds A, B, C
+    atomicAdd(a.work_counter + 1, st_iter); atomicAdd(a.work_counter + 2, st_a);
+    atomicAdd(a.work_counter + 3, st_b); atomicAdd(a.work_counter + 4, st_c);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------

@@ -180,6 +180,9 @@ int ptmi_present(ptmi_ctx *ctx, int iterations, float *rgb32f_out, uint8_t *rgba
 
 int ptmi_get_stats(ptmi_ctx *ctx, ptmi_stats *out);   /* synchronises the launch stream */
 int ptmi_reset_stats(ptmi_ctx *ctx);
+/* Diagnostics: the 64 raw device counters (hand-out counter in [0]; a -DPTMI_PHASE_STATS build of the kernels
+ * adds round statistics, see tools/phase_stats.py).  Synchronises the launch stream. */
+int ptmi_debug_counters(ptmi_ctx *ctx, uint32_t out[64]);
 
 /* ---- point queries (the reference's unit-test surface) ------------------------ */
 /* Evaluates distanceTo / hit (src/Scene/Intersection.hs:16-64) on the DEVICE for n independent

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""phase_stats.py -- where do the lanes go?  Builds a -DPTMI_PHASE_STATS copy of libptmi (diagnostic,
+never the measured library), renders C2 once with the static kCached kernel and prints, per round of its
+[shade A][shade B][trace C] loop, the fraction of lane-slots that did work, plus the wave-tail factor
+(lane-iterations the waves paid for / lane-iterations needed)."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as graft  # noqa: E402
+
+
+def main():
+    pkg = graft.load_package()
+    out = "/tmp/libptmi_phase_stats.so"
+    pkg._build.build_lib(out=out, extra_flags=["-DPTMI_PHASE_STATS"])
+    pkg.binding._lib = None
+    pkg.binding.load_library(out)
+    sp, pl = pkg.world.scene16()
+    w, h, spp = 1920, 1080, 64
+    with pkg.Context(0) as ctx:
+        ctx.set_scene(sp, pl)
+        ctx.resize(w, h)
+        ctx.set_variant(4)
+        ctx.init_output(0x5EED1234)
+        ctx.reset_stats()
+        ctx.render(pkg.world.initial_camera(), 8, spp)
+        c = ctx.debug_counters().astype(float)
+        ctx.set_variant(1)
+        ctx.init_output(0x5EED1234)
+        ctx.reset_stats()
+        ctx.render(pkg.world.initial_camera(), 8, spp)
+        p = ctx.debug_counters().astype(float)
+    print(json.dumps({"persistent_kernel": {
+        "lane_slots_paid": p[1], "round_A_occupancy": p[2] / p[1], "round_B_occupancy": p[3] / p[1],
+        "round_C_occupancy": p[4] / p[1], "useful_trace_slots": p[4]}}))
+    lane_iter, a, b, cc, paid = c[1], c[2], c[3], c[4], c[5]
+    print(json.dumps({
+        "lane_iterations_needed": lane_iter, "lane_iterations_paid_by_waves": paid,
+        "wave_tail_factor": paid / lane_iter,
+        "round_A_occupancy": a / lane_iter, "round_B_occupancy": b / lane_iter, "round_C_occupancy": cc / lane_iter,
+        "iterations_per_sample": lane_iter / (w * h * spp)}))
+
+
+if __name__ == "__main__":
+    main()
