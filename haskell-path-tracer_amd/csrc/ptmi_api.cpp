@@ -50,6 +50,13 @@ struct ptmi_ctx {
     // scratch for ptmi_render1 / point queries
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+
+    // wavefront Streams (scenes with the GLASS extension): two ray streams + {next length, dropped}
+    bool has_glass = false;
+    void *queue_block = nullptr;
+    size_t queue_capacity = 0;
+    unsigned int *d_qcount = nullptr;
+    uint64_t rays_dropped = 0;
 };
 
 namespace {
@@ -149,6 +156,59 @@ void pack_scene(const ptmi_sphere *sph, int ns, const ptmi_plane *pl, int np, st
     for (int j = 0; j < np; ++j) mat(pl[j].color, pl[j].illuminance, pl[j].brdf_tag, pl[j].brdf_param);
 }
 
+constexpr int kStreamCapacityFactor = 4;     // next stream holds at most 4 rays per pixel; excess children are dropped and counted
+constexpr int kStreamHardCap = 64;           // steps per sample; the reference has no bound (Trace.hs:166-170)
+
+RayQueue carve_queue(void *block, size_t capacity, int which)
+{
+    RayQueue q;
+    char *b = static_cast<char *>(block) + (size_t)which * kRayQueueWords * capacity * 4;
+    for (int k = 0; k < 9; ++k) q.f[k] = reinterpret_cast<float *>(b + (size_t)k * capacity * 4);
+    q.pixel = reinterpret_cast<uint32_t *>(b + (size_t)9 * capacity * 4);
+    for (int k = 0; k < 4; ++k) q.seed[k] = reinterpret_cast<uint32_t *>(b + (size_t)(10 + k) * capacity * 4);
+    q.capacity = (unsigned int)capacity;
+    return q;
+}
+
+// `render Streams` as a stream: awhile (Trace.hs:142-150) on the host, one traceStep launch per iteration, the
+// length of the next stream read back after every step (that read-back is the loop's predicate, `null state`).
+int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
+{
+    const size_t n = (size_t)a.rows_local * a.width;
+    if (n == 0 || n_spp <= 0) return PTMI_OK;
+    if (n * kStreamCapacityFactor > 0xffffffffull) return fail(c, PTMI_ELIMIT, "image too large for the wavefront Streams path");
+    const size_t capacity = n * kStreamCapacityFactor;
+    if (capacity != c->queue_capacity) {
+        if (c->queue_block) { (void)hipFree(c->queue_block); c->queue_block = nullptr; c->queue_capacity = 0; }
+        PTMI_HIP(c, hipMalloc(&c->queue_block, 2 * (size_t)kRayQueueWords * capacity * 4));
+        c->queue_capacity = capacity;
+    }
+    if (!c->d_qcount) PTMI_HIP(c, hipMalloc(&c->d_qcount, 2 * sizeof(unsigned int)));
+    RayQueue q[2] = {carve_queue(c->queue_block, capacity, 0), carve_queue(c->queue_block, capacity, 1)};
+    unsigned int longest = 0;
+    for (int s = 0; s < n_spp; ++s) {
+        PTMI_HIP(c, launch_streams_init(a, q[0], c->stream));
+        unsigned int n_cur = (unsigned int)n, steps = 0;
+        int cur = 0;
+        while (n_cur > 0 && steps < (unsigned int)kStreamHardCap) {
+            unsigned int h[2] = {0, 0};
+            PTMI_HIP(c, hipMemsetAsync(c->d_qcount, 0, 2 * sizeof(unsigned int), c->stream));
+            PTMI_HIP(c, launch_streams_step(a, q[cur], n_cur, q[cur ^ 1], c->d_qcount, c->d_qcount + 1, c->stream));
+            PTMI_HIP(c, hipMemcpyAsync(h, c->d_qcount, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+            PTMI_HIP(c, hipStreamSynchronize(c->stream));
+            c->rays_dropped += h[1];
+            n_cur = h[0] < (unsigned int)capacity ? h[0] : (unsigned int)capacity;
+            cur ^= 1;
+            ++steps;
+        }
+        longest = steps > longest ? steps : longest;
+        PTMI_HIP(c, launch_streams_update_seed(a.planes, (long long)n, c->stream));
+    }
+    PTMI_HIP(c, hipMemcpyAsync(c->d_iters, &longest, sizeof longest, hipMemcpyHostToDevice, c->stream));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    return PTMI_OK;
+}
+
 int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, int algorithm,
                   int bounce_limit, int n_spp, int width, int height, int rows_local,
                   int stripe_rows, int n_parts, int part, const int64_t *sx, const int64_t *sy)
@@ -165,6 +225,8 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
     if (c->timing) { PTMI_HIP(c, hipEventRecord(c->ev0, c->stream)); }
     if (algorithm == PTMI_INLINE) {
         PTMI_HIP(c, launch_render_inline(a, c->variant, c->stream));
+    } else if (c->has_glass || c->variant == 9) {          // rays may split: the stream form (variant 9 forces it)
+        if (int rc = render_streams_wavefront(c, a, n_spp)) return rc;
     } else {
         PTMI_HIP(c, launch_render_streams(a, c->variant, c->stream));
     }
@@ -182,6 +244,9 @@ int check_render_args(ptmi_ctx *c, const ptmi_camera *camera, int algorithm, int
     if (bounce_limit < 0) return fail(c, PTMI_EINVAL, "bounce_limit < 0");
     if (n_spp < 0) return fail(c, PTMI_EINVAL, "n_spp < 0");
     if (!c->d_scene) return fail(c, PTMI_ESTATE, "ptmi_set_scene has not been called");
+    // "features that require diverging rays like light refraction" need the stream algorithm (Trace.hs:56-67)
+    if (algorithm == PTMI_INLINE && c->has_glass)
+        return fail(c, PTMI_EINVAL, "the scene holds a GLASS material: render Inline cannot split rays, use PTMI_STREAMS");
     return PTMI_OK;
 }
 
@@ -253,6 +318,8 @@ void ptmi_destroy(ptmi_ctx *c)
     if (c->d_work) (void)hipFree(c->d_work);
     if (c->d_iters) (void)hipFree(c->d_iters);
     if (c->scratch) (void)hipFree(c->scratch);
+    if (c->queue_block) (void)hipFree(c->queue_block);
+    if (c->d_qcount) (void)hipFree(c->d_qcount);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -269,10 +336,10 @@ int ptmi_set_scene(ptmi_ctx *c, const ptmi_sphere *spheres, int n_spheres, const
     if (n_spheres + n_planes == 0) return fail(c, PTMI_EINVAL, "empty scene (expMinWith on an empty list)");
     if (n_spheres + n_planes > PTMI_MAX_PRIMITIVES) return fail(c, PTMI_ELIMIT, "too many primitives");
     for (int i = 0; i < n_spheres; ++i)
-        if (spheres[i].brdf_tag != PTMI_MATTE && spheres[i].brdf_tag != PTMI_GLOSSY)
+        if (spheres[i].brdf_tag < PTMI_MATTE || spheres[i].brdf_tag > PTMI_GLASS)
             return fail(c, PTMI_EINVAL, "sphere with unknown brdf_tag");
     for (int j = 0; j < n_planes; ++j)
-        if (planes[j].brdf_tag != PTMI_MATTE && planes[j].brdf_tag != PTMI_GLOSSY)
+        if (planes[j].brdf_tag < PTMI_MATTE || planes[j].brdf_tag > PTMI_GLASS)
             return fail(c, PTMI_EINVAL, "plane with unknown brdf_tag");
     PTMI_HIP(c, hipSetDevice(c->device));
     std::vector<float4> packed;
@@ -283,6 +350,9 @@ int ptmi_set_scene(ptmi_ctx *c, const ptmi_sphere *spheres, int n_spheres, const
     PTMI_HIP(c, hipMemcpyAsync(c->d_scene, packed.data(), packed.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));               // `packed` dies at return
     c->n_spheres = n_spheres; c->n_planes = n_planes;
+    c->has_glass = false;
+    for (int i = 0; i < n_spheres; ++i) c->has_glass |= spheres[i].brdf_tag == PTMI_GLASS;
+    for (int j = 0; j < n_planes; ++j) c->has_glass |= planes[j].brdf_tag == PTMI_GLASS;
     return PTMI_OK;
 }
 
@@ -370,7 +440,7 @@ int ptmi_set_variant(ptmi_ctx *c, int variant)
 {
     if (!c) return PTMI_EINVAL;
     std::lock_guard<std::mutex> lock(c->mu);
-    if (variant < 0 || variant > 15) return fail(c, PTMI_EINVAL, "unknown variant");
+    if (variant < 0 || variant > 9) return fail(c, PTMI_EINVAL, "unknown variant");
     c->variant = variant;
     return PTMI_OK;
 }
@@ -544,6 +614,7 @@ int ptmi_get_stats(ptmi_ctx *c, ptmi_stats *out)
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
     out->live_bounces = live; out->nominal_bounces = c->nominal; out->samples = c->samples;
     out->stream_iterations = iters;
+    out->stream_rays_dropped = c->rays_dropped;
     out->last_render_ms = 0.0f;
     if (c->timing && c->ev_valid) PTMI_HIP(c, hipEventElapsedTime(&out->last_render_ms, c->ev0, c->ev1));
     return PTMI_OK;
@@ -569,7 +640,7 @@ int ptmi_reset_stats(ptmi_ctx *c)
     PTMI_HIP(c, hipMemsetAsync(c->d_live, 0, sizeof(unsigned long long), c->stream));
     PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, sizeof(unsigned int), c->stream));
     PTMI_HIP(c, hipMemsetAsync(c->d_work, 0, 64 * sizeof(unsigned int), c->stream));
-    c->nominal = 0; c->samples = 0;
+    c->nominal = 0; c->samples = 0; c->rays_dropped = 0;
     return PTMI_OK;
 }
 

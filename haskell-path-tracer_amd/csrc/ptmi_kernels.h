@@ -38,6 +38,20 @@ struct RenderArgs {
     unsigned int *stream_iterations;      // Streams: steps taken by the last sample (max over waves)
 };
 
+// Ray stream of the wavefront Streams path: struct-of-arrays, `capacity` rays (type RayState, Trace.hs:46)
+struct RayQueue {
+    float *f[9];            // origin xyz, direction xyz, throughput xyz
+    uint32_t *pixel;        // local pixel index
+    uint32_t *seed[4];      // SFC32 a, b, c, counter
+    unsigned int capacity;
+};
+constexpr int kRayQueueWords = 14;
+
+hipError_t launch_streams_init(const RenderArgs &a, RayQueue q, hipStream_t stream);
+hipError_t launch_streams_step(const RenderArgs &a, RayQueue in, unsigned int n_in, RayQueue out,
+                               unsigned int *out_count, unsigned int *dropped, hipStream_t stream);
+hipError_t launch_streams_update_seed(Planes p, long long n, hipStream_t stream);
+
 hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t stream);
 hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t stream);
 hipError_t launch_seed(Planes p, int width, int rows_local, int stripe_rows, int n_parts, int part,

@@ -668,6 +668,145 @@ __global__ void __launch_bounds__(kBlock) render_streams_kernel(const RenderArgs
 }
 
 // ---------------------------------------------------------------------------------------
+// render Streams as a stream ("wavefront" path): used when a ray can split, i.e. when the scene holds the
+// build-defined GLASS material (numNewRays = 2; the reference only announces such materials, Trace.hs:109-118,
+// :306-307, :327-328 -- there are NO reference semantics for GLASS; the definition is glass_children below,
+// mirrored by the oracle).  One launch per traceStep (Trace.hs:272-294):
+//   map checkHit over the stream; computeResult for every hit -> `permute (+)` = float atomics into the
+//   colour planes; `expand` = wave-level compaction: ballot of the lanes that emit a child, popcount prefix
+//   for the slot, ONE atomic per wave on the next stream's length.  A lane never waits for another.
+// Without GLASS every pixel has at most one ray per step, so every colour word sees one adder per launch and
+// the result equals the per-pixel chain kernel bit for bit (tested); with GLASS several rays of one pixel may
+// add in the same launch and the order of those additions is not defined (neither is it in Accelerate's
+// permute), so GLASS scenes are compared with a tolerance.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void queue_store(const RayQueue &q, unsigned int i, V3 o, V3 d, V3 t, uint32_t pixel, Sfc32 s)
+{
+    q.f[0][i] = o.x; q.f[1][i] = o.y; q.f[2][i] = o.z;
+    q.f[3][i] = d.x; q.f[4][i] = d.y; q.f[5][i] = d.z;
+    q.f[6][i] = t.x; q.f[7][i] = t.y; q.f[8][i] = t.z;
+    q.pixel[i] = pixel;
+    q.seed[0][i] = s.a; q.seed[1][i] = s.b; q.seed[2][i] = s.c; q.seed[3][i] = s.counter;
+}
+
+// GLASS ior (extension): reflection child + refraction child; see the oracle's glass_children for the spec.
+__device__ __forceinline__ void glass_children(V3 color, float ior, V3 p, V3 n, V3 d, V3 throughput, Sfc32 seed,
+                                               V3 o_out[2], V3 d_out[2], V3 t_out[2], Sfc32 s_out[2])
+{
+    (void)gen_component(seed); (void)gen_component(seed); (void)gen_component(seed);   // genVec is drawn before the match
+    const float dn = dot(d, n);
+    const float cosi = -dn;
+    const float eta = 1.0f / ior;
+    const float k = 1.0f - (eta * eta) * (1.0f - cosi * cosi);
+    const V3 reflection = d - scale_l(2.0f * dn, n);
+    float r0 = (1.0f - ior) / (1.0f + ior); r0 = r0 * r0;
+    const float mm = 1.0f - cosi;
+    float R = r0 + (1.0f - r0) * (((mm * mm) * (mm * mm)) * mm);
+    V3 refraction;
+    if (k < 0.0f) { R = 1.0f; refraction = reflection; }
+    else refraction = scale_l(eta, d) + scale_l(eta * cosi - __builtin_sqrtf(k), n);
+    o_out[0] = p + scale_r(reflection, kEpsilon); d_out[0] = reflection;
+    t_out[0] = throughput * scale_r(color, R);
+    s_out[0] = seed;
+    o_out[1] = p + scale_r(refraction, kEpsilon); d_out[1] = refraction;
+    t_out[1] = throughput * scale_r(color, 1.0f - R);
+    (void)random_float(seed);
+    s_out[1] = seed;
+}
+
+__global__ void __launch_bounds__(kBlock) streams_init_kernel(const RenderArgs a, RayQueue q)
+{
+    const long long n_local = (long long)a.rows_local * a.width;
+    const long long pixel = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (pixel >= n_local) return;
+    const int local_row = (int)(pixel / a.width);
+    const int col = (int)(pixel - (long long)local_row * a.width);
+    const V3 primary = primary_direction(a.cam, col, global_row(local_row, a.stripe_rows, a.n_parts, a.part));
+    Sfc32 s;
+    s.a = a.planes.sa[pixel]; s.b = a.planes.sb[pixel]; s.c = a.planes.sc[pixel]; s.counter = a.planes.sctr[pixel];
+    queue_store(q, (unsigned int)pixel, a.cam.pos, primary, mk(1.0f, 1.0f, 1.0f), (uint32_t)pixel, s);   // initialState (Trace.hs:158-162)
+}
+
+template <bool LDS_SCENE>
+__global__ void __launch_bounds__(kBlock) streams_step_kernel(const RenderArgs a, const RayQueue in, unsigned int n_in,
+                                                              const RayQueue out, unsigned int *out_count,
+                                                              unsigned int *dropped)
+{
+    extern __shared__ float4 lds_scene[];
+    const int ns = a.scene.n_spheres, np = a.scene.n_planes;
+    if (LDS_SCENE) {
+        const int total = a.scene.total_f4();
+        for (int i = threadIdx.x; i < total; i += kBlock) lds_scene[i] = a.scene.packed[i];
+        __syncthreads();
+    }
+    const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
+    const float4 *M = S + a.scene.geom_f4();
+    const unsigned int i = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+
+    int n_kids = 0;
+    V3 ko[2], kd[2], kt[2]; Sfc32 ks[2];
+    uint32_t pixel = 0;
+    if (i < n_in) {
+        V3 o = mk(in.f[0][i], in.f[1][i], in.f[2][i]);
+        V3 d = mk(in.f[3][i], in.f[4][i], in.f[5][i]);
+        V3 throughput = mk(in.f[6][i], in.f[7][i], in.f[8][i]);
+        pixel = in.pixel[i];
+        Sfc32 seed;
+        seed.a = in.seed[0][i]; seed.b = in.seed[1][i]; seed.c = in.seed[2][i]; seed.counter = in.seed[3][i];
+        const HitSel h = check_hit(S, ns, np, o, d);
+        if (h.just) {
+            V3 hit_pos, normal;
+            hit_record(S, ns, h.idx, o, d, h.t, hit_pos, normal);
+            const float4 ma = M[2 * h.idx], mb = M[2 * h.idx + 1];
+            const bool alive = !near_zero(throughput);                      // numNewRays (Trace.hs:329-331)
+            V3 contribution;
+            if (f2u(mb.x) == 2u) {                                          // GLASS
+                contribution = scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput;
+                if (alive) { glass_children(mk(ma.x, ma.y, ma.z), mb.y, hit_pos, normal, d, throughput, seed, ko, kd, kt, ks); n_kids = 2; }
+            } else {
+                contribution = mk(0.0f, 0.0f, 0.0f);
+                shade(M, h.idx, hit_pos, normal, o, d, throughput, contribution, seed);   // contribution = 0 + emittance * throughput
+                if (alive) { ko[0] = o; kd[0] = d; kt[0] = throughput; ks[0] = seed; n_kids = 1; }
+            }
+            // computeResult + permute (+) (Trace.hs:179-184, :318-323); adding an exact zero changes nothing
+            if (contribution.x != 0.0f) atomicAdd(a.planes.r + pixel, contribution.x);
+            if (contribution.y != 0.0f) atomicAdd(a.planes.g + pixel, contribution.y);
+            if (contribution.z != 0.0f) atomicAdd(a.planes.b + pixel, contribution.z);
+        }
+    }
+    // expand (Trace.hs:284-289): compaction of the children into the next stream, child 0 then child 1
+    unsigned int emitted = 0;
+    for (int k = 0; k < 2; ++k) {
+        const bool has = n_kids > k;
+        const unsigned long long mask = __ballot(has);
+        if (!mask) continue;                                               // wave-uniform
+        const int leader = (int)__builtin_ctzll(mask);
+        unsigned int base = 0;
+        if (lane == leader) base = atomicAdd(out_count, (unsigned int)__builtin_popcountll(mask));
+        base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
+        if (has) {
+            const unsigned int slot = base + (unsigned int)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            if (slot < out.capacity) { queue_store(out, slot, ko[k], kd[k], kt[k], pixel, ks[k]); ++emitted; }
+            else atomicAdd(dropped, 1u);
+        }
+    }
+    if (a.live_counter) {
+        const unsigned long long total = wave_sum(emitted);
+        if (lane == 0 && total) atomicAdd(a.live_counter, total);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) streams_update_seed_kernel(Planes p, long long n)
+{
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    Sfc32 s; s.a = p.sa[i]; s.b = p.sb[i]; s.c = p.sc[i]; s.counter = p.sctr[i];
+    (void)random_float(s);                                                  // updateSeed (Trace.hs:190-191)
+    p.sa[i] = s.a; p.sb[i] = s.b; p.sc[i] = s.c; p.sctr[i] = s.counter;
+}
+
+// ---------------------------------------------------------------------------------------
 // genSeeds / createWith / initialOutput / reseed  (src/Util.hs:122-135, 204-205)
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) seed_kernel(Planes p, int width, int rows_local, int stripe_rows,
@@ -853,6 +992,31 @@ hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t s
     if (e != hipSuccess) return e;
     if (variant == 5 || variant == 6) hipLaunchKernelGGL((render_streams_kernel<false>), grid, block, 0, stream, a);
     else                              hipLaunchKernelGGL((render_streams_kernel<true>), grid, block, lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_streams_init(const RenderArgs &a, RayQueue q, hipStream_t stream)
+{
+    const long long n = (long long)a.rows_local * a.width;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(streams_init_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, a, q);
+    return hipGetLastError();
+}
+
+hipError_t launch_streams_step(const RenderArgs &a, RayQueue in, unsigned int n_in, RayQueue out,
+                               unsigned int *out_count, unsigned int *dropped, hipStream_t stream)
+{
+    if (n_in == 0) return hipSuccess;
+    const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
+    hipLaunchKernelGGL((streams_step_kernel<true>), dim3(blocks_for(n_in)), dim3(kBlock), lds, stream, a, in, n_in, out,
+                       out_count, dropped);
+    return hipGetLastError();
+}
+
+hipError_t launch_streams_update_seed(Planes p, long long n, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(streams_update_seed_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, p, n);
     return hipGetLastError();
 }
 

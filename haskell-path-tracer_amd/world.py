@@ -7,6 +7,7 @@ SURVEY.md 8(d): main scene + a 3x3 grid of unit spheres.
 import numpy as np
 
 MATTE, GLOSSY = 0, 1          # data Brdf = Matte Float | Glossy Float  (src/Scene/Objects.hs:77-87)
+GLASS = 2                     # build-defined extension (no reference semantics); parameter = index of refraction
 STREAMS, INLINE = 0, 1        # data Algorithm = Streams | Inline        (src/Scene/Trace.hs:68)
 
 # field order = src/Scene/Objects.hs (Sphere :126-131, Plane :103-108, Material :90-100, Camera :67-74)
@@ -69,6 +70,18 @@ def scene16():
             extra.append(sphere((-6.0 + 6.0 * i, 0.0, -6.0 - 6.0 * j), 1.0,
                                 (0.2 + 0.3 * i, 0.5, 0.2 + 0.3 * j), 0.0, tag, p))
     spheres = np.concatenate([spheres, np.array(extra, dtype=SPHERE_DTYPE)])
+    return spheres, planes
+
+
+def glass_scene():
+    """BASELINE.json configs[4] ("glass / refraction-heavy scene"): scene16 with the big sphere and four of the
+    grid spheres turned into GLASS (ior 1.5 / 1.33).  Build-defined; the reference has no such material."""
+    spheres, planes = scene16()
+    spheres = spheres.copy()
+    for i, ior in ((0, 1.5), (5, 1.5), (7, 1.33), (9, 1.5), (11, 1.33)):
+        spheres["brdf_tag"][i] = GLASS
+        spheres["brdf_param"][i] = ior
+        spheres["color"][i] = (0.95, 0.95, 0.95)
     return spheres, planes
 
 

@@ -51,8 +51,12 @@ enum {
 /* data Algorithm = Streams | Inline                       (src/Scene/Trace.hs:68) */
 enum { PTMI_STREAMS = 0, PTMI_INLINE = 1 };
 
-/* data Brdf = Matte Float | Glossy Float                 (src/Scene/Objects.hs:77-87) */
-enum { PTMI_MATTE = 0, PTMI_GLOSSY = 1 };
+/* data Brdf = Matte Float | Glossy Float                 (src/Scene/Objects.hs:77-87)
+ * PTMI_GLASS is a build-defined EXTENSION (parameter = index of refraction): a hit spawns a reflection and a
+ * refraction ray.  The reference only announces such materials (src/Scene/Trace.hs:109-118, :306-307, :327-328),
+ * so GLASS has no reference semantics; it is accepted by PTMI_STREAMS only (Inline cannot split rays,
+ * src/Scene/Trace.hs:62-67) and rendered by the stream ("wavefront") form of Streams.  See DESIGN.md. */
+enum { PTMI_MATTE = 0, PTMI_GLOSSY = 1, PTMI_GLASS = 2 };
 
 #define PTMI_MAX_PRIMITIVES 1024   /* spheres + planes staged in LDS per workgroup */
 
@@ -62,7 +66,7 @@ typedef struct ptmi_sphere {       /* data Sphere   Objects.hs:126-131, Material
     float   radius;
     float   color[3];
     float   illuminance;
-    int32_t brdf_tag;              /* PTMI_MATTE | PTMI_GLOSSY */
+    int32_t brdf_tag;              /* PTMI_MATTE | PTMI_GLOSSY (| PTMI_GLASS, extension) */
     float   brdf_param;
 } ptmi_sphere;                     /* 10 words */
 
@@ -87,6 +91,7 @@ typedef struct ptmi_stats {
     uint64_t samples;              /* pixels x samples                                                       */
     float    last_render_ms;       /* device time of the last ptmi_render launch(es); 0 unless timing is on */
     uint32_t stream_iterations;    /* Streams: steps of the last sample's awhile loop                        */
+    uint64_t stream_rays_dropped;  /* wavefront Streams: children that did not fit the next stream (4 rays/pixel) */
 } ptmi_stats;
 
 typedef struct ptmi_ctx ptmi_ctx;

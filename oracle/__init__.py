@@ -76,6 +76,9 @@ def lib():
                                         C.c_void_p, C.c_void_p] + [C.c_void_p] * 7 + [C.c_int]
         L.ora_render_streams.restype = C.c_int64
         L.ora_render_streams.argtypes = [C.POINTER(_Scene), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7
+        L.ora_render_streams_wavefront.restype = C.c_int64
+        L.ora_render_streams_wavefront.argtypes = ([C.POINTER(_Scene), C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 7 +
+                                                   [C.POINTER(C.c_int64), C.POINTER(C.c_int)])
         L.ora_gen_seeds.restype = None
         L.ora_gen_seeds.argtypes = [C.c_uint64, C.c_int64, C.c_int64] + [C.c_void_p] * 4
         L.ora_sfc32_next.restype = C.c_uint32; L.ora_sfc32_next.argtypes = [C.POINTER(_Sfc)]
@@ -199,6 +202,18 @@ def render_streams(spheres, planes, camera, width, height, max_iterations, n_spp
     live = lib().ora_render_streams(C.byref(sc), _p(cam), width, height, max_iterations, n_spp,
                                     *[_p(a) for a in outs])
     return tuple(outs), int(live)
+
+
+def render_streams_wavefront(spheres, planes, camera, width, height, hard_cap, n_spp, planes_in, capacity_factor=4):
+    """Streams as a stream (supports the build-defined GLASS extension). -> (planes, live, dropped, steps)"""
+    sc, keep = _scene(spheres, planes)
+    cam = np.ascontiguousarray(camera, CAMERA_DTYPE)
+    outs = [np.array(a, dtype=np.float32, copy=True).reshape(height, width) for a in planes_in[:3]] + \
+           [np.array(a, dtype=np.uint32, copy=True).reshape(height, width) for a in planes_in[3:]]
+    dropped, steps = C.c_int64(0), C.c_int(0)
+    live = lib().ora_render_streams_wavefront(C.byref(sc), _p(cam), width, height, hard_cap, n_spp, capacity_factor,
+                                              *[_p(a) for a in outs], C.byref(dropped), C.byref(steps))
+    return tuple(outs), int(live), int(dropped.value), int(steps.value)
 
 
 def max_threads():

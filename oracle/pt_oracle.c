@@ -567,6 +567,105 @@ int64_t ora_render_streams(const ora_scene *scene, const ora_camera *cam,
     return live_total;
 }
 
+/* ========================================================================== */
+/* Streams as a stream, with the build-defined GLASS extension                 */
+/* ========================================================================== */
+typedef struct { ora_ray ray; int64_t pixel; ora_v3 throughput; ora_sfc32 seed; } ora_ray_state;   /* Trace.hs:46 */
+
+/* GLASS (extension, no reference semantics; the reference only says rays "will expand into zero, one, or
+ * two new rays", Trace.hs:109-113).  Defined here, mirrored by the device:
+ *   (rv, seed') = genVec seed                       -- drawn before the match on the BRDF (Trace.hs:402)
+ *   dn = d . n ; cosi = -dn ; eta = 1 / ior ; k = 1 - (eta*eta) * (1 - cosi*cosi)
+ *   reflection = d - (2*dn) *^ n                     -- the Glossy formula (Trace.hs:421)
+ *   r0 = ((1-ior)/(1+ior))^2 ; m = 1 - cosi ; R = r0 + (1-r0) * (((m*m)*(m*m))*m)   -- Schlick
+ *   k < 0 (total internal reflection):  R = 1, refraction = reflection
+ *   else refraction = eta *^ d + (eta*cosi - sqrt k) *^ n
+ *   child 0 = (iPoint + reflection ^* epsilon, reflection), throughput * (color ^* R),     seed'
+ *   child 1 = (iPoint + refraction ^* epsilon, refraction), throughput * (color ^* (1-R)), seed' advanced one draw
+ * Back faces are culled by distanceTo, so a refracted ray never meets the far side of its sphere.       */
+static void glass_children(const ora_material *m, ora_ray normal_p, ora_ray ray, ora_v3 throughput, ora_sfc32 seed,
+                           ora_ray_state out[2])
+{
+    ora_v3 n = normal_p.direction, d = ray.direction, p = normal_p.origin;
+    (void)ora_gen_vec(&seed);
+    float ior = m->brdf_param;
+    float dn = v3_dot(d, n);
+    float cosi = -dn;
+    float eta = 1.0f / ior;
+    float k = 1.0f - (eta * eta) * (1.0f - cosi * cosi);
+    ora_v3 reflection = v3_sub(d, v3_scale_l(2.0f * dn, n));
+    float r0 = (1.0f - ior) / (1.0f + ior); r0 = r0 * r0;
+    float mm = 1.0f - cosi;
+    float R = r0 + (1.0f - r0) * (((mm * mm) * (mm * mm)) * mm);
+    ora_v3 refraction;
+    if (k < 0.0f) { R = 1.0f; refraction = reflection; }
+    else refraction = v3_add(v3_scale_l(eta, d), v3_scale_l(eta * cosi - sqrtf(k), n));
+    out[0].ray.origin = v3_add(p, v3_scale_r(reflection, ORA_EPSILON)); out[0].ray.direction = reflection;
+    out[0].throughput = v3_mul(throughput, v3_scale_r(m->color, R));
+    out[0].seed = seed;
+    out[1].ray.origin = v3_add(p, v3_scale_r(refraction, ORA_EPSILON)); out[1].ray.direction = refraction;
+    out[1].throughput = v3_mul(throughput, v3_scale_r(m->color, 1.0f - R));
+    (void)ora_random_float(&seed);
+    out[1].seed = seed;
+}
+
+int64_t ora_render_streams_wavefront(const ora_scene *scene, const ora_camera *cam,
+                                     int width, int height, int hard_cap, int n_spp, int capacity_factor,
+                                     float *r, float *g, float *b,
+                                     uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr,
+                                     int64_t *dropped, int *steps_last_sample)
+{
+    const int64_t n_px = (int64_t)width * height, cap = n_px * (capacity_factor > 0 ? capacity_factor : 1);
+    ora_primary_uniforms u = ora_primary_setup(cam, width, height);
+    ora_ray_state *cur = malloc(sizeof *cur * (size_t)cap), *nxt = malloc(sizeof *nxt * (size_t)cap);
+    int64_t live_total = 0, n_dropped = 0;
+    int steps = 0;
+    for (int s = 0; s < n_spp; ++s) {
+        int64_t n_cur = n_px;                                   /* initialState (Trace.hs:158-162) */
+        for (int64_t i = 0; i < n_px; ++i) {
+            cur[i].ray = ora_primary_ray(&u, i % width, i / width, width, height);
+            cur[i].pixel = i; cur[i].throughput = v3(1.0f, 1.0f, 1.0f);
+            cur[i].seed.a = sa[i]; cur[i].seed.b = sb[i]; cur[i].seed.c = sc[i]; cur[i].seed.counter = sctr[i];
+        }
+        for (steps = 0; n_cur > 0 && steps < hard_cap; ++steps) {          /* awhile notFinished (:142-150, :166-170) */
+            int64_t n_nxt = 0;
+            for (int64_t i = 0; i < n_cur; ++i) {                         /* traceStep (:272-294) */
+                const ora_ray_state *rs = &cur[i];
+                ora_maybe_hit hit = ora_check_hit(scene, rs->ray);
+                if (!hit.is_just) continue;
+                ora_v3 emittance = v3_scale_r(hit.material.color, hit.material.illuminance);
+                ora_v3 c = v3_mul(emittance, rs->throughput);                /* computeResult (:318-323) */
+                r[rs->pixel] = r[rs->pixel] + c.x; g[rs->pixel] = g[rs->pixel] + c.y; b[rs->pixel] = b[rs->pixel] + c.z;   /* permute (+) */
+                if (ora_near_zero_v3(rs->throughput)) continue;              /* numNewRays (:329-331) */
+                ora_ray_state kids[2]; int n_kids;
+                if (hit.material.brdf_tag == ORA_GLASS) {
+                    glass_children(&hit.material, hit.normal_p, rs->ray, rs->throughput, rs->seed, kids);
+                    n_kids = 2;
+                } else {
+                    ora_v3 tmod;
+                    ora_calc_next_ray(&hit.material, hit.normal_p, rs->ray, rs->seed, &kids[0].ray, &tmod, &kids[0].seed);
+                    kids[0].throughput = v3_mul(rs->throughput, tmod);
+                    n_kids = 1;
+                }
+                for (int kk = 0; kk < n_kids; ++kk) {                        /* expand: children in element order */
+                    if (n_nxt < cap) { kids[kk].pixel = rs->pixel; nxt[n_nxt++] = kids[kk]; ++live_total; }
+                    else ++n_dropped;
+                }
+            }
+            ora_ray_state *t = cur; cur = nxt; nxt = t; n_cur = n_nxt;
+        }
+        for (int64_t i = 0; i < n_px; ++i) {                                 /* map updateSeed (:151, :190-191) */
+            ora_sfc32 sd = { sa[i], sb[i], sc[i], sctr[i] };
+            (void)ora_random_float(&sd);
+            sa[i] = sd.a; sb[i] = sd.b; sc[i] = sd.c; sctr[i] = sd.counter;
+        }
+    }
+    free(cur); free(nxt);
+    if (dropped) *dropped = n_dropped;
+    if (steps_last_sample) *steps_last_sample = steps;
+    return live_total;
+}
+
 int ora_max_threads(void)
 {
 #ifdef _OPENMP

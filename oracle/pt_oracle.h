@@ -39,7 +39,8 @@ typedef struct { float w; ora_v3 v; } ora_quat;           /* linear: Quaternion 
 typedef struct { uint32_t a, b, c, counter; } ora_sfc32;  /* sfc-random-accelerate (L0)        */
 typedef struct { ora_v3 origin, direction; } ora_ray;     /* Objects.hs:114-123 (also NormalP) */
 
-enum { ORA_MATTE = 0, ORA_GLOSSY = 1 };                   /* Objects.hs:77-87 constructor tags */
+enum { ORA_MATTE = 0, ORA_GLOSSY = 1,                     /* Objects.hs:77-87 constructor tags */
+       ORA_GLASS = 2 };                                   /* build-defined extension (no reference semantics), Streams only */
 
 /* Flat records, 10 and 12 32-bit words; identical in layout to ptmi_sphere /
  * ptmi_plane of include/ptmi.h so tests can hand the same bytes to both. */
@@ -134,6 +135,19 @@ int64_t ora_render_streams(const ora_scene *scene, const ora_camera *cam,
                            int width, int height, int max_iterations, int n_spp,
                            float *r, float *g, float *b,
                            uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr);
+
+/* `render Streams` as an actual stream (Trace.hs:141-191, 272-331): a vector of ray states, one
+ * traceStep per iteration, `expand` (children appended in element order) and `permute (+)`.  With only
+ * Matte / Glossy materials it equals ora_render_streams bit for bit.  It also defines the build's GLASS
+ * extension (numNewRays = 2: reflection + refraction children; see pt_oracle.c) -- the reference has no
+ * such material (TODOs at Trace.hs:117-118, :306-307, :327-328), so this part has NO reference semantics.
+ * The next stream holds at most capacity_factor * width * height rays; excess children are dropped and
+ * counted in *dropped.  hard_cap bounds the number of steps (the reference has no bound). */
+int64_t ora_render_streams_wavefront(const ora_scene *scene, const ora_camera *cam,
+                                     int width, int height, int hard_cap, int n_spp, int capacity_factor,
+                                     float *r, float *g, float *b,
+                                     uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr,
+                                     int64_t *dropped, int *steps_last_sample);
 
 /* genSeeds / createWith (Util.hs:122-127) made deterministic: word triple k of pixel i
  * from ora_seed_words(seed0, i), then sfc32 3-word seeding. */

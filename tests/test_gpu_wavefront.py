@@ -1,0 +1,70 @@
+"""The stream ("wavefront") form of render Streams: ballot/prefix compaction of children, float atomics
+for permute (+).  Without GLASS it must equal the per-pixel chain kernel and the oracle BIT FOR BIT (one
+adder per colour word per launch).  With the build-defined GLASS extension (no reference semantics; spec in
+oracle/pt_oracle.c glass_children) several rays of a pixel add in one launch in undefined order -- as in
+Accelerate's permute -- so colours are compared within north_star's 1e-4 relative; seeds stay exact."""
+import numpy as np
+import pytest
+
+from conftest import assert_planes_equal, initial_planes
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-4
+CAP = 64           # kStreamHardCap
+
+
+def render(ctx, pkg, scene, cam, w, h, spp, start, variant=0):
+    ctx.set_variant(variant)
+    ctx.set_scene(*scene)
+    ctx.resize(w, h)
+    ctx.upload_state(*start)
+    ctx.reset_stats()
+    ctx.render(cam, 15, spp, pkg.STREAMS)
+    out, st = ctx.download_state(), ctx.stats()
+    ctx.set_variant(0)
+    return out, st
+
+
+@pytest.mark.parametrize("scene_name,w,h,spp", [("main", 96, 64, 2), ("s16", 120, 67, 3)])
+def test_wavefront_without_glass_is_bit_exact(ctx, pkg, ora, scene_name, w, h, spp):
+    scene = pkg.world.main_scene() if scene_name == "main" else pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    start = initial_planes(ora, w, h)
+    got, st = render(ctx, pkg, scene, cam, w, h, spp, start, variant=9)          # force the stream form
+    want, live, dropped, steps = ora.render_streams_wavefront(scene[0], scene[1], cam, w, h, CAP, spp, start)
+    assert_planes_equal(got, want, "wavefront vs oracle stream")
+    chain, _ = ora.render_streams(scene[0], scene[1], cam, w, h, 1 << 16, spp, start)
+    assert_planes_equal(got, chain, "wavefront vs per-pixel chain")
+    assert st["live_bounces"] == live and st["stream_iterations"] == steps and st["stream_rays_dropped"] == 0 == dropped
+
+
+def test_glass_scene_within_tolerance_and_seeds_exact(ctx, pkg, ora):
+    scene = pkg.world.glass_scene()
+    cam = pkg.world.initial_camera()
+    w, h, spp = 128, 72, 3
+    start = initial_planes(ora, w, h)
+    got, st = render(ctx, pkg, scene, cam, w, h, spp, start)
+    want, live, dropped, steps = ora.render_streams_wavefront(scene[0], scene[1], cam, w, h, CAP, spp, start)
+    for a, b in zip(got[3:], want[3:]):
+        assert np.array_equal(a, b)                       # updateSeed: integer, exact
+    assert st["live_bounces"] == live and st["stream_rays_dropped"] == dropped == 0
+    assert st["stream_iterations"] == steps
+    split = live - ora.render_streams_wavefront(pkg.world.scene16()[0], scene[1], cam, w, h, CAP, spp, start)[1]
+    assert split != 0                                      # the scene really splits rays
+    for a, b in zip(got[:3], want[:3]):
+        scale = np.maximum(np.abs(b), 1e-3)
+        assert np.max(np.abs(a - b) / scale) <= REL_TOL
+    # and the glass changed the picture
+    plain, _, _, _ = ora.render_streams_wavefront(pkg.world.scene16()[0], scene[1], cam, w, h, CAP, spp, start)
+    assert not np.array_equal(plain[0], want[0])
+
+
+def test_inline_refuses_glass(ctx, pkg):
+    """"features that require diverging rays like light refraction" need the stream algorithm (Trace.hs:56-67)."""
+    ctx.set_scene(*pkg.world.glass_scene())
+    ctx.resize(16, 16)
+    with pytest.raises(pkg.PtmiError) as e:
+        ctx.render(pkg.world.initial_camera(), 8, 1, pkg.INLINE)
+    assert e.value.code == -1
+    ctx.render(pkg.world.initial_camera(), 8, 1, pkg.STREAMS)
+    ctx.synchronize()
