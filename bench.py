@@ -80,7 +80,8 @@ def main():
     ap.add_argument("--width", type=int, default=WIDTH, help="experiments only: the headline number is the default C2 workload")
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--spp", type=int, default=SPP_PER_GPU)
-    ap.add_argument("--scene", choices=["s16", "main"], default="s16")
+    ap.add_argument("--scene", choices=["s16", "main", "glass"], default="s16")
+    ap.add_argument("--algorithm", choices=["inline", "streams"], default="inline")
     args = ap.parse_args()
     WIDTH, HEIGHT, SPP_PER_GPU = args.width, args.height, args.spp
 
@@ -112,7 +113,8 @@ def main():
     pkg._build.build_lib()
     from haskell_path_tracer_amd.parallel import ColorGatherer, StripePartition
 
-    spheres, planes = pkg.world.scene16() if args.scene == "s16" else pkg.world.main_scene()
+    spheres, planes = {"s16": pkg.world.scene16, "main": pkg.world.main_scene, "glass": pkg.world.glass_scene}[args.scene]()
+    algorithm = pkg.INLINE if args.algorithm == "inline" else pkg.STREAMS
     cam = pkg.world.initial_camera()
     spp = SPP_PER_GPU * world
 
@@ -139,7 +141,7 @@ def main():
     gather = ColorGatherer(part, WIDTH, color.dtype, color.device, dst=0) if world > 1 else None
 
     def step():
-        ctx.render(cam, BOUNCE_LIMIT, spp, pkg.INLINE)
+        ctx.render(cam, BOUNCE_LIMIT, spp, algorithm)
         if world > 1:
             return gather(color)
         return None
@@ -157,7 +159,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        ctx.render(cam, BOUNCE_LIMIT, spp, pkg.INLINE)
+        ctx.render(cam, BOUNCE_LIMIT, spp, algorithm)
         ev[k][1].record()
         if world > 1:
             gather(color)
@@ -176,7 +178,7 @@ def main():
     else:
         live_total = stats["live_bounces"]
 
-    is_c2 = (WIDTH, HEIGHT, SPP_PER_GPU, args.scene) == (1920, 1080, 64, "s16")
+    is_c2 = (WIDTH, HEIGHT, SPP_PER_GPU, args.scene, args.algorithm) == (1920, 1080, 64, "s16", "inline")
     if rank == 0:
         nominal_per_step = WIDTH * HEIGHT * spp * BOUNCE_LIMIT          # whole job, all ranks
         value = nominal_per_step * args.steps / elapsed / 1e6
@@ -191,9 +193,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %dx%d, %d spp per step per GPU, bounce limit 8, scene %s "
-                                   "(%d spheres + %d planes), render Inline, seeds from seed0=0x5EED1234"
-                                   % ("C2" if is_c2 else "experiment",
-                                      WIDTH, HEIGHT, SPP_PER_GPU, args.scene.upper(), len(spheres), len(planes)),
+                                   "(%d spheres + %d planes), render %s, seeds from seed0=0x5EED1234"
+                                   % ("C2" if is_c2 else "experiment", WIDTH, HEIGHT, SPP_PER_GPU, args.scene.upper(),
+                                      len(spheres), len(planes), args.algorithm.capitalize()),
                        "width": WIDTH, "height": HEIGHT, "spp_per_step": spp, "bounce_limit": BOUNCE_LIMIT,
                        "primitives": int(len(spheres) + len(planes)),
                        "parallelism": "row stripes of %d rows over %d GPU(s)%s"

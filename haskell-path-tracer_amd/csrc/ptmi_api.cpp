@@ -57,6 +57,7 @@ struct ptmi_ctx {
     size_t queue_capacity = 0;
     unsigned int *d_qcount = nullptr;
     uint64_t rays_dropped = 0;
+    uint64_t live_host = 0;        // live rays counted on the host (wavefront path)
 };
 
 namespace {
@@ -177,27 +178,40 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
     const size_t n = (size_t)a.rows_local * a.width;
     if (n == 0 || n_spp <= 0) return PTMI_OK;
     if (n * kStreamCapacityFactor > 0xffffffffull) return fail(c, PTMI_ELIMIT, "image too large for the wavefront Streams path");
-    const size_t capacity = n * kStreamCapacityFactor;
+    const size_t capacity = ((n * kStreamCapacityFactor + kStreamShards - 1) / kStreamShards) * kStreamShards;
+    const unsigned int shard_cap = (unsigned int)(capacity / kStreamShards);
     if (capacity != c->queue_capacity) {
         if (c->queue_block) { (void)hipFree(c->queue_block); c->queue_block = nullptr; c->queue_capacity = 0; }
         PTMI_HIP(c, hipMalloc(&c->queue_block, 2 * (size_t)kRayQueueWords * capacity * 4));
         c->queue_capacity = capacity;
     }
-    if (!c->d_qcount) PTMI_HIP(c, hipMalloc(&c->d_qcount, 2 * sizeof(unsigned int)));
+    constexpr size_t kCounterWords = (size_t)(kStreamShards + 1) * kCounterStride;     // shard k at word k * stride, dropped last
+    if (!c->d_qcount) PTMI_HIP(c, hipMalloc(&c->d_qcount, kCounterWords * sizeof(unsigned int)));
     RayQueue q[2] = {carve_queue(c->queue_block, capacity, 0), carve_queue(c->queue_block, capacity, 1)};
     unsigned int longest = 0;
     for (int s = 0; s < n_spp; ++s) {
-        PTMI_HIP(c, launch_streams_init(a, q[0], c->stream));
-        unsigned int n_cur = (unsigned int)n, steps = 0;
+        PTMI_HIP(c, launch_streams_init(a, q[0], c->stream));            // pixel i at linear slot i: fills shards 0, 1, ... in order
+        unsigned int counts[kStreamShards + 1], raw[(kStreamShards + 1) * kCounterStride];
+        for (int k = 0; k < kStreamShards; ++k) {
+            const size_t lo = (size_t)k * shard_cap;
+            counts[k] = n > lo ? (unsigned int)(n - lo < shard_cap ? n - lo : shard_cap) : 0u;
+        }
+        unsigned int steps = 0;
         int cur = 0;
-        while (n_cur > 0 && steps < (unsigned int)kStreamHardCap) {
-            unsigned int h[2] = {0, 0};
-            PTMI_HIP(c, hipMemsetAsync(c->d_qcount, 0, 2 * sizeof(unsigned int), c->stream));
-            PTMI_HIP(c, launch_streams_step(a, q[cur], n_cur, q[cur ^ 1], c->d_qcount, c->d_qcount + 1, c->stream));
-            PTMI_HIP(c, hipMemcpyAsync(h, c->d_qcount, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+        for (;;) {
+            StreamLayout layout;
+            layout.prefix[0] = 0;
+            for (int k = 0; k < kStreamShards; ++k) layout.prefix[k + 1] = layout.prefix[k] + counts[k];
+            if (layout.prefix[kStreamShards] == 0 || steps >= (unsigned int)kStreamHardCap) break;
+            PTMI_HIP(c, hipMemsetAsync(c->d_qcount, 0, kCounterWords * sizeof(unsigned int), c->stream));
+            PTMI_HIP(c, launch_streams_step(a, q[cur], layout, q[cur ^ 1], c->d_qcount, c->d_qcount + kStreamShards * kCounterStride, c->stream));
+            PTMI_HIP(c, hipMemcpyAsync(raw, c->d_qcount, kCounterWords * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
             PTMI_HIP(c, hipStreamSynchronize(c->stream));
-            c->rays_dropped += h[1];
-            n_cur = h[0] < (unsigned int)capacity ? h[0] : (unsigned int)capacity;
+            c->rays_dropped += raw[kStreamShards * kCounterStride];
+            for (int k = 0; k < kStreamShards; ++k) {
+                counts[k] = raw[k * kCounterStride] < shard_cap ? raw[k * kCounterStride] : shard_cap;
+                c->live_host += counts[k];                                   // children that entered the next stream
+            }
             cur ^= 1;
             ++steps;
         }
@@ -612,7 +626,7 @@ int ptmi_get_stats(ptmi_ctx *c, ptmi_stats *out)
     PTMI_HIP(c, hipMemcpyAsync(&live, c->d_live, sizeof live, hipMemcpyDeviceToHost, c->stream));
     PTMI_HIP(c, hipMemcpyAsync(&iters, c->d_iters, sizeof iters, hipMemcpyDeviceToHost, c->stream));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
-    out->live_bounces = live; out->nominal_bounces = c->nominal; out->samples = c->samples;
+    out->live_bounces = live + c->live_host; out->nominal_bounces = c->nominal; out->samples = c->samples;
     out->stream_iterations = iters;
     out->stream_rays_dropped = c->rays_dropped;
     out->last_render_ms = 0.0f;
@@ -640,7 +654,7 @@ int ptmi_reset_stats(ptmi_ctx *c)
     PTMI_HIP(c, hipMemsetAsync(c->d_live, 0, sizeof(unsigned long long), c->stream));
     PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, sizeof(unsigned int), c->stream));
     PTMI_HIP(c, hipMemsetAsync(c->d_work, 0, 64 * sizeof(unsigned int), c->stream));
-    c->nominal = 0; c->samples = 0; c->rays_dropped = 0;
+    c->nominal = 0; c->samples = 0; c->rays_dropped = 0; c->live_host = 0;
     return PTMI_OK;
 }
 

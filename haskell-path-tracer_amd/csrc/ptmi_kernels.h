@@ -43,13 +43,16 @@ struct RayQueue {
     float *f[9];            // origin xyz, direction xyz, throughput xyz
     uint32_t *pixel;        // local pixel index
     uint32_t *seed[4];      // SFC32 a, b, c, counter
-    unsigned int capacity;
+    unsigned int capacity;  // total; split into kStreamShards equal regions, each with its own length counter
 };
 constexpr int kRayQueueWords = 14;
+constexpr int kStreamShards = 8;            // one append counter per shard: a single counter word serves ~90 requests/us
+constexpr int kCounterStride = 32;          // the shard counters sit 128 B apart (one per cache line)
+struct StreamLayout { unsigned int prefix[kStreamShards + 1]; };   // ray i of the input lives in shard k: prefix[k] <= i < prefix[k+1]
 
 hipError_t launch_streams_init(const RenderArgs &a, RayQueue q, hipStream_t stream);
-hipError_t launch_streams_step(const RenderArgs &a, RayQueue in, unsigned int n_in, RayQueue out,
-                               unsigned int *out_count, unsigned int *dropped, hipStream_t stream);
+hipError_t launch_streams_step(const RenderArgs &a, RayQueue in, StreamLayout layout, RayQueue out,
+                               unsigned int *out_counts, unsigned int *dropped, hipStream_t stream);
 hipError_t launch_streams_update_seed(Planes p, long long n, hipStream_t stream);
 
 hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t stream);

@@ -728,11 +728,13 @@ __global__ void __launch_bounds__(kBlock) streams_init_kernel(const RenderArgs a
 }
 
 template <bool LDS_SCENE>
-__global__ void __launch_bounds__(kBlock) streams_step_kernel(const RenderArgs a, const RayQueue in, unsigned int n_in,
-                                                              const RayQueue out, unsigned int *out_count,
+__global__ void __launch_bounds__(kBlock) streams_step_kernel(const RenderArgs a, const RayQueue in, const StreamLayout layout,
+                                                              const RayQueue out, unsigned int *out_counts,
                                                               unsigned int *dropped)
 {
     extern __shared__ float4 lds_scene[];
+    __shared__ unsigned int wave_kids[2][kBlock / 64];       // children per wave, pass 0 / pass 1
+    __shared__ unsigned int block_base;
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
         const int total = a.scene.total_f4();
@@ -741,13 +743,17 @@ __global__ void __launch_bounds__(kBlock) streams_step_kernel(const RenderArgs a
     }
     const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
     const float4 *M = S + a.scene.geom_f4();
-    const unsigned int i = blockIdx.x * kBlock + threadIdx.x;
-    const int lane = threadIdx.x & 63;
+    const unsigned int gi = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned int shard_cap = in.capacity / kStreamShards;
 
     int n_kids = 0;
     V3 ko[2], kd[2], kt[2]; Sfc32 ks[2];
     uint32_t pixel = 0;
-    if (i < n_in) {
+    if (gi < layout.prefix[kStreamShards]) {
+        int k = 0;
+        while (gi >= layout.prefix[k + 1]) ++k;                            // at most kStreamShards - 1 steps
+        const unsigned int i = (unsigned int)k * shard_cap + (gi - layout.prefix[k]);
         V3 o = mk(in.f[0][i], in.f[1][i], in.f[2][i]);
         V3 d = mk(in.f[3][i], in.f[4][i], in.f[5][i]);
         V3 throughput = mk(in.f[6][i], in.f[7][i], in.f[8][i]);
@@ -775,26 +781,33 @@ __global__ void __launch_bounds__(kBlock) streams_step_kernel(const RenderArgs a
             if (contribution.z != 0.0f) atomicAdd(a.planes.b + pixel, contribution.z);
         }
     }
-    // expand (Trace.hs:284-289): compaction of the children into the next stream, child 0 then child 1
-    unsigned int emitted = 0;
+    // expand (Trace.hs:284-289): compaction of the children into the next stream.  Wave level: ballot + popcount
+    // prefix; workgroup level: the wave totals meet in LDS and ONE lane appends for the whole workgroup, to the
+    // counter of the shard this workgroup writes (blockIdx & 7: workgroups dealt to the same XCD share a shard).
+    const unsigned long long mask0 = __ballot(n_kids > 0), mask1 = __ballot(n_kids > 1);
+    if (lane == 0) { wave_kids[0][wave] = (unsigned int)__builtin_popcountll(mask0); wave_kids[1][wave] = (unsigned int)__builtin_popcountll(mask1); }
+    __syncthreads();
+    const int shard = blockIdx.x & (kStreamShards - 1);
+    if (threadIdx.x == 0) {
+        unsigned int total = 0;
+        for (int w = 0; w < kBlock / 64; ++w) total += wave_kids[0][w] + wave_kids[1][w];
+        block_base = total ? atomicAdd(out_counts + shard * kCounterStride, total) : 0u;
+    }
+    __syncthreads();
+    unsigned int base = block_base;
+    for (int w = 0; w < wave; ++w) base += wave_kids[0][w] + wave_kids[1][w];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned int out_cap = out.capacity / kStreamShards;
     for (int k = 0; k < 2; ++k) {
-        const bool has = n_kids > k;
-        const unsigned long long mask = __ballot(has);
-        if (!mask) continue;                                               // wave-uniform
-        const int leader = (int)__builtin_ctzll(mask);
-        unsigned int base = 0;
-        if (lane == leader) base = atomicAdd(out_count, (unsigned int)__builtin_popcountll(mask));
-        base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
-        if (has) {
-            const unsigned int slot = base + (unsigned int)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            if (slot < out.capacity) { queue_store(out, slot, ko[k], kd[k], kt[k], pixel, ks[k]); ++emitted; }
+        if (n_kids > k) {
+            const unsigned int slot = base + (k == 0 ? (unsigned int)__builtin_popcountll(mask0 & below)
+                                                     : wave_kids[0][wave] + (unsigned int)__builtin_popcountll(mask1 & below));
+            if (slot < out_cap) queue_store(out, (unsigned int)shard * out_cap + slot, ko[k], kd[k], kt[k], pixel, ks[k]);
             else atomicAdd(dropped, 1u);
         }
     }
-    if (a.live_counter) {
-        const unsigned long long total = wave_sum(emitted);
-        if (lane == 0 && total) atomicAdd(a.live_counter, total);
-    }
+    // No per-wave statistics atomic here: 130 000 waves per step on one counter word is what made this kernel
+    // 10x slower (a word serves ~90 atomics/us).  The host derives the live count from the stream lengths.
 }
 
 __global__ void __launch_bounds__(kBlock) streams_update_seed_kernel(Planes p, long long n)
@@ -1003,13 +1016,14 @@ hipError_t launch_streams_init(const RenderArgs &a, RayQueue q, hipStream_t stre
     return hipGetLastError();
 }
 
-hipError_t launch_streams_step(const RenderArgs &a, RayQueue in, unsigned int n_in, RayQueue out,
-                               unsigned int *out_count, unsigned int *dropped, hipStream_t stream)
+hipError_t launch_streams_step(const RenderArgs &a, RayQueue in, StreamLayout layout, RayQueue out,
+                               unsigned int *out_counts, unsigned int *dropped, hipStream_t stream)
 {
+    const unsigned int n_in = layout.prefix[kStreamShards];
     if (n_in == 0) return hipSuccess;
     const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
-    hipLaunchKernelGGL((streams_step_kernel<true>), dim3(blocks_for(n_in)), dim3(kBlock), lds, stream, a, in, n_in, out,
-                       out_count, dropped);
+    hipLaunchKernelGGL((streams_step_kernel<true>), dim3(blocks_for(n_in)), dim3(kBlock), lds, stream, a, in, layout, out,
+                       out_counts, dropped);
     return hipGetLastError();
 }
 
