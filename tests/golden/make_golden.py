@@ -24,6 +24,8 @@ CASES = {
     "main_64x48_l15_s2": ("main", 64, 48, 15, 2, "inline"),
     "s16_80x45_l8_s4": ("s16", 80, 45, 8, 4, "inline"),
     "main_64x48_streams_s2": ("main", 64, 48, 1 << 16, 2, "streams"),
+    # build-defined GLASS extension (no reference semantics at all): stream form, hard cap 64 steps
+    "glass_64x48_wavefront_s2": ("glass", 64, 48, 64, 2, "wavefront"),
 }
 SEED0 = 0x5EED1234
 
@@ -32,13 +34,16 @@ def main():
     pkg, ora = graft.load_package(), graft.load_oracle()
     cam = pkg.world.initial_camera()
     for name, (scene, w, h, limit, spp, alg) in CASES.items():
-        sp, pl = pkg.world.main_scene() if scene == "main" else pkg.world.scene16()
+        sp, pl = {"main": pkg.world.main_scene, "s16": pkg.world.scene16, "glass": pkg.world.glass_scene}[scene]()
         seeds = ora.gen_seeds(SEED0, 0, w * h)
         start = [np.zeros((h, w), np.float32)] * 3 + [s.reshape(h, w) for s in seeds]
         if alg == "inline":
             out, live = ora.render_inline(sp, pl, cam, w, h, limit, spp, start)
-        else:
+        elif alg == "streams":
             out, live = ora.render_streams(sp, pl, cam, w, h, limit, spp, start)
+        else:
+            out, live, dropped, _steps = ora.render_streams_wavefront(sp, pl, cam, w, h, limit, spp, start)
+            assert dropped == 0
         np.savez_compressed(os.path.join(HERE, name + ".npz"), scene=scene, width=w, height=h, limit=limit,
                             spp=spp, algorithm=alg, seed0=SEED0, live=live,
                             spheres=sp, planes=pl, camera=cam,

@@ -28,8 +28,10 @@ def test_oracle_reproduces_golden(ora, path):
     w, h, limit, spp = int(z["width"]), int(z["height"]), int(z["limit"]), int(z["spp"])
     if str(z["algorithm"]) == "inline":
         got, live = ora.render_inline(z["spheres"], z["planes"], z["camera"], w, h, limit, spp, start)
-    else:
+    elif str(z["algorithm"]) == "streams":
         got, live = ora.render_streams(z["spheres"], z["planes"], z["camera"], w, h, limit, spp, start)
+    else:
+        got, live, _dropped, _steps = ora.render_streams_wavefront(z["spheres"], z["planes"], z["camera"], w, h, limit, spp, start)
     assert_planes_equal(got, want, os.path.basename(path))
     assert live == int(z["live"])
 
@@ -46,5 +48,11 @@ def test_gpu_reproduces_golden(ctx, pkg, path):
     ctx.reset_stats()
     ctx.render(z["camera"], limit, spp, alg)
     got = ctx.download_state()
-    assert_planes_equal(got, want, os.path.basename(path))
+    if str(z["algorithm"]) == "wavefront":
+        # GLASS: several rays of a pixel add in one launch, in undefined order (as in Accelerate's permute)
+        assert_planes_equal(got[3:], want[3:] , os.path.basename(path))
+        for a, b in zip(got[:3], want[:3]):
+            assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) <= 1e-4
+    else:
+        assert_planes_equal(got, want, os.path.basename(path))
     assert ctx.stats()["live_bounces"] == int(z["live"])
