@@ -17,7 +17,8 @@ namespace ptmi {
 
 namespace {
 
-constexpr int kBlock = 256;
+constexpr int kBlock = 256;      // small kernels and the wavefront step (its workgroup-level append wants many waves per atomic)
+constexpr int kRenderBlock = 64; // render kernels: one wave per workgroup, so a finished wave's slot is refilled at once (+1 % on C2)
 #ifndef PTMI_FETCH_BATCH
 #define PTMI_FETCH_BATCH 1
 #endif
@@ -231,21 +232,21 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned int v)
 enum { kCached = 0, kRegenerate = 1, kLockstep = 2 };
 
 template <bool LDS_SCENE, int MODE>
-__global__ void __launch_bounds__(kBlock, MODE == kCached ? 6 : 4) render_inline_kernel(const RenderArgs a)
+__global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_inline_kernel(const RenderArgs a)
 {
-    __shared__ float pixel_const[MODE == kCached ? 9 : 1][kBlock];   // kCached: per-lane restart record (see below)
+    __shared__ float pixel_const[MODE == kCached ? 9 : 1][kRenderBlock];   // kCached: per-lane restart record (see below)
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
         const int total = a.scene.total_f4();
-        for (int i = threadIdx.x; i < total; i += kBlock) lds_scene[i] = a.scene.packed[i];
+        for (int i = threadIdx.x; i < total; i += kRenderBlock) lds_scene[i] = a.scene.packed[i];
         __syncthreads();
     }
     const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
     const float4 *M = S + a.scene.geom_f4();
 
     const long long n_local = (long long)a.rows_local * a.width;
-    const long long pixel = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long pixel = (long long)blockIdx.x * kRenderBlock + threadIdx.x;
     unsigned int live = 0;
     if (pixel < n_local) {
         const int local_row = (int)(pixel / a.width);
@@ -281,8 +282,8 @@ __global__ void __launch_bounds__(kBlock, MODE == kCached ? 6 : 4) render_inline
                 // words) are read once per sample: they live in a lane-private LDS column instead of VGPRs,
                 // which is what lets the kernel fit 80 VGPRs = 6 waves per SIMD.
                 float *mine = &pixel_const[0][threadIdx.x];
-                auto put = [&](int k, float v) { mine[k * kBlock] = v; };
-                auto get = [&](int k) { return mine[k * kBlock]; };
+                auto put = [&](int k, float v) { mine[k * kRenderBlock] = v; };
+                auto get = [&](int k) { return mine[k * kRenderBlock]; };
                 V3 pos, normal;                                       // pos: the hit to shade, then the next ray's origin
                 hit_record(S, ns, h0.idx, origin, primary, h0.t, pos, normal);
                 put(0, pos.x); put(1, pos.y); put(2, pos.z);
@@ -411,13 +412,13 @@ __global__ void __launch_bounds__(kBlock, MODE == kCached ? 6 : 4) render_inline
 // Requires bounce_limit >= 1 and n_spp >= 1 (the launcher routes the degenerate cases elsewhere).
 // ---------------------------------------------------------------------------------------
 template <bool LDS_SCENE>
-__global__ void __launch_bounds__(kBlock) render_inline_persistent_kernel(const RenderArgs a)
+__global__ void __launch_bounds__(kRenderBlock) render_inline_persistent_kernel(const RenderArgs a)
 {
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
         const int total = a.scene.total_f4();
-        for (int i = threadIdx.x; i < total; i += kBlock) lds_scene[i] = a.scene.packed[i];
+        for (int i = threadIdx.x; i < total; i += kRenderBlock) lds_scene[i] = a.scene.packed[i];
         __syncthreads();
     }
     const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
@@ -581,20 +582,20 @@ __global__ void __launch_bounds__(kBlock) render_inline_persistent_kernel(const 
 constexpr int kStreamsHardCap = 1 << 16;
 
 template <bool LDS_SCENE>
-__global__ void __launch_bounds__(kBlock) render_streams_kernel(const RenderArgs a)
+__global__ void __launch_bounds__(kRenderBlock) render_streams_kernel(const RenderArgs a)
 {
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
         const int total = a.scene.total_f4();
-        for (int i = threadIdx.x; i < total; i += kBlock) lds_scene[i] = a.scene.packed[i];
+        for (int i = threadIdx.x; i < total; i += kRenderBlock) lds_scene[i] = a.scene.packed[i];
         __syncthreads();
     }
     const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
     const float4 *M = S + a.scene.geom_f4();
 
     const long long n_local = (long long)a.rows_local * a.width;
-    const long long pixel = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long pixel = (long long)blockIdx.x * kRenderBlock + threadIdx.x;
     unsigned int live = 0, longest = 0;
     if (pixel < n_local) {
         const int local_row = (int)(pixel / a.width);
@@ -952,7 +953,7 @@ __global__ void __launch_bounds__(kBlock) eval_sincos_kernel(const float *x, int
     s[i] = sn; c[i] = cs;
 }
 
-inline unsigned int blocks_for(long long n) { return (unsigned int)((n + kBlock - 1) / kBlock); }
+inline unsigned int blocks_for(long long n, int block = kBlock) { return (unsigned int)((n + block - 1) / block); }
 
 }  // namespace
 
@@ -960,13 +961,12 @@ hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t st
 {
     const long long n_local = (long long)a.rows_local * a.width;
     if (n_local <= 0) return hipSuccess;
-    const dim3 grid(blocks_for(n_local)), block(kBlock);
+    const dim3 grid(blocks_for(n_local, kRenderBlock)), block(kRenderBlock);
     const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
     // variants: 0 auto | 1 persistent (LDS scene) | 2 lock step | 3 regenerate | 4 cached, static mapping (LDS scene)
     //           5 cached, static, scene through scalar loads | 6 persistent, scene through scalar loads
     if (a.bounce_limit <= 0 || a.n_spp <= 0) variant = 2;   // degenerate counts: the plain loop handles them
-    if (variant == 0)                                        // measured cross-over: hand-out pays from ~2.5e8 pixel-samples
-        variant = (unsigned long long)n_local * (unsigned long long)a.n_spp >= 250000000ull ? 1 : 4;
+    if (variant == 0) variant = 4;                           // static mapping wins at every size measured
     if (variant == 1 || variant == 6) {
         // persistent grid; more workgroups than fit would only start late and find the queue empty: cap at 8 per CU
         static int max_blocks = 0;
@@ -975,7 +975,7 @@ hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t st
             hipError_t e = hipGetDevice(&dev);
             if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             if (e != hipSuccess) return e;
-            max_blocks = (cus > 0 ? cus : 256) * 8;
+            max_blocks = (cus > 0 ? cus : 256) * 8 * (256 / kRenderBlock);
         }
         const unsigned int blocks = grid.x < (unsigned int)max_blocks ? grid.x : (unsigned int)max_blocks;
         hipError_t e = hipMemsetAsync(a.work_counter, 0, sizeof(unsigned int), stream);
@@ -999,7 +999,7 @@ hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t s
 {
     const long long n_local = (long long)a.rows_local * a.width;
     if (n_local <= 0) return hipSuccess;
-    const dim3 grid(blocks_for(n_local)), block(kBlock);
+    const dim3 grid(blocks_for(n_local, kRenderBlock)), block(kRenderBlock);
     const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
     hipError_t e = hipMemsetAsync(a.stream_iterations, 0, sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
