@@ -43,11 +43,17 @@ def build_lib(force=False, verbose=False, extra_flags=(), out=None):
         return out
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc_path()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    os.replace(LIB + ".tmp", LIB)
+    # one builder at a time: the ranks of a multi-GPU launch all come through here
+    import fcntl
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or is_stale():
+            tmp = "%s.tmp.%d" % (LIB, os.getpid())
+            cmd = [hipcc_path()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+            os.replace(tmp, LIB)
     return LIB

@@ -582,8 +582,9 @@ __global__ void __launch_bounds__(kRenderBlock) render_inline_persistent_kernel(
 constexpr int kStreamsHardCap = 1 << 16;
 
 template <bool LDS_SCENE>
-__global__ void __launch_bounds__(kRenderBlock) render_streams_kernel(const RenderArgs a)
+__global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const RenderArgs a)
 {
+    __shared__ float pixel_const[9][kRenderBlock];          // per-lane restart record, as in render_inline_kernel
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -613,12 +614,18 @@ __global__ void __launch_bounds__(kRenderBlock) render_streams_kernel(const Rend
         if (!h0.just) {
             for (int s = 0; s < n_spp; ++s) (void)random_float(pixel_seed);     // updateSeed only
         } else {
-            V3 p0, n0;
-            hit_record(S, ns, h0.idx, origin, primary, h0.t, p0, n0);
+            float *mine = &pixel_const[0][threadIdx.x];
+            auto put = [&](int k, float v) { mine[k * kRenderBlock] = v; };
+            auto get = [&](int k) { return mine[k * kRenderBlock]; };
+            V3 pos, normal;                                       // pos: the hit to shade, then the next ray's origin
+            hit_record(S, ns, h0.idx, origin, primary, h0.t, pos, normal);
+            put(0, pos.x); put(1, pos.y); put(2, pos.z);
+            put(3, normal.x); put(4, normal.y); put(5, normal.z);
+            put(6, primary.x); put(7, primary.y); put(8, primary.z);
             const int idx0 = h0.idx;
             int s = 0, idx = idx0;
             unsigned int steps = 0;
-            V3 hit_pos = p0, normal = n0, o = origin, d = primary;
+            V3 d = primary;
             V3 throughput = mk(1.0f, 1.0f, 1.0f);
             Sfc32 seed = pixel_seed;
             bool pending = n_spp > 0, has_ray = false;
@@ -627,7 +634,8 @@ __global__ void __launch_bounds__(kRenderBlock) render_streams_kernel(const Rend
                 seed = pixel_seed;
                 ++s; longest = steps > longest ? steps : longest; steps = 0;
                 throughput = mk(1.0f, 1.0f, 1.0f);
-                hit_pos = p0; normal = n0; idx = idx0; d = primary;
+                pos = mk(get(0), get(1), get(2)); normal = mk(get(3), get(4), get(5));
+                d = mk(get(6), get(7), get(8)); idx = idx0;
                 pending = s < n_spp;
             };
             while (pending) {
@@ -635,17 +643,17 @@ __global__ void __launch_bounds__(kRenderBlock) render_streams_kernel(const Rend
                     if (pending && !has_ray) {
                         const bool dying = near_zero(throughput) || steps + 1u >= (unsigned int)kStreamsHardCap;
                         // results: colour += emittance * throughput for EVERY hit; then the new ray (if any)
-                        shade(M, idx, hit_pos, normal, o, d, throughput, acc, seed);
+                        shade(M, idx, pos, normal, pos, d, throughput, acc, seed);
                         ++steps;
                         if (dying) { end_sample(); }
                         else { ++live; pending = false; has_ray = true; }
                     }
                 }
                 if (has_ray) {
-                    const HitSel h = check_hit(S, ns, np, o, d);
+                    const HitSel h = check_hit(S, ns, np, pos, d);
                     has_ray = false;
                     if (h.just) {
-                        hit_record(S, ns, h.idx, o, d, h.t, hit_pos, normal);
+                        hit_record(S, ns, h.idx, pos, d, h.t, pos, normal);
                         idx = h.idx;
                         pending = true;
                     } else {
