@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (DESIGN.md); 0 = default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--stripe-rows", type=int, default=8)
+    ap.add_argument("--stripe-rows", type=int, default=0, help="0 = largest stripe <= 8 rows that deals every rank the same number of rows")
     ap.add_argument("--width", type=int, default=WIDTH, help="experiments only: the headline number is the default C2 workload")
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--spp", type=int, default=SPP_PER_GPU)
@@ -118,6 +118,8 @@ def main():
     cam = pkg.world.initial_camera()
     spp = SPP_PER_GPU * world
 
+    if args.stripe_rows <= 0:
+        args.stripe_rows = next((s for s in range(8, 0, -1) if HEIGHT % (s * world) == 0), 8)
     ctx = pkg.Context(local_rank)
     ctx.set_scene(spheres, planes)
     part = StripePartition(HEIGHT, world, rank, args.stripe_rows)
