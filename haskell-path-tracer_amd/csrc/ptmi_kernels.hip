@@ -234,7 +234,7 @@ enum { kCached = 0, kRegenerate = 1, kLockstep = 2 };
 template <bool LDS_SCENE, int MODE>
 __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_inline_kernel(const RenderArgs a)
 {
-    __shared__ float pixel_const[MODE == kCached ? 9 : 1][kRenderBlock];   // kCached: per-lane restart record (see below)
+    __shared__ float pixel_const[MODE == kCached ? 12 : 1][kRenderBlock];   // kCached: per-lane restart record (see below)
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -289,13 +289,15 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_
                 put(0, pos.x); put(1, pos.y); put(2, pos.z);
                 put(3, normal.x); put(4, normal.y); put(5, normal.z);
                 put(6, primary.x); put(7, primary.y); put(8, primary.z);
+                put(9, acc.x); put(10, acc.y); put(11, acc.z);        // the accumulator is touched once per sample: LDS too
                 const int idx0 = h0.idx;
                 int s = 0, it = 0, idx = idx0;
                 V3 d = primary;                                       // the ray that produced the hit / the next ray
                 V3 throughput = mk(1.0f, 1.0f, 1.0f), result = mk(0.0f, 0.0f, 0.0f);
                 bool pending = n_spp > 0, has_ray = false;
                 auto restart = [&]() {                                // next sample of this pixel
-                    acc = result + acc;                               // \(new, seed') (old, _) -> (new + old, seed')
+                    // \(new, seed') (old, _) -> (new + old, seed')
+                    put(9, result.x + get(9)); put(10, result.y + get(10)); put(11, result.z + get(11));
                     ++s; it = 0;
                     throughput = mk(1.0f, 1.0f, 1.0f); result = mk(0.0f, 0.0f, 0.0f);
                     pos = mk(get(0), get(1), get(2)); normal = mk(get(3), get(4), get(5));
@@ -336,6 +338,7 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_
                         }
                     }
                 }
+                acc = mk(get(9), get(10), get(11));
 #ifdef PTMI_PHASE_STATS
                 // diagnostic build only: [1] lane-iterations, [2..4] lane participations in rounds A, B, C,
                 // [5] max lane-iterations of the wave x lanes that had work (what the wave paid for)
