@@ -145,7 +145,7 @@ def main():
     def step():
         ctx.render(cam, BOUNCE_LIMIT, spp, algorithm)
         if world > 1:
-            return gather(color)
+            return gather.overlapped(color)          # the gather of step k runs beside the render of step k + 1
         return None
 
     def fence():
@@ -155,6 +155,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if world > 1:
+        gather.wait()
     fence()
     ctx.reset_stats()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -164,7 +166,9 @@ def main():
         ctx.render(cam, BOUNCE_LIMIT, spp, algorithm)
         ev[k][1].record()
         if world > 1:
-            gather(color)
+            gather.overlapped(color)
+    if world > 1:
+        gather.wait()
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)

@@ -70,6 +70,31 @@ class ColorGatherer:
             if self.world > 1:
                 self.bufs = [torch.empty((3, self.max_rows, width), dtype=dtype, device=dev) for _ in range(self.world)]
 
+    def overlapped(self, color_local):
+        """Pipelined form for a render loop on a GPU: snapshot the colour planes on the current (render) stream,
+        then gather the snapshot on a private stream, so the transfer over xGMI runs beside the next render
+        launch.  Call wait() before reading the result or at the end of the loop."""
+        import torch
+
+        if self.world == 1 or self.via_cpu or not color_local.is_cuda:
+            return self(color_local)
+        if not hasattr(self, "_comm"):
+            self._comm = torch.cuda.Stream()
+            self._snap = torch.empty_like(color_local)
+            self._ready = torch.cuda.Event()
+        torch.cuda.current_stream().wait_stream(self._comm)     # the previous gather has finished reading the snapshot
+        self._snap.copy_(color_local)
+        self._ready.record()
+        with torch.cuda.stream(self._comm):
+            self._comm.wait_event(self._ready)
+            out = self(self._snap)
+        return out
+
+    def wait(self):
+        import torch
+        if hasattr(self, "_comm"):
+            torch.cuda.current_stream().wait_stream(self._comm)
+
     def __call__(self, color_local):
         import torch.distributed as dist
 
