@@ -49,7 +49,7 @@ class ColorGatherer:
     tensors are padded to the largest.  With backend "gloo" and CUDA tensors the data takes a CPU detour
     (rehearsal of the N > 1 path on a one-GPU box); RCCL takes the device tensors directly."""
 
-    def __init__(self, partition, width, dtype, device, dst=0, group=None):
+    def __init__(self, partition, width, dtype, device, dst=0, group=None, force_collective=False):
         import torch
         import torch.distributed as dist
 
@@ -67,7 +67,7 @@ class ColorGatherer:
         if self.rank == dst:
             self.full = torch.empty((3, partition.height, width), dtype=dtype, device=dev)
             self.rows = [torch.as_tensor(partition.global_rows(p), device=dev) for p in range(self.world)]
-            if self.world > 1:
+            if self.world > 1 or force_collective:      # force_collective: run the collective even with one rank (tests)
                 self.bufs = [torch.empty((3, self.max_rows, width), dtype=dtype, device=dev) for _ in range(self.world)]
 
     def overlapped(self, color_local):
@@ -76,7 +76,7 @@ class ColorGatherer:
         launch.  Call wait() before reading the result or at the end of the loop."""
         import torch
 
-        if self.world == 1 or self.via_cpu or not color_local.is_cuda:
+        if self.bufs is None and self.rank == self.dst and self.world == 1 or self.via_cpu or not color_local.is_cuda:
             return self(color_local)
         if not hasattr(self, "_comm"):
             self._comm = torch.cuda.Stream()
@@ -98,7 +98,7 @@ class ColorGatherer:
     def __call__(self, color_local):
         import torch.distributed as dist
 
-        if self.world == 1:
+        if self.world == 1 and self.bufs is None:
             self.full[:, self.rows[0], :] = color_local
             return self.full
         if self.via_cpu:
