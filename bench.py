@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path (BASELINE.json: Msamples/s, paths x bounces).
 
-A step = one pass of `render Inline` over the C2 workload: the 1920x1080 image of the
-16-primitive scene, bounce limit 8, 64 samples per pixel PER GPU (so with N GPUs a step adds
-64*N spp to the image, which is row-stripe partitioned over the N ranks: per-GPU work is fixed,
-scaling is weak), followed by the RCCL gather of the colour planes to rank 0 when N > 1.
+A step = one pass of `render Inline` over the C2 workload: 1920x1080 pixels PER GPU of the
+16-primitive scene, bounce limit 8, 64 samples per pixel.  With N GPUs the image is 1920 x (1080*N),
+row-stripe partitioned over the N ranks, so every rank launches exactly the N = 1 kernel shape
+(per-GPU work fixed: weak scaling; `--weak spp` scales the sample count instead), followed by the
+RCCL gather of the colour planes to rank 0, which overlaps the next step's render.
 Inputs (state planes, scene) are resident in HBM before the timed region starts.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
@@ -82,6 +83,7 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP_PER_GPU)
     ap.add_argument("--scene", choices=["s16", "main", "glass"], default="s16")
     ap.add_argument("--algorithm", choices=["inline", "streams"], default="inline")
+    ap.add_argument("--weak", choices=["rows", "spp"], default="rows", help="what grows with the GPU count")
     args = ap.parse_args()
     WIDTH, HEIGHT, SPP_PER_GPU = args.width, args.height, args.spp
 
@@ -116,7 +118,9 @@ def main():
     spheres, planes = {"s16": pkg.world.scene16, "main": pkg.world.main_scene, "glass": pkg.world.glass_scene}[args.scene]()
     algorithm = pkg.INLINE if args.algorithm == "inline" else pkg.STREAMS
     cam = pkg.world.initial_camera()
-    spp = SPP_PER_GPU * world
+    spp = SPP_PER_GPU * (world if args.weak == "spp" else 1)
+    if args.weak == "rows":
+        HEIGHT = HEIGHT * world                      # 1080 rows per GPU
 
     if args.stripe_rows <= 0:
         args.stripe_rows = next((s for s in range(8, 0, -1) if HEIGHT % (s * world) == 0), 8)
@@ -184,7 +188,7 @@ def main():
     else:
         live_total = stats["live_bounces"]
 
-    is_c2 = (WIDTH, HEIGHT, SPP_PER_GPU, args.scene, args.algorithm) == (1920, 1080, 64, "s16", "inline")
+    is_c2 = (WIDTH, HEIGHT // (world if args.weak == "rows" else 1), SPP_PER_GPU, args.scene, args.algorithm) == (1920, 1080, 64, "s16", "inline")
     if rank == 0:
         nominal_per_step = WIDTH * HEIGHT * spp * BOUNCE_LIMIT          # whole job, all ranks
         value = nominal_per_step * args.steps / elapsed / 1e6
@@ -198,9 +202,10 @@ def main():
             "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %dx%d, %d spp per step per GPU, bounce limit 8, scene %s "
+            "config": {"workload": "%s: %dx%d image, %d spp per step, bounce limit 8, scene %s "
                                    "(%d spheres + %d planes), render %s, seeds from seed0=0x5EED1234"
-                                   % ("C2" if is_c2 else "experiment", WIDTH, HEIGHT, SPP_PER_GPU, args.scene.upper(),
+                                   % (("C2" if world == 1 else "C2 per GPU (1920x1080 pixels each, weak scaling by %s)" % args.weak) if is_c2 else "experiment",
+                                      WIDTH, HEIGHT, spp, args.scene.upper(),
                                       len(spheres), len(planes), args.algorithm.capitalize()),
                        "width": WIDTH, "height": HEIGHT, "spp_per_step": spp, "bounce_limit": BOUNCE_LIMIT,
                        "primitives": int(len(spheres) + len(planes)),
