@@ -52,7 +52,13 @@ def cpu_baseline(pkg, spheres, planes, cam, budget_s=15.0):
     _, live = ora.render_inline(spheres, planes, cam, WIDTH, HEIGHT, BOUNCE_LIMIT, spp, start, n_threads=threads)
     dt = time.perf_counter() - t0
     nominal = WIDTH * HEIGHT * spp * BOUNCE_LIMIT
+    # per-core figure: a quarter of the rows, one sample, one thread (a few seconds)
+    q = max(1, HEIGHT // 4)
+    t0 = time.perf_counter()
+    ora.render_inline(spheres, planes, cam, WIDTH, q, BOUNCE_LIMIT, 1, [a[:q] for a in start], n_threads=1)
+    one = WIDTH * q * BOUNCE_LIMIT / (time.perf_counter() - t0) / 1e6
     return {"value": round(nominal / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "single_thread_value": round(one, 3),
             "sample": "%dx%d, scene S16, limit %d, %d spp (the GPU step is %d), %.1f s, C oracle (oracle/pt_oracle.c) with OpenMP"
                       % (WIDTH, HEIGHT, BOUNCE_LIMIT, spp, SPP_PER_GPU, dt),
             "live_fraction": round(live / nominal, 4)}
