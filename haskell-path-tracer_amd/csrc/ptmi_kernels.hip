@@ -18,6 +18,7 @@ namespace ptmi {
 namespace {
 
 constexpr int kBlock = 256;      // small kernels and the wavefront step (its workgroup-level append wants many waves per atomic)
+constexpr size_t kMaxSceneLds = 3 * 1024;  // bytes of staged scene per one-wave workgroup before LDS would cap occupancy (~60 primitives)
 constexpr int kRenderBlock = 64; // render kernels: one wave per workgroup, so a finished wave's slot is refilled at once (+1 % on C2)
 #ifndef PTMI_FETCH_BATCH
 #define PTMI_FETCH_BATCH 1
@@ -977,7 +978,8 @@ hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t st
     // variants: 0 auto | 1 persistent (LDS scene) | 2 lock step | 3 regenerate | 4 cached, static mapping (LDS scene)
     //           5 cached, static, scene through scalar loads | 6 persistent, scene through scalar loads
     if (a.bounce_limit <= 0 || a.n_spp <= 0) variant = 2;   // degenerate counts: the plain loop handles them
-    if (variant == 0) variant = 4;                           // static mapping wins at every size measured
+    if (variant == 0) variant = lds <= kMaxSceneLds ? 4 : 5;  // static mapping wins at every size measured;
+                                                             // a scene too big to keep 6 waves/SIMD in LDS is read through scalar loads
     if (variant == 1 || variant == 6) {
         // persistent grid; more workgroups than fit would only start late and find the queue empty: cap at 8 per CU
         static int max_blocks = 0;
@@ -1014,7 +1016,7 @@ hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t s
     const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
     hipError_t e = hipMemsetAsync(a.stream_iterations, 0, sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
-    if (variant == 5 || variant == 6) hipLaunchKernelGGL((render_streams_kernel<false>), grid, block, 0, stream, a);
+    if (variant == 5 || variant == 6 || lds > kMaxSceneLds) hipLaunchKernelGGL((render_streams_kernel<false>), grid, block, 0, stream, a);
     else                              hipLaunchKernelGGL((render_streams_kernel<true>), grid, block, lds, stream, a);
     return hipGetLastError();
 }

@@ -238,3 +238,45 @@ def test_present_matches_graphics_loop_arithmetic(ctx, pkg, ora, w, h):
     assert np.array_equal(rgba[..., :3], want8) and np.all(rgba[..., 3] == 255)
     with pytest.raises(pkg.PtmiError):
         ctx.present(0)
+
+
+@pytest.mark.parametrize("n_spheres,n_planes", [(200, 3), (1000, 24)])
+def test_large_scenes_up_to_the_primitive_limit(ctx, pkg, ora, n_spheres, n_planes):
+    """PTMI_MAX_PRIMITIVES = 1024.  Big scenes are read through scalar loads instead of LDS (occupancy);
+    every variant must still agree with the oracle.  One more primitive is refused with PTMI_ELIMIT."""
+    r = np.random.default_rng(n_spheres)
+    w = pkg.world
+    spheres = np.zeros(n_spheres, w.SPHERE_DTYPE)
+    spheres["position"] = r.uniform(-30, 30, (n_spheres, 3))
+    spheres["radius"] = r.uniform(0.2, 1.5, n_spheres)
+    spheres["color"] = r.uniform(0.1, 1, (n_spheres, 3))
+    spheres["illuminance"] = np.where(r.random(n_spheres) < 0.1, 50.0, 0.0)
+    spheres["brdf_tag"] = r.integers(0, 2, n_spheres)
+    spheres["brdf_param"] = r.uniform(0.2, 1.0, n_spheres)
+    planes = np.zeros(n_planes, w.PLANE_DTYPE)
+    planes["position"] = r.uniform(-40, 40, (n_planes, 3))
+    nrm = r.normal(0, 1, (n_planes, 3))
+    planes["direction"] = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+    planes["color"] = r.uniform(0.2, 1, (n_planes, 3))
+    planes["brdf_tag"] = r.integers(0, 2, n_planes)
+    planes["brdf_param"] = 0.8
+    cam = w.initial_camera()
+    wd, ht = 64, 40
+    start = initial_planes(ora, wd, ht)
+    want, _ = ora.render_inline(spheres, planes, cam, wd, ht, 6, 2, start)
+    for variant in (0, 4, 1):
+        ctx.set_variant(variant)
+        ctx.set_scene(spheres, planes)
+        ctx.resize(wd, ht)
+        ctx.upload_state(*start)
+        ctx.render(cam, 6, 2)
+        assert_planes_equal(ctx.download_state(), want, "%d+%d primitives, variant %d" % (n_spheres, n_planes, variant))
+    ctx.set_variant(0)
+    ctx.upload_state(*start)
+    ctx.render(cam, 6, 1, pkg.STREAMS)
+    want_s, _ = ora.render_streams(spheres, planes, cam, wd, ht, 1 << 16, 1, start)
+    assert_planes_equal(ctx.download_state(), want_s, "streams, %d primitives" % (n_spheres + n_planes))
+    if n_spheres + n_planes == 1024:
+        with pytest.raises(pkg.PtmiError) as e:
+            ctx.set_scene(np.concatenate([spheres, spheres[:1]]), planes)
+        assert e.value.code == -6
