@@ -109,6 +109,33 @@ static inline double ora_reduce_large(uint32_t xi, int *np)
     return x * 0x1.921FB54442D18p-62;
 }
 
+#ifdef ORA_SINCOS_ALT
+/* SENSITIVITY STUDY ONLY (tools/sensitivity.py): a different, equally legitimate single-precision sin/cos
+ * (Cephes-style reduction and polynomials, ~1 ulp) standing in for "some other libm".  Never part of the
+ * oracle proper. */
+static void alt_sincosf(float x, float *sn, float *cs)
+{
+    float ax = fabsf(x);
+    int j = (int)(ax * 1.27323954473516f);            /* 4/pi */
+    j = (j + 1) & ~1;
+    float y = (float)j;
+    float z = ((ax - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    float zz = z * z;
+    float s = ((-1.9515295891e-4f * zz + 8.3321608736e-3f) * zz - 1.6666654611e-1f) * zz * z + z;
+    float c = ((2.443315711809948e-5f * zz - 1.388731625493765e-3f) * zz + 4.166664568298827e-2f) * zz * zz - 0.5f * zz + 1.0f;
+    int q = (j >> 1) & 3;
+    float rs = (q & 1) ? c : s, rc = (q & 1) ? s : c;
+    if (q & 2) rs = -rs;
+    if (((q + 1) >> 1) & 1) rc = -rc;
+    if (x < 0) rs = -rs;
+    *sn = rs; *cs = rc;
+}
+float ora_sinf(float y) { float s, c; alt_sincosf(y, &s, &c); return s; }
+float ora_cosf(float y) { float s, c; alt_sincosf(y, &s, &c); return c; }
+#define ora_sinf ora_sinf_glibc_unused
+#define ora_cosf ora_cosf_glibc_unused
+#endif
+
 float ora_sinf(float y)
 {
     double x = y, s;
@@ -162,6 +189,11 @@ float ora_cosf(float y)
     }
     return (y - y) / (y - y);
 }
+
+#ifdef ORA_SINCOS_ALT
+#undef ora_sinf
+#undef ora_cosf
+#endif
 
 /* ========================================================================== */
 /* linear / linear-accelerate vector algebra (L0, restated)                    */
