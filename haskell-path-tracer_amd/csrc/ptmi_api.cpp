@@ -158,7 +158,6 @@ void pack_scene(const ptmi_sphere *sph, int ns, const ptmi_plane *pl, int np, st
 }
 
 constexpr int kStreamCapacityFactor = 4;     // next stream holds at most 4 rays per pixel; excess children are dropped and counted
-constexpr int kStreamHardCap = 64;           // steps per sample; the reference has no bound (Trace.hs:166-170)
 
 RayQueue carve_queue(void *block, size_t capacity, int which)
 {
@@ -167,6 +166,7 @@ RayQueue carve_queue(void *block, size_t capacity, int which)
     for (int k = 0; k < 9; ++k) q.f[k] = reinterpret_cast<float *>(b + (size_t)k * capacity * 4);
     q.pixel = reinterpret_cast<uint32_t *>(b + (size_t)9 * capacity * 4);
     for (int k = 0; k < 4; ++k) q.seed[k] = reinterpret_cast<uint32_t *>(b + (size_t)(10 + k) * capacity * 4);
+    q.depth = reinterpret_cast<uint32_t *>(b + (size_t)14 * capacity * 4);
     q.capacity = (unsigned int)capacity;
     return q;
 }
@@ -185,37 +185,39 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
         PTMI_HIP(c, hipMalloc(&c->queue_block, 2 * (size_t)kRayQueueWords * capacity * 4));
         c->queue_capacity = capacity;
     }
-    constexpr size_t kCounterWords = (size_t)(kStreamShards + 1) * kCounterStride;     // shard k at word k * stride, dropped last
+    constexpr size_t kCounterWords = (size_t)kStreamCounters * kCounterStride;
     if (!c->d_qcount) PTMI_HIP(c, hipMalloc(&c->d_qcount, kCounterWords * sizeof(unsigned int)));
     RayQueue q[2] = {carve_queue(c->queue_block, capacity, 0), carve_queue(c->queue_block, capacity, 1)};
     unsigned int longest = 0;
     for (int s = 0; s < n_spp; ++s) {
         PTMI_HIP(c, launch_streams_init(a, q[0], c->stream));            // pixel i at linear slot i: fills shards 0, 1, ... in order
-        unsigned int counts[kStreamShards + 1], raw[(kStreamShards + 1) * kCounterStride];
+        unsigned int counts[kStreamShards], raw[kStreamCounters * kCounterStride];
         for (int k = 0; k < kStreamShards; ++k) {
             const size_t lo = (size_t)k * shard_cap;
             counts[k] = n > lo ? (unsigned int)(n - lo < shard_cap ? n - lo : shard_cap) : 0u;
         }
-        unsigned int steps = 0;
+        unsigned int launches = 0, deepest = 0;
         int cur = 0;
         for (;;) {
             StreamLayout layout;
             layout.prefix[0] = 0;
             for (int k = 0; k < kStreamShards; ++k) layout.prefix[k + 1] = layout.prefix[k] + counts[k];
-            if (layout.prefix[kStreamShards] == 0 || steps >= (unsigned int)kStreamHardCap) break;
+            if (layout.prefix[kStreamShards] == 0 || launches >= (unsigned int)kStreamStepCap) break;
             PTMI_HIP(c, hipMemsetAsync(c->d_qcount, 0, kCounterWords * sizeof(unsigned int), c->stream));
-            PTMI_HIP(c, launch_streams_step(a, q[cur], layout, q[cur ^ 1], c->d_qcount, c->d_qcount + kStreamShards * kCounterStride, c->stream));
+            PTMI_HIP(c, launch_streams_step(a, q[cur], layout, q[cur ^ 1], c->d_qcount, c->stream));
             PTMI_HIP(c, hipMemcpyAsync(raw, c->d_qcount, kCounterWords * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
             PTMI_HIP(c, hipStreamSynchronize(c->stream));
-            c->rays_dropped += raw[kStreamShards * kCounterStride];
+            c->rays_dropped += raw[kCtrDropped * kCounterStride];
             for (int k = 0; k < kStreamShards; ++k) {
                 counts[k] = raw[k * kCounterStride] < shard_cap ? raw[k * kCounterStride] : shard_cap;
-                c->live_host += counts[k];                                   // children that entered the next stream
+                c->live_host += raw[(kCtrLive + k) * kCounterStride];         // rays that took another traceStep
+                const unsigned int deep = raw[(kCtrDeepest + k) * kCounterStride];
+                deepest = deep > deepest ? deep : deepest;
             }
             cur ^= 1;
-            ++steps;
+            ++launches;
         }
-        longest = steps > longest ? steps : longest;
+        longest = deepest > longest ? deepest : longest;
         PTMI_HIP(c, launch_streams_update_seed(a.planes, (long long)n, c->stream));
     }
     PTMI_HIP(c, hipMemcpyAsync(c->d_iters, &longest, sizeof longest, hipMemcpyHostToDevice, c->stream));

@@ -43,16 +43,22 @@ struct RayQueue {
     float *f[9];            // origin xyz, direction xyz, throughput xyz
     uint32_t *pixel;        // local pixel index
     uint32_t *seed[4];      // SFC32 a, b, c, counter
+    uint32_t *depth;        // traceSteps already taken by the ray's ancestors (= the awhile iteration it belongs to)
     unsigned int capacity;  // total; split into kStreamShards equal regions, each with its own length counter
 };
-constexpr int kRayQueueWords = 14;
+constexpr int kRayQueueWords = 15;
 constexpr int kStreamShards = 8;            // one append counter per shard: a single counter word serves ~90 requests/us
 constexpr int kCounterStride = 32;          // the shard counters sit 128 B apart (one per cache line)
+constexpr int kStreamStepCap = 64;          // traceSteps per ray lineage; the reference has no bound (Trace.hs:166-170)
+// device counters of one step launch, each kCounterStride words apart:
+//   [0, 8) next-stream length per shard | 8 dropped children | [9, 17) rays continued or emitted per shard | [17, 25) deepest step + 1
+constexpr int kStreamCounters = 3 * kStreamShards + 1;
+constexpr int kCtrDropped = kStreamShards, kCtrLive = kStreamShards + 1, kCtrDeepest = 2 * kStreamShards + 1;
 struct StreamLayout { unsigned int prefix[kStreamShards + 1]; };   // ray i of the input lives in shard k: prefix[k] <= i < prefix[k+1]
 
 hipError_t launch_streams_init(const RenderArgs &a, RayQueue q, hipStream_t stream);
 hipError_t launch_streams_step(const RenderArgs &a, RayQueue in, StreamLayout layout, RayQueue out,
-                               unsigned int *out_counts, unsigned int *dropped, hipStream_t stream);
+                               unsigned int *counters, hipStream_t stream);
 hipError_t launch_streams_update_seed(Planes p, long long n, hipStream_t stream);
 
 hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t stream);

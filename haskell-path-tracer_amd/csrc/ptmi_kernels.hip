@@ -693,8 +693,9 @@ __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const R
 // add in the same launch and the order of those additions is not defined (neither is it in Accelerate's
 // permute), so GLASS scenes are compared with a tolerance.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void queue_store(const RayQueue &q, unsigned int i, V3 o, V3 d, V3 t, uint32_t pixel, Sfc32 s)
+__device__ __forceinline__ void queue_store(const RayQueue &q, unsigned int i, V3 o, V3 d, V3 t, uint32_t pixel, Sfc32 s, uint32_t depth)
 {
+    q.depth[i] = depth;
     q.f[0][i] = o.x; q.f[1][i] = o.y; q.f[2][i] = o.z;
     q.f[3][i] = d.x; q.f[4][i] = d.y; q.f[5][i] = d.z;
     q.f[6][i] = t.x; q.f[7][i] = t.y; q.f[8][i] = t.z;
@@ -737,16 +738,16 @@ __global__ void __launch_bounds__(kBlock) streams_init_kernel(const RenderArgs a
     const V3 primary = primary_direction(a.cam, col, global_row(local_row, a.stripe_rows, a.n_parts, a.part));
     Sfc32 s;
     s.a = a.planes.sa[pixel]; s.b = a.planes.sb[pixel]; s.c = a.planes.sc[pixel]; s.counter = a.planes.sctr[pixel];
-    queue_store(q, (unsigned int)pixel, a.cam.pos, primary, mk(1.0f, 1.0f, 1.0f), (uint32_t)pixel, s);   // initialState (Trace.hs:158-162)
+    queue_store(q, (unsigned int)pixel, a.cam.pos, primary, mk(1.0f, 1.0f, 1.0f), (uint32_t)pixel, s, 0u);   // initialState (Trace.hs:158-162)
 }
 
 template <bool LDS_SCENE>
 __global__ void __launch_bounds__(kBlock) streams_step_kernel(const RenderArgs a, const RayQueue in, const StreamLayout layout,
-                                                              const RayQueue out, unsigned int *out_counts,
-                                                              unsigned int *dropped)
+                                                              const RayQueue out, unsigned int *counters)
 {
     extern __shared__ float4 lds_scene[];
     __shared__ unsigned int wave_kids[2][kBlock / 64];       // children per wave, pass 0 / pass 1
+    __shared__ unsigned int wave_live[kBlock / 64], wave_deep[kBlock / 64];
     __shared__ unsigned int block_base;
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -762,7 +763,8 @@ __global__ void __launch_bounds__(kBlock) streams_step_kernel(const RenderArgs a
 
     int n_kids = 0;
     V3 ko[2], kd[2], kt[2]; Sfc32 ks[2];
-    uint32_t pixel = 0;
+    uint32_t pixel = 0, depth = 0;
+    unsigned int continued = 0, deepest = 0;
     if (gi < layout.prefix[kStreamShards]) {
         int k = 0;
         while (gi >= layout.prefix[k + 1]) ++k;                            // at most kStreamShards - 1 steps
@@ -771,56 +773,77 @@ __global__ void __launch_bounds__(kBlock) streams_step_kernel(const RenderArgs a
         V3 d = mk(in.f[3][i], in.f[4][i], in.f[5][i]);
         V3 throughput = mk(in.f[6][i], in.f[7][i], in.f[8][i]);
         pixel = in.pixel[i];
+        depth = in.depth[i];
         Sfc32 seed;
         seed.a = in.seed[0][i]; seed.b = in.seed[1][i]; seed.c = in.seed[2][i]; seed.counter = in.seed[3][i];
-        const HitSel h = check_hit(S, ns, np, o, d);
-        if (h.just) {
+        // A ray whose hit spawns ONE child (Matte, Glossy) keeps that child in this lane and takes its next
+        // traceStep right away; only GLASS hits, which spawn two rays, go through the stream.  The set of
+        // results is that of one traceStep per launch; a pixel's results still arrive in step order from
+        // any one lineage, so scenes without GLASS stay bit-identical to the per-pixel kernel.
+        for (;;) {
+            if (depth >= (uint32_t)kStreamStepCap) break;                  // awhile would have stopped here
+            deepest = depth + 1;
+            const HitSel h = check_hit(S, ns, np, o, d);
+            if (!h.just) break;
             V3 hit_pos, normal;
             hit_record(S, ns, h.idx, o, d, h.t, hit_pos, normal);
             const float4 ma = M[2 * h.idx], mb = M[2 * h.idx + 1];
             const bool alive = !near_zero(throughput);                      // numNewRays (Trace.hs:329-331)
+            const bool glass = f2u(mb.x) == 2u;
             V3 contribution;
-            if (f2u(mb.x) == 2u) {                                          // GLASS
+            if (glass) {
                 contribution = scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput;
                 if (alive) { glass_children(mk(ma.x, ma.y, ma.z), mb.y, hit_pos, normal, d, throughput, seed, ko, kd, kt, ks); n_kids = 2; }
             } else {
                 contribution = mk(0.0f, 0.0f, 0.0f);
                 shade(M, h.idx, hit_pos, normal, o, d, throughput, contribution, seed);   // contribution = 0 + emittance * throughput
-                if (alive) { ko[0] = o; kd[0] = d; kt[0] = throughput; ks[0] = seed; n_kids = 1; }
             }
             // computeResult + permute (+) (Trace.hs:179-184, :318-323); adding an exact zero changes nothing
             if (contribution.x != 0.0f) atomicAdd(a.planes.r + pixel, contribution.x);
             if (contribution.y != 0.0f) atomicAdd(a.planes.g + pixel, contribution.y);
             if (contribution.z != 0.0f) atomicAdd(a.planes.b + pixel, contribution.z);
+            if (glass || !alive) break;
+            ++depth; ++continued;                                           // the single child: next traceStep, same lane
         }
     }
-    // expand (Trace.hs:284-289): compaction of the children into the next stream.  Wave level: ballot + popcount
-    // prefix; workgroup level: the wave totals meet in LDS and ONE lane appends for the whole workgroup, to the
-    // counter of the shard this workgroup writes (blockIdx & 7: workgroups dealt to the same XCD share a shard).
+    // expand (Trace.hs:284-289) for the rays that split: compaction of the children into the next stream.  Wave
+    // level: ballot + popcount prefix; workgroup level: the wave totals meet in LDS and ONE lane appends for the
+    // whole workgroup, to the counter of the shard this workgroup writes (blockIdx & 7: workgroups dealt to the same
+    // XCD share a shard).  Statistics ride on the same pattern: no per-wave atomics on a single word.
     const unsigned long long mask0 = __ballot(n_kids > 0), mask1 = __ballot(n_kids > 1);
-    if (lane == 0) { wave_kids[0][wave] = (unsigned int)__builtin_popcountll(mask0); wave_kids[1][wave] = (unsigned int)__builtin_popcountll(mask1); }
+    const unsigned int wave_cont = (unsigned int)wave_sum(continued);
+    unsigned int wave_max = deepest;
+    for (int off = 32; off > 0; off >>= 1) { const unsigned int other = __shfl_xor(wave_max, off, 64); wave_max = other > wave_max ? other : wave_max; }
+    if (lane == 0) {
+        wave_kids[0][wave] = (unsigned int)__builtin_popcountll(mask0); wave_kids[1][wave] = (unsigned int)__builtin_popcountll(mask1);
+        wave_live[wave] = wave_cont; wave_deep[wave] = wave_max;
+    }
     __syncthreads();
     const int shard = blockIdx.x & (kStreamShards - 1);
+    const unsigned int out_cap = out.capacity / kStreamShards;
     if (threadIdx.x == 0) {
-        unsigned int total = 0;
-        for (int w = 0; w < kBlock / 64; ++w) total += wave_kids[0][w] + wave_kids[1][w];
-        block_base = total ? atomicAdd(out_counts + shard * kCounterStride, total) : 0u;
+        unsigned int total = 0, live = 0, deep = 0;
+        for (int w = 0; w < kBlock / 64; ++w) {
+            total += wave_kids[0][w] + wave_kids[1][w]; live += wave_live[w];
+            deep = wave_deep[w] > deep ? wave_deep[w] : deep;
+        }
+        block_base = total ? atomicAdd(counters + shard * kCounterStride, total) : 0u;
+        const unsigned int fit = block_base >= out_cap ? 0u : (out_cap - block_base < total ? out_cap - block_base : total);
+        if (live + fit) atomicAdd(counters + (kCtrLive + shard) * kCounterStride, live + fit);
+        if (total - fit) atomicAdd(counters + kCtrDropped * kCounterStride, total - fit);
+        if (deep) atomicMax(counters + (kCtrDeepest + shard) * kCounterStride, deep);
     }
     __syncthreads();
     unsigned int base = block_base;
     for (int w = 0; w < wave; ++w) base += wave_kids[0][w] + wave_kids[1][w];
     const unsigned long long below = (1ull << lane) - 1ull;
-    const unsigned int out_cap = out.capacity / kStreamShards;
     for (int k = 0; k < 2; ++k) {
         if (n_kids > k) {
             const unsigned int slot = base + (k == 0 ? (unsigned int)__builtin_popcountll(mask0 & below)
                                                      : wave_kids[0][wave] + (unsigned int)__builtin_popcountll(mask1 & below));
-            if (slot < out_cap) queue_store(out, (unsigned int)shard * out_cap + slot, ko[k], kd[k], kt[k], pixel, ks[k]);
-            else atomicAdd(dropped, 1u);
+            if (slot < out_cap) queue_store(out, (unsigned int)shard * out_cap + slot, ko[k], kd[k], kt[k], pixel, ks[k], depth + 1u);
         }
     }
-    // No per-wave statistics atomic here: 130 000 waves per step on one counter word is what made this kernel
-    // 10x slower (a word serves ~90 atomics/us).  The host derives the live count from the stream lengths.
 }
 
 __global__ void __launch_bounds__(kBlock) streams_update_seed_kernel(Planes p, long long n)
@@ -1030,13 +1053,12 @@ hipError_t launch_streams_init(const RenderArgs &a, RayQueue q, hipStream_t stre
 }
 
 hipError_t launch_streams_step(const RenderArgs &a, RayQueue in, StreamLayout layout, RayQueue out,
-                               unsigned int *out_counts, unsigned int *dropped, hipStream_t stream)
+                               unsigned int *counters, hipStream_t stream)
 {
     const unsigned int n_in = layout.prefix[kStreamShards];
     if (n_in == 0) return hipSuccess;
     const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
-    hipLaunchKernelGGL((streams_step_kernel<true>), dim3(blocks_for(n_in)), dim3(kBlock), lds, stream, a, in, layout, out,
-                       out_counts, dropped);
+    hipLaunchKernelGGL((streams_step_kernel<true>), dim3(blocks_for(n_in)), dim3(kBlock), lds, stream, a, in, layout, out, counters);
     return hipGetLastError();
 }
 
