@@ -157,7 +157,8 @@ void pack_scene(const ptmi_sphere *sph, int ns, const ptmi_plane *pl, int np, st
     for (int j = 0; j < np; ++j) mat(pl[j].color, pl[j].illuminance, pl[j].brdf_tag, pl[j].brdf_param);
 }
 
-constexpr int kStreamCapacityFactor = 4;     // next stream holds at most 4 rays per pixel; excess children are dropped and counted
+constexpr int kStreamCapacityFactor = 4;     // next stream holds at most 4 rays per pixel-sample; excess children are dropped and counted
+constexpr int kStreamBatch = 4;              // samples that share one stream when the scene holds GLASS
 
 RayQueue carve_queue(void *block, size_t capacity, int which)
 {
@@ -177,8 +178,12 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
 {
     const size_t n = (size_t)a.rows_local * a.width;
     if (n == 0 || n_spp <= 0) return PTMI_OK;
+    // With GLASS the order of a pixel's additions is undefined anyway (several rays per pixel and launch), so up to
+    // kStreamBatch samples share one stream: fewer, larger launches and read-backs.  Without GLASS one sample per
+    // stream keeps the additions in sample order, i.e. bit-identical to the per-pixel kernel.
+    const int batch_max = c->has_glass ? (n * kStreamBatch * kStreamCapacityFactor <= 0xffffffffull ? kStreamBatch : 1) : 1;
     if (n * kStreamCapacityFactor > 0xffffffffull) return fail(c, PTMI_ELIMIT, "image too large for the wavefront Streams path");
-    const size_t capacity = ((n * kStreamCapacityFactor + kStreamShards - 1) / kStreamShards) * kStreamShards;
+    const size_t capacity = ((n * batch_max * kStreamCapacityFactor + kStreamShards - 1) / kStreamShards) * kStreamShards;
     const unsigned int shard_cap = (unsigned int)(capacity / kStreamShards);
     if (capacity != c->queue_capacity) {
         if (c->queue_block) { (void)hipFree(c->queue_block); c->queue_block = nullptr; c->queue_capacity = 0; }
@@ -189,12 +194,14 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
     if (!c->d_qcount) PTMI_HIP(c, hipMalloc(&c->d_qcount, kCounterWords * sizeof(unsigned int)));
     RayQueue q[2] = {carve_queue(c->queue_block, capacity, 0), carve_queue(c->queue_block, capacity, 1)};
     unsigned int longest = 0;
-    for (int s = 0; s < n_spp; ++s) {
-        PTMI_HIP(c, launch_streams_init(a, q[0], c->stream));            // pixel i at linear slot i: fills shards 0, 1, ... in order
+    for (int s = 0; s < n_spp;) {
+        const int batch = n_spp - s < batch_max ? n_spp - s : batch_max;
+        const size_t n_rays = n * (size_t)batch;
+        PTMI_HIP(c, launch_streams_init(a, q[0], batch, c->stream));     // ray j*n + i at linear slot j*n + i: fills shards 0, 1, ... in order
         unsigned int counts[kStreamShards], raw[kStreamCounters * kCounterStride];
         for (int k = 0; k < kStreamShards; ++k) {
             const size_t lo = (size_t)k * shard_cap;
-            counts[k] = n > lo ? (unsigned int)(n - lo < shard_cap ? n - lo : shard_cap) : 0u;
+            counts[k] = n_rays > lo ? (unsigned int)(n_rays - lo < shard_cap ? n_rays - lo : shard_cap) : 0u;
         }
         unsigned int launches = 0, deepest = 0;
         int cur = 0;
@@ -218,7 +225,8 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
             ++launches;
         }
         longest = deepest > longest ? deepest : longest;
-        PTMI_HIP(c, launch_streams_update_seed(a.planes, (long long)n, c->stream));
+        PTMI_HIP(c, launch_streams_update_seed(a.planes, (long long)n, batch, c->stream));
+        s += batch;
     }
     PTMI_HIP(c, hipMemcpyAsync(c->d_iters, &longest, sizeof longest, hipMemcpyHostToDevice, c->stream));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));

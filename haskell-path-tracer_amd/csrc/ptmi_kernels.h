@@ -56,10 +56,10 @@ constexpr int kStreamCounters = 3 * kStreamShards + 1;
 constexpr int kCtrDropped = kStreamShards, kCtrLive = kStreamShards + 1, kCtrDeepest = 2 * kStreamShards + 1;
 struct StreamLayout { unsigned int prefix[kStreamShards + 1]; };   // ray i of the input lives in shard k: prefix[k] <= i < prefix[k+1]
 
-hipError_t launch_streams_init(const RenderArgs &a, RayQueue q, hipStream_t stream);
+hipError_t launch_streams_init(const RenderArgs &a, RayQueue q, int batch, hipStream_t stream);
 hipError_t launch_streams_step(const RenderArgs &a, RayQueue in, StreamLayout layout, RayQueue out,
                                unsigned int *counters, hipStream_t stream);
-hipError_t launch_streams_update_seed(Planes p, long long n, hipStream_t stream);
+hipError_t launch_streams_update_seed(Planes p, long long n, int draws, hipStream_t stream);
 
 hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t stream);
 hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t stream);

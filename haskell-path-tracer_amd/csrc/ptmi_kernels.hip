@@ -728,7 +728,7 @@ __device__ __forceinline__ void glass_children(V3 color, float ior, V3 p, V3 n, 
     s_out[1] = seed;
 }
 
-__global__ void __launch_bounds__(kBlock) streams_init_kernel(const RenderArgs a, RayQueue q)
+__global__ void __launch_bounds__(kBlock) streams_init_kernel(const RenderArgs a, RayQueue q, int batch)
 {
     const long long n_local = (long long)a.rows_local * a.width;
     const long long pixel = (long long)blockIdx.x * kBlock + threadIdx.x;
@@ -738,7 +738,12 @@ __global__ void __launch_bounds__(kBlock) streams_init_kernel(const RenderArgs a
     const V3 primary = primary_direction(a.cam, col, global_row(local_row, a.stripe_rows, a.n_parts, a.part));
     Sfc32 s;
     s.a = a.planes.sa[pixel]; s.b = a.planes.sb[pixel]; s.c = a.planes.sc[pixel]; s.counter = a.planes.sctr[pixel];
-    queue_store(q, (unsigned int)pixel, a.cam.pos, primary, mk(1.0f, 1.0f, 1.0f), (uint32_t)pixel, s, 0u);   // initialState (Trace.hs:158-162)
+    // initialState (Trace.hs:158-162).  `batch` consecutive samples of the pixel share one stream: sample j starts from
+    // the pixel's seed advanced by j draws, which is what j applications of updateSeed leave behind (Trace.hs:190-191).
+    for (int j = 0; j < batch; ++j) {
+        queue_store(q, (unsigned int)((long long)j * n_local + pixel), a.cam.pos, primary, mk(1.0f, 1.0f, 1.0f), (uint32_t)pixel, s, 0u);
+        (void)random_float(s);
+    }
 }
 
 template <bool LDS_SCENE>
@@ -846,12 +851,12 @@ __global__ void __launch_bounds__(kBlock) streams_step_kernel(const RenderArgs a
     }
 }
 
-__global__ void __launch_bounds__(kBlock) streams_update_seed_kernel(Planes p, long long n)
+__global__ void __launch_bounds__(kBlock) streams_update_seed_kernel(Planes p, long long n, int draws)
 {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     Sfc32 s; s.a = p.sa[i]; s.b = p.sb[i]; s.c = p.sc[i]; s.counter = p.sctr[i];
-    (void)random_float(s);                                                  // updateSeed (Trace.hs:190-191)
+    for (int j = 0; j < draws; ++j) (void)random_float(s);                  // updateSeed (Trace.hs:190-191), once per sample
     p.sa[i] = s.a; p.sb[i] = s.b; p.sc[i] = s.c; p.sctr[i] = s.counter;
 }
 
@@ -1044,11 +1049,11 @@ hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t s
     return hipGetLastError();
 }
 
-hipError_t launch_streams_init(const RenderArgs &a, RayQueue q, hipStream_t stream)
+hipError_t launch_streams_init(const RenderArgs &a, RayQueue q, int batch, hipStream_t stream)
 {
     const long long n = (long long)a.rows_local * a.width;
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(streams_init_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, a, q);
+    hipLaunchKernelGGL(streams_init_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, a, q, batch);
     return hipGetLastError();
 }
 
@@ -1062,10 +1067,10 @@ hipError_t launch_streams_step(const RenderArgs &a, RayQueue in, StreamLayout la
     return hipGetLastError();
 }
 
-hipError_t launch_streams_update_seed(Planes p, long long n, hipStream_t stream)
+hipError_t launch_streams_update_seed(Planes p, long long n, int draws, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(streams_update_seed_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, p, n);
+    hipLaunchKernelGGL(streams_update_seed_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, p, n, draws);
     return hipGetLastError();
 }
 
