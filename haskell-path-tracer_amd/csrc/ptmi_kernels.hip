@@ -308,9 +308,13 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_
 #ifdef PTMI_PHASE_STATS
                 unsigned int st_iter = 0, st_a = 0, st_b = 0, st_c = 0;   // this lane's participation per round
 #endif
+#ifdef PTMI_PHASE_STATS
+                unsigned long long cyc_a = 0, cyc_b = 0, cyc_c = 0;
+#endif
                 while (pending) {
 #ifdef PTMI_PHASE_STATS
                     ++st_iter;
+                    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
 #endif
                     for (int round = 0; round < 2; ++round) {
                         if (pending && !has_ray) {
@@ -323,6 +327,9 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_
                             if (it >= limit || near_zero(throughput)) restart();
                             else { pending = false; has_ray = true; }
                         }
+#ifdef PTMI_PHASE_STATS
+                        { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); (round == 0 ? cyc_a : cyc_b) += t_now - t_prev; t_prev = t_now; }
+#endif
                     }
 #ifdef PTMI_PHASE_STATS
                     if (has_ray) ++st_c;
@@ -338,6 +345,9 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_
                             restart();
                         }
                     }
+#ifdef PTMI_PHASE_STATS
+                    cyc_c += __builtin_amdgcn_s_memtime() - t_prev;
+#endif
                 }
                 acc = mk(get(9), get(10), get(11));
 #ifdef PTMI_PHASE_STATS
@@ -349,7 +359,13 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_
                     for (int off = 32; off > 0; off >>= 1) { const unsigned int o2 = __shfl_xor(mx, off, 64); mx = o2 > mx ? o2 : mx; }
                     atomicAdd(a.work_counter + 1, st_iter); atomicAdd(a.work_counter + 2, st_a);
                     atomicAdd(a.work_counter + 3, st_b); atomicAdd(a.work_counter + 4, st_c);
-                    if ((threadIdx.x & 63) == (int)__builtin_ctzll(m)) atomicAdd(a.work_counter + 5, mx * 64u);
+                    if ((threadIdx.x & 63) == (int)__builtin_ctzll(m)) {
+                        atomicAdd(a.work_counter + 5, mx * 64u);
+                        // wave cycles spent in rounds A, B, C (the waves of a SIMD interleave, so these are shares, not costs)
+                        atomicAdd(reinterpret_cast<unsigned long long *>(a.work_counter + 8), cyc_a);
+                        atomicAdd(reinterpret_cast<unsigned long long *>(a.work_counter + 10), cyc_b);
+                        atomicAdd(reinterpret_cast<unsigned long long *>(a.work_counter + 12), cyc_c);
+                    }
                 }
 #endif
             }

@@ -35,6 +35,9 @@ def main():
     print(json.dumps({"persistent_kernel": {
         "lane_slots_paid": p[1], "round_A_occupancy": p[2] / p[1], "round_B_occupancy": p[3] / p[1],
         "round_C_occupancy": p[4] / p[1], "useful_trace_slots": p[4]}}))
+    raw = c.astype("uint32")
+    cyc = [int(raw[8 + 2 * k]) | (int(raw[9 + 2 * k]) << 32) for k in range(3)]
+    print(json.dumps({"wave_cycle_share": {"round_A": cyc[0] / sum(cyc), "round_B": cyc[1] / sum(cyc), "round_C_trace": cyc[2] / sum(cyc)}}))
     lane_iter, a, b, cc, paid = c[1], c[2], c[3], c[4], c[5]
     print(json.dumps({
         "lane_iterations_needed": lane_iter, "lane_iterations_paid_by_waves": paid,
