@@ -92,7 +92,7 @@ __device__ __noinline__ HitSel check_hit_exact(ScenePtr S, int ns, int np, V3 o,
 //   * spheres are walked two per trip with the two register sets swapping roles, so the prefetch of
 //     the next primitive costs no moves.
 template <typename ScenePtr>
-__device__ __forceinline__ HitSel check_hit(ScenePtr S, int ns, int np, V3 o, V3 d)
+__device__ __forceinline__ HitSel check_hit(ScenePtr S, int ns, int np, V3 o, V3 d, unsigned int *diag = nullptr)
 {
     float best_key = __builtin_nanf("");
     int best_idx = 0;
@@ -106,6 +106,17 @@ __device__ __forceinline__ HitSel check_hit(ScenePtr S, int ns, int np, V3 o, V3
         const float x = g.w - d2;                            // rad ** 2 - d2 (rad ** 2 squared at upload)
         // Nothing iff tca < 0 || d2 > rad**2 || t < 0;  d2 > r2 <=> r2 - d2 < 0 (exact: gradual underflow)
         const bool cand = !(tca < 0.0f) && !(x < 0.0f);
+#ifdef PTMI_SPHERE_STATS
+        {
+            const unsigned long long cm = __ballot(cand), am = __ballot(1);
+            if (diag && (threadIdx.x & 63) == (int)__builtin_ctzll(am)) {
+                atomicAdd(diag + 16, 1u);                                    // sphere tests (per wave)
+                if (cm) atomicAdd(diag + 17, 1u);                            // ... that took the square-root path
+                atomicAdd(diag + 18, (unsigned int)__builtin_popcountll(cm));   // candidate lanes
+                atomicAdd(diag + 19, (unsigned int)__builtin_popcountll(am));   // active lanes
+            }
+        }
+#endif
         if (__any(cand)) {
             const float t = tca - sqrt_rn(x);                // min t0 t1 == t0 (thc >= 0 or NaN)
             const bool just = cand && !(t < 0.0f);
@@ -335,7 +346,11 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_
                     if (has_ray) ++st_c;
 #endif
                     if (has_ray) {
+#ifdef PTMI_SPHERE_STATS
+                        const HitSel h = check_hit(S, ns, np, pos, d, a.work_counter);
+#else
                         const HitSel h = check_hit(S, ns, np, pos, d);
+#endif
                         has_ray = false;
                         if (h.just) {
                             hit_record(S, ns, h.idx, pos, d, h.t, pos, normal);

@@ -38,6 +38,22 @@ def main():
     raw = c.astype("uint32")
     cyc = [int(raw[8 + 2 * k]) | (int(raw[9 + 2 * k]) << 32) for k in range(3)]
     print(json.dumps({"wave_cycle_share": {"round_A": cyc[0] / sum(cyc), "round_B": cyc[1] / sum(cyc), "round_C_trace": cyc[2] / sum(cyc)}}))
+    # second diagnostic build: per-sphere statistics (many atomics: never combined with the cycle stamps)
+    out2 = "/tmp/libptmi_sphere_stats.so"
+    pkg._build.build_lib(out=out2, extra_flags=["-DPTMI_SPHERE_STATS"])
+    pkg.binding._lib = None
+    pkg.binding.load_library(out2)
+    with pkg.Context(0) as ctx:
+        ctx.set_scene(sp, pl)
+        ctx.resize(w, h)
+        ctx.set_variant(4)
+        ctx.init_output(0x5EED1234)
+        ctx.reset_stats()
+        ctx.render(pkg.world.initial_camera(), 8, 8)
+        raw = ctx.debug_counters().astype("uint32")
+    print(json.dumps({"sphere_tests": {"per_wave_tests": float(raw[16]), "fraction_taking_sqrt_path": float(raw[17]) / max(float(raw[16]), 1),
+                                       "candidate_lanes_per_test": float(raw[18]) / max(float(raw[16]), 1),
+                                       "active_lanes_per_test": float(raw[19]) / max(float(raw[16]), 1)}}))
     lane_iter, a, b, cc, paid = c[1], c[2], c[3], c[4], c[5]
     print(json.dumps({
         "lane_iterations_needed": lane_iter, "lane_iterations_paid_by_waves": paid,
