@@ -170,6 +170,9 @@ def main():
     while time.perf_counter() - t_ramp < 0.3:
         ctx.render(cam, BOUNCE_LIMIT, spp, algorithm)
         torch.cuda.synchronize()
+    if world > 1:
+        gather.overlapped(color)                     # first collective = communicator set-up; not a warm-up step
+        gather.wait()
     ctx.init_output(SEED0)
     for _ in range(args.warmup):
         step()
