@@ -154,9 +154,12 @@ PTMI_HD void sincos_t(float y, float &sn, float &cs)
         const double c = c1 + x4 * 0x1.55553e1068f19p-5;
         Cp = (float)(c + x6 * c2);
     }
-    const float C = (m & 2) ? -Cp : Cp;
-    sn = (n & 1) ? C : S;
-    cs = (n & 1) ? S : C;
+    // table row 1 (m & 2) negates the cosine polynomial; n & 1 swaps which polynomial is the sine.  Done on the bit
+    // patterns (xor / and) instead of selects: back-to-back v_cndmask pairs are slow on gfx950.
+    const uint32_t cb = f2u(Cp) ^ (((uint32_t)m & 2u) << 30), sb = f2u(S);
+    const uint32_t swap = (sb ^ cb) & (0u - ((uint32_t)n & 1u));
+    sn = u2f(sb ^ swap);
+    cs = u2f(cb ^ swap);
     if (top < 0x398) { sn = y; cs = 1.0f; }              // |y| < 2^-12
 }
 
