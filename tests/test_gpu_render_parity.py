@@ -27,6 +27,8 @@ def run_gpu(ctx, pkg, scene, cam, w, h, limit, spp, start, algorithm=None):
     (97, 61, 15, 3, "s16"),        # ragged: not a multiple of the 256-lane workgroup
     (64, 1, 8, 2, "main"),
     (1, 64, 8, 2, "main"),
+    (48, 40, 8, 700, "s16"),       # many restarts per lane: long per-pixel chains of samples
+    (32, 24, 64, 33, "main"),      # a bounce limit no path reaches
 ])
 def test_render_inline_matches_oracle(ctx, pkg, ora, w, h, limit, spp, scene_name):
     scene = pkg.world.main_scene() if scene_name == "main" else pkg.world.scene16()
