@@ -187,20 +187,16 @@ __device__ __forceinline__ float gen_component(Sfc32 &seed)
     return ((i * 4.656612873077392578125e-10f + 1.0f) + 2.3283064365386962890625e-10f) - 1.0f;
 }
 
-// computeRay (Trace.hs:374-383) + calcNextRay (Trace.hs:394-435), both BRDF arms evaluated
-// through selects so that Matte and Glossy lanes of one wave do not serialise.
+// calcNextRay's direction part (Trace.hs:394-429): the three draws, the rotated direction `next` and the BRDF
+// factor `b`.  Both BRDF arms are evaluated through selects so that Matte and Glossy lanes of one wave do not
+// serialise.  M points at the material records.
 template <typename ScenePtr>
-__device__ __forceinline__ void shade(ScenePtr M, int idx, V3 hit_pos, V3 normal,
-                                      V3 &o, V3 &d, V3 &throughput, V3 &result, Sfc32 &seed)
+__device__ __forceinline__ void next_direction(ScenePtr M, int idx, V3 normal, V3 d, Sfc32 &seed, V3 &next, float &brdf)
 {
-    const float4 ma = M[2 * idx], mb = M[2 * idx + 1];
-    const V3 color = mk(ma.x, ma.y, ma.z);
-    const float illuminance = ma.w;
+    const float4 mb = M[2 * idx + 1];
     const bool matte = f2u(mb.x) == 0u;
     const float p_over_pi = mb.z;          // p / pi            (Trace.hs:411), divided at upload
     const float half_k_glossy = mb.w;      // 0.5 * (1 - p)     (Trace.hs:424 and Util.hs:62-67), exact halving
-
-    const V3 emittance = scale_r(color, illuminance);
     V3 rv;
     rv.x = gen_component(seed); rv.y = gen_component(seed); rv.z = gen_component(seed);
     // Matte:  rotate (anglesToQuaternion $ pi *^ rv) iNormal
@@ -210,16 +206,36 @@ __device__ __forceinline__ void shade(ScenePtr M, int idx, V3 hit_pos, V3 normal
     const V3 reflection = d - scale_l(2.0f * ia, normal);
     const V3 axis = matte ? normal : reflection;
     const float hk = matte ? 0.5f * kPi : half_k_glossy;
-    const V3 next = rotate(quaternion_from_half_angles(hk * rv.x, hk * rv.y, hk * rv.z), axis);
+    next = rotate(quaternion_from_half_angles(hk * rv.x, hk * rv.y, hk * rv.z), axis);
     const float nd = dot(next, axis);
-    const float brdf = matte ? p_over_pi * nd : __builtin_fmaxf(0.0f, nd);
-    constexpr float next_ray_prob = 1.0f / (kPi * 2.0f);
+    brdf = matte ? p_over_pi * nd : __builtin_fmaxf(0.0f, nd);
+}
 
+// The rest of calcNextRay (Trace.hs:431-435) and computeRay (Trace.hs:374-383) once `next` and `b` are known.
+template <typename ScenePtr>
+__device__ __forceinline__ void apply_bounce(ScenePtr M, int idx, V3 hit_pos, V3 next, float brdf,
+                                             V3 &o, V3 &d, V3 &throughput, V3 &result)
+{
+    const float4 ma = M[2 * idx];
+    const V3 color = mk(ma.x, ma.y, ma.z);
+    const float illuminance = ma.w;
+    const V3 emittance = scale_r(color, illuminance);
+    constexpr float next_ray_prob = 1.0f / (kPi * 2.0f);
     o = hit_pos + scale_r(next, kEpsilon);
     d = next;
     const V3 tmod = scale_r(color, brdf * next_ray_prob);
     result = result + (emittance * throughput);
     throughput = throughput * tmod;
+}
+
+// computeRay (Trace.hs:374-383) + calcNextRay (Trace.hs:394-435)
+template <typename ScenePtr>
+__device__ __forceinline__ void shade(ScenePtr M, int idx, V3 hit_pos, V3 normal,
+                                      V3 &o, V3 &d, V3 &throughput, V3 &result, Sfc32 &seed)
+{
+    V3 next; float brdf;
+    next_direction(M, idx, normal, d, seed, next, brdf);
+    apply_bounce(M, idx, hit_pos, next, brdf, o, d, throughput, result);
 }
 
 __device__ __forceinline__ int global_row(int local_row, int stripe_rows, int n_parts, int part)
@@ -432,6 +448,192 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_
         const unsigned long long total = wave_sum(live);
         if ((threadIdx.x & 63) == 0 && total) atomicAdd(a.live_counter, total);
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// render Inline, pooled second shade round.  Same loop [shade A][shade B][trace C] and the same arithmetic as
+// kCached, but the B round -- lanes whose sample ended in A and whose next sample starts from the cached
+// primary hit; only ~49 % of a wave's lanes -- is shared by the W waves of a workgroup: a restarting lane
+// posts (seed, owner) into an LDS pool (ballot + prefix inside the wave, one LDS atomic per wave for the base),
+// the pool's items are shaded densely by as many waves as it takes (the others skip the round), and the
+// owner picks up (seed', next, b) and finishes computeRay itself.  An item's inputs besides the seed are the
+// owner's restart record, which already lives in LDS.  A pixel's arithmetic does not depend on which lane
+// executes it, so the planes stay bit-identical.
+// Requires bounce_limit >= 1 and n_spp >= 1 (the launcher routes the degenerate cases elsewhere).
+// ---------------------------------------------------------------------------------------
+template <bool LDS_SCENE, int W>
+__global__ void __launch_bounds__(64 * W, 6) render_inline_pooled_kernel(const RenderArgs a)
+{
+    constexpr int kThreads = 64 * W;
+    __shared__ float pixel_const[13][kThreads];             // restart record: hit pos, normal, primary dir, acc, primitive index
+    __shared__ unsigned int pool[8][kThreads];              // in: seed[4], owner | out: seed'[4], b, next[3]
+    __shared__ unsigned int pool_count[2];                  // items | (waves with work << 16), alternating per trip
+    extern __shared__ float4 lds_scene[];
+    const int ns = a.scene.n_spheres, np = a.scene.n_planes;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 2) pool_count[tid] = 0;
+    if (LDS_SCENE) {
+        const int total = a.scene.total_f4();
+        for (int i = tid; i < total; i += kThreads) lds_scene[i] = a.scene.packed[i];
+    }
+    __syncthreads();
+    const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
+    const float4 *M = S + a.scene.geom_f4();
+
+    const long long n_local = (long long)a.rows_local * a.width;
+    const long long pixel = (long long)blockIdx.x * kThreads + tid;
+    const bool valid = pixel < n_local;
+    const int limit = a.bounce_limit, n_spp = a.n_spp;
+    unsigned int live = 0;
+
+    float *mine = &pixel_const[0][tid];
+    auto put = [&](int k, float v) { mine[k * kThreads] = v; };
+    auto get = [&](int k) { return mine[k * kThreads]; };
+
+    Sfc32 seed; seed.a = seed.b = seed.c = seed.counter = 0;
+    V3 pos = mk(0, 0, 0), normal = pos, d = pos;
+    V3 throughput = mk(1.0f, 1.0f, 1.0f), result = mk(0.0f, 0.0f, 0.0f);
+    int s = 0, it = 0, idx = 0, idx0 = 0;
+    bool pending = false, has_ray = false;
+
+    if (valid) {
+        const int local_row = (int)(pixel / a.width);
+        const int col = (int)(pixel - (long long)local_row * a.width);
+        int64_t px = col, py = global_row(local_row, a.stripe_rows, a.n_parts, a.part);
+        if (a.screen_x) { px = a.screen_x[pixel]; py = a.screen_y[pixel]; }
+        const V3 origin = a.cam.pos;
+        const V3 primary = primary_direction(a.cam, px, py);
+        V3 acc = mk(a.planes.r[pixel], a.planes.g[pixel], a.planes.b[pixel]);
+        seed.a = a.planes.sa[pixel]; seed.b = a.planes.sb[pixel];
+        seed.c = a.planes.sc[pixel]; seed.counter = a.planes.sctr[pixel];
+        const HitSel h0 = check_hit(S, ns, np, origin, primary);
+        if (!h0.just) {
+            acc = mk(0.0f, 0.0f, 0.0f) + acc;                // every sample: result 0, seed untouched
+        } else {
+            hit_record(S, ns, h0.idx, origin, primary, h0.t, pos, normal);
+            put(0, pos.x); put(1, pos.y); put(2, pos.z);
+            put(3, normal.x); put(4, normal.y); put(5, normal.z);
+            put(6, primary.x); put(7, primary.y); put(8, primary.z);
+            put(12, u2f((uint32_t)h0.idx));
+            idx0 = idx = h0.idx;
+            d = primary;
+            pending = true;
+        }
+        put(9, acc.x); put(10, acc.y); put(11, acc.z);
+    }
+    auto restart = [&]() {                                    // next sample of this pixel
+        // \(new, seed') (old, _) -> (new + old, seed')
+        put(9, result.x + get(9)); put(10, result.y + get(10)); put(11, result.z + get(11));
+        ++s; it = 0;
+        throughput = mk(1.0f, 1.0f, 1.0f); result = mk(0.0f, 0.0f, 0.0f);
+        pos = mk(get(0), get(1), get(2)); normal = mk(get(3), get(4), get(5));
+        d = mk(get(6), get(7), get(8)); idx = idx0;
+        pending = s < n_spp;
+    };
+
+#ifdef PTMI_POOL_STATS
+    unsigned int st_trips = 0, st_alive = 0, st_batches = 0, st_items = 0;
+    unsigned long long cyc[5] = {0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
+    auto stamp = [&](int k) { const unsigned long long t = __builtin_amdgcn_s_memtime(); cyc[k] += t - t_prev; t_prev = t; };
+#else
+    auto stamp = [](int) {};
+#endif
+    for (unsigned int trip = 0;; ++trip) {
+        // ---- round A: in place
+        if (pending && !has_ray) {
+            shade(M, idx, pos, normal, pos, d, throughput, result, seed);
+            ++it; ++live;
+            // the next prepareRay would freeze the path (Trace.hs:364-365)
+            if (it >= limit || near_zero(throughput)) restart();
+            else { pending = false; has_ray = true; }
+        }
+        stamp(0);
+        // ---- round B: restarted lanes post their item
+        const bool need_b = pending && !has_ray;
+        const unsigned long long mask = __ballot(need_b);
+        const bool wave_alive = __any(pending || has_ray);
+        unsigned int base = 0;
+        if (lane == 0 && wave_alive)
+            base = atomicAdd(&pool_count[trip & 1], (unsigned int)__builtin_popcountll(mask) | (1u << 16));
+        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base) & 0xffffu;
+        const int slot = (int)base + (int)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        if (need_b) {
+            pool[0][slot] = seed.a; pool[1][slot] = seed.b; pool[2][slot] = seed.c; pool[3][slot] = seed.counter;
+            pool[4][slot] = (unsigned int)tid;
+        }
+        __syncthreads();
+        stamp(1);
+        const unsigned int count = pool_count[trip & 1];
+        if ((count >> 16) == 0) break;                       // no wave of the workgroup has work left
+        if (tid == 0) pool_count[(trip & 1) ^ 1] = 0;        // last read before this barrier, next written after the one below
+        const int n_items = (int)(count & 0xffffu);
+        // the waves take 64-item batches in an order that rotates with the trip, so the extra work moves over the SIMDs
+        for (int b0 = (int)((wave + trip) % W) * 64; b0 < n_items; b0 += kThreads) {
+            const int item = b0 + lane;
+#ifdef PTMI_POOL_STATS
+            ++st_batches; st_items += (unsigned int)__builtin_popcountll(__ballot(item < n_items));
+#endif
+            if (item < n_items) {
+                Sfc32 sd; sd.a = pool[0][item]; sd.b = pool[1][item]; sd.c = pool[2][item]; sd.counter = pool[3][item];
+                const float *rec = &pixel_const[0][pool[4][item]];
+                const V3 n_i = mk(rec[3 * kThreads], rec[4 * kThreads], rec[5 * kThreads]);
+                const V3 d_i = mk(rec[6 * kThreads], rec[7 * kThreads], rec[8 * kThreads]);
+                const int idx_i = (int)f2u(rec[12 * kThreads]);
+                V3 next; float brdf;
+                next_direction(M, idx_i, n_i, d_i, sd, next, brdf);
+                pool[0][item] = sd.a; pool[1][item] = sd.b; pool[2][item] = sd.c; pool[3][item] = sd.counter;
+                pool[4][item] = f2u(brdf);
+                pool[5][item] = f2u(next.x); pool[6][item] = f2u(next.y); pool[7][item] = f2u(next.z);
+            }
+        }
+        stamp(2);
+        __syncthreads();
+        if (need_b) {
+            seed.a = pool[0][slot]; seed.b = pool[1][slot]; seed.c = pool[2][slot]; seed.counter = pool[3][slot];
+            const float brdf = u2f(pool[4][slot]);
+            const V3 next = mk(u2f(pool[5][slot]), u2f(pool[6][slot]), u2f(pool[7][slot]));
+            apply_bounce(M, idx, pos, next, brdf, pos, d, throughput, result);
+            ++it; ++live;
+            if (it >= limit || near_zero(throughput)) restart();
+            else { pending = false; has_ray = true; }
+        }
+        stamp(3);
+#ifdef PTMI_POOL_STATS
+        ++st_trips; st_alive += wave_alive ? 1u : 0u;
+#endif
+        // ---- round C: trace
+        if (has_ray) {
+            const HitSel h = check_hit(S, ns, np, pos, d);
+            has_ray = false;
+            if (h.just) {
+                hit_record(S, ns, h.idx, pos, d, h.t, pos, normal);
+                idx = h.idx;
+                pending = true;
+            } else {
+                restart();
+            }
+        }
+        stamp(4);
+    }
+
+    if (valid) {
+        a.planes.r[pixel] = get(9); a.planes.g[pixel] = get(10); a.planes.b[pixel] = get(11);
+        a.planes.sa[pixel] = seed.a; a.planes.sb[pixel] = seed.b;
+        a.planes.sc[pixel] = seed.c; a.planes.sctr[pixel] = seed.counter;
+    }
+    if (a.live_counter) {
+        const unsigned long long total = wave_sum(live);
+        if (lane == 0 && total) atomicAdd(a.live_counter, total);
+    }
+#ifdef PTMI_POOL_STATS
+    // diagnostic build only: per wave [1] trips, [2] trips with own work, [3] B batches executed, [4] B items executed,
+    // [8..17] cycles in: round A | post + barrier | B batches | barrier + pick-up | trace
+    if (lane == 0) {
+        atomicAdd(a.work_counter + 1, st_trips); atomicAdd(a.work_counter + 2, st_alive);
+        atomicAdd(a.work_counter + 3, st_batches); atomicAdd(a.work_counter + 4, st_items);
+        for (int k = 0; k < 5; ++k) atomicAdd(reinterpret_cast<unsigned long long *>(a.work_counter + 8 + 2 * k), cyc[k]);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1054,6 +1256,14 @@ hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t st
         if (e != hipSuccess) return e;
         if (variant == 1) hipLaunchKernelGGL((render_inline_persistent_kernel<true>), dim3(blocks), block, lds, stream, a);
         else              hipLaunchKernelGGL((render_inline_persistent_kernel<false>), dim3(blocks), block, 0, stream, a);
+        return hipGetLastError();
+    }
+    if (variant >= 10 && variant <= 12) {                    // pooled second shade round, W = 2 / 4 / 8 waves per workgroup
+        const int w = variant == 10 ? 2 : variant == 11 ? 4 : 8;
+        const dim3 pgrid(blocks_for(n_local, 64 * w)), pblock(64 * w);
+        if (w == 2)      hipLaunchKernelGGL((render_inline_pooled_kernel<true, 2>), pgrid, pblock, lds, stream, a);
+        else if (w == 4) hipLaunchKernelGGL((render_inline_pooled_kernel<true, 4>), pgrid, pblock, lds, stream, a);
+        else             hipLaunchKernelGGL((render_inline_pooled_kernel<true, 8>), pgrid, pblock, lds, stream, a);
         return hipGetLastError();
     }
     switch (variant) {
