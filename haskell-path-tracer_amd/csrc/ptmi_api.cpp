@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "ptmi_kernels.h"
+#include "ptmi_stage.h"
 
 using namespace ptmi;
 
@@ -46,6 +47,7 @@ struct ptmi_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
     int variant = 0;
+    Stager stager;                          // pinned ring + worker threads for host-buffer entry points (ptmi_stage.h)
 
     // scratch for ptmi_render1 / point queries
     void *scratch = nullptr;
@@ -115,6 +117,36 @@ int ensure_scratch(ptmi_ctx *c, size_t bytes)
     PTMI_HIP(c, hipMalloc(&c->scratch, bytes));
     c->scratch_bytes = bytes;
     return PTMI_OK;
+}
+
+// Host-buffer transfers of the boundary (stream-ordered on c->stream).  Transfers of a megabyte or more go through
+// the context's Stager (ptmi_stage.h: parallel page copies into a pinned ring, one DMA per 8-MB chunk -- the driver
+// never pins the caller's pages); small ones, or all of them when the engine is off (PTMI_STAGE_THREADS=0), are
+// plain async copies.  copy_to_host leaves the stream drained in both cases.
+hipError_t copy_to_device(ptmi_ctx *c, const CopySpan *spans, int n)
+{
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += spans[i].bytes;
+    if (c->stager.threads() > 0 && total >= Stager::kMinBytes) return c->stager.to_device(spans, n, c->stream);
+    for (int i = 0; i < n; ++i) {
+        if (!spans[i].bytes) continue;
+        const hipError_t e = hipMemcpyAsync(spans[i].dev, spans[i].host, spans[i].bytes, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t copy_to_host(ptmi_ctx *c, const CopySpan *spans, int n)
+{
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += spans[i].bytes;
+    if (c->stager.threads() > 0 && total >= Stager::kMinBytes) return c->stager.to_host(spans, n, c->stream);
+    for (int i = 0; i < n; ++i) {
+        if (!spans[i].bytes) continue;
+        const hipError_t e = hipMemcpyAsync(spans[i].host, spans[i].dev, spans[i].bytes, hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipStreamSynchronize(c->stream);
 }
 
 // primaryRays' per-launch values (src/Scene/Trace.hs:205-242), evaluated on the host with
@@ -494,9 +526,9 @@ int ptmi_create_with(ptmi_ctx *c, const uint32_t *w0, const uint32_t *w1, const 
     if (int rc = ensure_scratch(c, 3 * n * 4)) return rc;
     uint32_t *d = static_cast<uint32_t *>(c->scratch);
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
-    PTMI_HIP(c, hipMemcpyAsync(d, w0, n * 4, hipMemcpyHostToDevice, c->stream));
-    PTMI_HIP(c, hipMemcpyAsync(d + n, w1, n * 4, hipMemcpyHostToDevice, c->stream));
-    PTMI_HIP(c, hipMemcpyAsync(d + 2 * n, w2, n * 4, hipMemcpyHostToDevice, c->stream));
+    const CopySpan words[3] = {{d, const_cast<uint32_t *>(w0), n * 4}, {d + n, const_cast<uint32_t *>(w1), n * 4},
+                               {d + 2 * n, const_cast<uint32_t *>(w2), n * 4}};
+    PTMI_HIP(c, copy_to_device(c, words, 3));
     PTMI_HIP(c, launch_create_with(active(c), d, d + n, d + 2 * n, (int64_t)n, c->stream));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
     return PTMI_OK;
@@ -514,8 +546,11 @@ int ptmi_upload_state(ptmi_ctx *c, const float *r, const float *g, const float *
     Planes &p = active(c);
     const void *src[7] = {r, g, b, sa, sb, sc, sctr};
     void *dst[7] = {p.r, p.g, p.b, p.sa, p.sb, p.sc, p.sctr};
+    CopySpan spans[7];
+    int n_spans = 0;
     for (int i = 0; i < 7; ++i)
-        if (src[i] && bytes) PTMI_HIP(c, hipMemcpyAsync(dst[i], src[i], bytes, hipMemcpyHostToDevice, c->stream));
+        if (src[i] && bytes) spans[n_spans++] = CopySpan{dst[i], const_cast<void *>(src[i]), bytes};
+    PTMI_HIP(c, copy_to_device(c, spans, n_spans));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
     return PTMI_OK;
 }
@@ -532,9 +567,11 @@ int ptmi_download_state(ptmi_ctx *c, float *r, float *g, float *b,
     Planes &p = active(c);
     void *dst[7] = {r, g, b, sa, sb, sc, sctr};
     const void *src[7] = {p.r, p.g, p.b, p.sa, p.sb, p.sc, p.sctr};
+    CopySpan spans[7];
+    int n_spans = 0;
     for (int i = 0; i < 7; ++i)
-        if (dst[i] && bytes) PTMI_HIP(c, hipMemcpyAsync(dst[i], src[i], bytes, hipMemcpyDeviceToHost, c->stream));
-    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+        if (dst[i] && bytes) spans[n_spans++] = CopySpan{const_cast<void *>(src[i]), dst[i], bytes};
+    PTMI_HIP(c, copy_to_host(c, spans, n_spans));
     return PTMI_OK;
 }
 
@@ -591,15 +628,17 @@ int ptmi_render1(ptmi_ctx *c, const ptmi_camera *camera, int algorithm, int boun
     const void *src[7] = {r_in, g_in, b_in, sa_in, sb_in, sc_in, sctr_in};
     void *dev[7] = {p.r, p.g, p.b, p.sa, p.sb, p.sc, p.sctr};
     void *dst[7] = {r_out, g_out, b_out, sa_out, sb_out, sc_out, sctr_out};
-    for (int i = 0; i < 7; ++i) PTMI_HIP(c, hipMemcpyAsync(dev[i], src[i], n * 4, hipMemcpyHostToDevice, c->stream));
+    CopySpan in[9];
+    for (int i = 0; i < 7; ++i) in[i] = CopySpan{dev[i], const_cast<void *>(src[i]), n * 4};
     if (screen_x) {
-        PTMI_HIP(c, hipMemcpyAsync(dsx, screen_x, n * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-        PTMI_HIP(c, hipMemcpyAsync(dsy, screen_y, n * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        in[7] = CopySpan{dsx, const_cast<int64_t *>(screen_x), n * sizeof(int64_t)};
+        in[8] = CopySpan{dsy, const_cast<int64_t *>(screen_y), n * sizeof(int64_t)};
     }
+    PTMI_HIP(c, copy_to_device(c, in, screen_x ? 9 : 7));
     if (int rc = launch_render(c, p, camera, algorithm, bounce_limit, 1, width, height, height, height, 1, 0, dsx, dsy)) return rc;
-    PTMI_HIP(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 7; ++i) PTMI_HIP(c, hipMemcpyAsync(dst[i], dev[i], n * 4, hipMemcpyDeviceToHost, c->stream));
-    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    CopySpan out[7];
+    for (int i = 0; i < 7; ++i) out[i] = CopySpan{dev[i], dst[i], n * 4};
+    PTMI_HIP(c, copy_to_host(c, out, 7));           // stream-ordered behind the kernel; returns with the planes filled
     return PTMI_OK;
 }
 
@@ -619,9 +658,11 @@ int ptmi_present(ptmi_ctx *c, int iterations, float *rgb32f_out, uint8_t *rgba8_
     uint32_t *d_rgba = reinterpret_cast<uint32_t *>(static_cast<char *>(c->scratch) + rgb_bytes);
     PTMI_HIP(c, launch_present(active(c), (long long)n, iterations, rgb32f_out ? d_rgb : nullptr,
                                rgba8_out ? d_rgba : nullptr, c->stream));
-    if (rgb32f_out) PTMI_HIP(c, hipMemcpyAsync(rgb32f_out, d_rgb, n * 12, hipMemcpyDeviceToHost, c->stream));
-    if (rgba8_out) PTMI_HIP(c, hipMemcpyAsync(rgba8_out, d_rgba, n * 4, hipMemcpyDeviceToHost, c->stream));
-    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    CopySpan out[2];
+    int n_out = 0;
+    if (rgb32f_out) out[n_out++] = CopySpan{d_rgb, rgb32f_out, n * 12};
+    if (rgba8_out) out[n_out++] = CopySpan{d_rgba, rgba8_out, n * 4};
+    PTMI_HIP(c, copy_to_host(c, out, n_out));
     return PTMI_OK;
 }
 

@@ -280,3 +280,43 @@ def test_large_scenes_up_to_the_primitive_limit(ctx, pkg, ora, n_spheres, n_plan
         with pytest.raises(pkg.PtmiError) as e:
             ctx.set_scene(np.concatenate([spheres, spheres[:1]]), planes)
         assert e.value.code == -6
+
+
+def test_staged_host_transfers_equal_plain_copies(pkg, ora, monkeypatch):
+    """Host-buffer entry points move large planes through the pinned ring with worker threads (ptmi_stage.h);
+    PTMI_STAGE_THREADS=0 switches the engine off.  Same bytes either way, at a size whose planes do not divide
+    into whole chunks or pieces, with and without the two Int64 screen planes, and equal to the oracle."""
+    sp, pl = pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    w, h = 2203, 1001                                           # 8.8 MB per plane: an 8-MB chunk and a ragged one; Int64 planes: 3 chunks
+    start = initial_planes(ora, w, h)
+    rng = np.random.default_rng(7)
+    start = tuple(rng.random((h, w), dtype=np.float32) for _ in range(3)) + tuple(start[3:])
+    sx, sy = pkg.world.screen_pixels(w, h)
+    flipped = (np.ascontiguousarray(sx[:, ::-1]), sy)
+    results = {}
+    for threads in ("0", "3", None):
+        if threads is None:
+            monkeypatch.delenv("PTMI_STAGE_THREADS", raising=False)
+        else:
+            monkeypatch.setenv("PTMI_STAGE_THREADS", threads)
+        with pkg.Context(0) as c:
+            c.set_scene(sp, pl)
+            one = c.render1(cam, 8, w, h, start)
+            two = c.render1(cam, 8, w, h, one, screen=flipped)
+            c.resize(w, h)
+            c.upload_state(*two)
+            back = c.download_state()
+            assert_planes_equal(back, two, "upload/download round trip, threads=%s" % threads)
+            c.render(cam, 8, 1)
+            three = c.download_state()
+            rgb, rgba = c.present(3)
+        results[threads] = (one, two, three, rgb, rgba)
+    want1, _ = ora.render_inline(sp, pl, cam, w, h, 8, 1, start)
+    want2, _ = ora.render_inline(sp, pl, cam, w, h, 8, 1, want1, screen=flipped)
+    want3, _ = ora.render_inline(sp, pl, cam, w, h, 8, 1, want2)
+    for threads, (one, two, three, rgb, rgba) in results.items():
+        assert_planes_equal(one, want1, "render1, threads=%s" % threads)
+        assert_planes_equal(two, want2, "render1 with screen planes, threads=%s" % threads)
+        assert_planes_equal(three, want3, "resident after upload, threads=%s" % threads)
+        assert np.array_equal(rgb, results["0"][3]) and np.array_equal(rgba, results["0"][4])
