@@ -44,6 +44,7 @@ import           Data.Word
 import           Foreign
 import           Foreign.C.String
 import           Foreign.C.Types
+import           GHC.Float                      ( castWord32ToFloat )
 import           Linear                         ( V3(..) )
 import           System.IO.Unsafe               ( unsafePerformIO )
 
@@ -71,7 +72,7 @@ instance Exception PtmiError
 foreign import ccall safe "ptmi.h ptmi_create"      c_create      :: Ptr (Ptr PtmiCtx) -> CInt -> IO CInt
 foreign import ccall safe "ptmi.h &ptmi_destroy"    p_destroy     :: FunPtr (Ptr PtmiCtx -> IO ())
 foreign import ccall safe "ptmi.h ptmi_last_error"  c_last_error  :: Ptr PtmiCtx -> IO CString
-foreign import ccall safe "ptmi.h ptmi_set_scene"   c_set_scene   :: Ptr PtmiCtx -> Ptr CFloat -> CInt -> Ptr CFloat -> CInt -> IO CInt
+foreign import ccall safe "ptmi.h ptmi_set_scene"   c_set_scene   :: Ptr PtmiCtx -> Ptr Float -> CInt -> Ptr Float -> CInt -> IO CInt
 foreign import ccall safe "ptmi.h ptmi_resize"      c_resize      :: Ptr PtmiCtx -> CInt -> CInt -> IO CInt
 foreign import ccall safe "ptmi.h ptmi_init_output" c_init_output :: Ptr PtmiCtx -> Word64 -> IO CInt
 foreign import ccall safe "ptmi.h ptmi_reseed"      c_reseed      :: Ptr PtmiCtx -> Word64 -> IO CInt
@@ -116,8 +117,9 @@ initialise device = alloca $ \pp -> do
   ctx <- peek pp
   fp  <- newForeignPtr p_destroy ctx
   let (spheres, planes) = mainScene'
-  withArrayLen (map realToFrac $ concatMap sphereWords spheres) $ \_ ps ->
-    withArrayLen (map realToFrac $ concatMap planeWords planes) $ \_ pp' ->
+  -- the records travel as raw 32-bit words (the BRDF tag is an int32 bit pattern in a float slot): no conversion
+  withArray (concatMap sphereWords spheres) $ \ps ->
+    withArray (concatMap planeWords planes) $ \pp' ->
       c_set_scene ctx ps (fromIntegral $ length spheres) pp' (fromIntegral $ length planes) >>= check ctx
   c_resize ctx (fromIntegral screenWidth) (fromIntegral screenHeight) >>= check ctx
   return (Handle fp)
