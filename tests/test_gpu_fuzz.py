@@ -4,13 +4,16 @@ plane normals, BRDF parameters outside their documented ranges, emissive everyth
 limits and sample counts -- device vs oracle, BIT-EXACT on all seven planes, for both algorithms.  Seeded:
 the same cases every run.  This is where a fast path that is only "almost always" equal to the literal
 fold, square root or sin/cos would show."""
+import os
+
 import numpy as np
 import pytest
 
 from conftest import assert_planes_equal, initial_planes
 
 pytestmark = pytest.mark.gpu
-N_CASES = 600
+N_CASES = int(os.environ.get("PTMI_FUZZ_CASES", "600"))        # a longer campaign: PTMI_FUZZ_CASES=30000 PTMI_FUZZ_SEED=...
+SEED = int(os.environ.get("PTMI_FUZZ_SEED", "20260101"))
 
 
 def random_case(pkg, r):
@@ -41,7 +44,7 @@ def random_case(pkg, r):
 
 
 def test_random_scenes_inline_and_streams(ctx, pkg, ora):
-    r = np.random.default_rng(20260101)
+    r = np.random.default_rng(SEED)
     checked = 0
     for case in range(N_CASES):
         spheres, planes, cam, w, h, limit, spp = random_case(pkg, r)
@@ -65,4 +68,77 @@ def test_random_scenes_inline_and_streams(ctx, pkg, ora):
                 want, _ = ora.render_streams(spheres, planes, cam, w, h, 1 << 16, spp, start)
             assert_planes_equal(got, want, "fuzz case %d streams" % case)
         checked += 1
+        if case % 5000 == 4999:
+            print("fuzz: %d cases" % (case + 1), flush=True)
     assert checked == N_CASES
+
+
+EXTREMES = np.array([0.0, -0.0, 1e-42, -1e-42, 1e-30, 1e30, -1e30, 3.4028235e38, np.inf, -np.inf, np.nan], np.float32)
+N_EXTREME = int(os.environ.get("PTMI_FUZZ_EXTREME_CASES", "300"))
+
+
+def poison(r, arr, rate):
+    """Replace a fraction of the float fields of a record array by zeros, denormals, huge values, infinities, NaN."""
+    for name in arr.dtype.names:
+        if arr.dtype[name].base == np.float32:
+            v = np.array(arr[name], np.float32).reshape(-1)
+            hit = r.random(v.size) < rate
+            v[hit] = r.choice(EXTREMES, int(hit.sum()))
+            arr[name] = v.reshape(np.shape(arr[name]))
+    return arr
+
+
+def assert_planes_equal_up_to_nan_payload(got, want, what):
+    """Bit-exact, except that any NaN equals any NaN (payload and sign of a NaN are not defined by the reference)."""
+    for k, (a, b) in enumerate(zip(got, want)):
+        ua, ub = np.asarray(a).reshape(-1).view(np.uint32), np.asarray(b).reshape(-1).view(np.uint32)
+        same = ua == ub
+        if k < 3:
+            same |= np.isnan(np.asarray(a).reshape(-1)) & np.isnan(np.asarray(b).reshape(-1))
+        if not same.all():
+            bad = np.flatnonzero(~same)
+            raise AssertionError("%s plane %d: %d of %d differ (first at %d: %#x vs %#x)" % (what, k, bad.size, ua.size, bad[0], ua[bad[0]], ub[bad[0]]))
+
+
+def test_random_scenes_with_non_finite_and_denormal_numbers(ctx, pkg, ora):
+    """The same campaign with zeros, signed zeros, denormals, 1e30-sized values, infinities and NaNs sprinkled over
+    the scene, the camera and the accumulated colour: every comparison and selection has to go the reference's way
+    (NaN keys in the fold, division by zero in the plane test, sqrt of negative and denormal numbers, sin/cos of
+    huge and non-finite angles).  Bit-exact up to NaN payloads."""
+    r = np.random.default_rng(SEED + 1)
+    for case in range(N_EXTREME):
+        spheres, planes, cam, w, h, limit, spp = random_case(pkg, r)
+        rate = float(r.choice([0.02, 0.1, 0.3]))
+        spheres, planes = poison(r, spheres, rate), poison(r, planes, rate)
+        if r.random() < 0.3:
+            cam = poison(r, np.array(cam, copy=True), 0.3)
+        start = list(initial_planes(ora, w, h, seed0=int(r.integers(0, 2 ** 63))))
+        if r.random() < 0.3:
+            for k in range(3):
+                v = start[k].reshape(-1).copy()
+                hit = r.random(v.size) < 0.05
+                v[hit] = r.choice(EXTREMES, int(hit.sum()))
+                start[k] = v.reshape(start[k].shape)
+        ctx.set_scene(spheres, planes)
+        ctx.resize(w, h)
+        ctx.upload_state(*start)
+        ctx.reset_stats()
+        ctx.render(cam, limit, spp, pkg.INLINE)
+        got = ctx.download_state()
+        live_gpu = ctx.stats()["live_bounces"]
+        with np.errstate(all="ignore"):
+            want, live = ora.render_inline(spheres, planes, cam, w, h, limit, spp, start)
+        what = "extreme case %d (%dx%d, %d+%d prims, limit %d, spp %d)" % (case, w, h, len(spheres), len(planes), limit, spp)
+        assert_planes_equal_up_to_nan_payload(got, want, what + " inline")
+        assert live_gpu == live, what
+        # Streams has no bounce limit (Trace.hs:166-170): a path whose throughput is NaN or infinite runs into the
+        # 65 536-step cap, so only small images go through it here (the oracle walks those steps on one thread)
+        if case % 3 == 0 and w * h * spp <= 150:
+            ctx.upload_state(*start)
+            ctx.render(cam, limit, spp, pkg.STREAMS)
+            got = ctx.download_state()
+            with np.errstate(all="ignore"):
+                want, _ = ora.render_streams(spheres, planes, cam, w, h, 1 << 16, spp, start)
+            assert_planes_equal_up_to_nan_payload(got, want, what + " streams")
+        if case % 500 == 499:
+            print("extreme fuzz: %d cases" % (case + 1), flush=True)
