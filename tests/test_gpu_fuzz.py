@@ -14,6 +14,7 @@ from conftest import assert_planes_equal, initial_planes
 pytestmark = pytest.mark.gpu
 N_CASES = int(os.environ.get("PTMI_FUZZ_CASES", "600"))        # a longer campaign: PTMI_FUZZ_CASES=30000 PTMI_FUZZ_SEED=...
 SEED = int(os.environ.get("PTMI_FUZZ_SEED", "20260101"))
+INLINE_VARIANTS = [0, 1, 0, 2, 0, 3, 0, 5, 0, 6, 0, 10, 0, 11, 0, 12]
 
 
 def random_case(pkg, r):
@@ -49,24 +50,33 @@ def test_random_scenes_inline_and_streams(ctx, pkg, ora):
     for case in range(N_CASES):
         spheres, planes, cam, w, h, limit, spp = random_case(pkg, r)
         start = initial_planes(ora, w, h, seed0=int(r.integers(0, 2 ** 63)))
+        variant = INLINE_VARIANTS[case % len(INLINE_VARIANTS)]     # half the cases on the default kernel, the rest spread over the others
         ctx.set_scene(spheres, planes)
         ctx.resize(w, h)
         ctx.upload_state(*start)
         ctx.reset_stats()
+        ctx.set_variant(variant)
         ctx.render(cam, limit, spp, pkg.INLINE)
+        ctx.set_variant(0)
         got = ctx.download_state()
         live_gpu = ctx.stats()["live_bounces"]
         with np.errstate(all="ignore"):
             want, live = ora.render_inline(spheres, planes, cam, w, h, limit, spp, start)
-        assert_planes_equal(got, want, "fuzz case %d inline (%dx%d, %d+%d prims, limit %d, spp %d)" % (case, w, h, len(spheres), len(planes), limit, spp))
+        assert_planes_equal(got, want, "fuzz case %d inline, variant %d (%dx%d, %d+%d prims, limit %d, spp %d)" % (case, variant, w, h, len(spheres), len(planes), limit, spp))
         assert live_gpu == live
         if case % 3 == 0:
             ctx.upload_state(*start)
+            stream_form = case % 2 == 1                            # the stream ("wavefront") form or the per-pixel form
+            ctx.set_variant(9 if stream_form else 0)
             ctx.render(cam, limit, spp, pkg.STREAMS)
+            ctx.set_variant(0)
             got = ctx.download_state()
             with np.errstate(all="ignore"):
-                want, _ = ora.render_streams(spheres, planes, cam, w, h, 1 << 16, spp, start)
-            assert_planes_equal(got, want, "fuzz case %d streams" % case)
+                if stream_form:                                    # `awhile` is capped at 64 steps there, 65 536 in the chain
+                    want = ora.render_streams_wavefront(spheres, planes, cam, w, h, 64, spp, start)[0]
+                else:
+                    want, _ = ora.render_streams(spheres, planes, cam, w, h, 1 << 16, spp, start)
+            assert_planes_equal(got, want, "fuzz case %d streams (%s)" % (case, "stream form" if stream_form else "per-pixel form"))
         checked += 1
         if case % 5000 == 4999:
             print("fuzz: %d cases" % (case + 1), flush=True)
