@@ -250,6 +250,31 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned int v)
     return s;
 }
 
+// Which pixel a lane of a one-wave workgroup works on.  TILE_W == 0: 64 consecutive pixels of a row (plane order).
+// TILE_W > 0: a TILE_W x (64 / TILE_W) tile of the image -- the 64 primary rays of a wave meet the same few
+// primitives and their paths have similar lengths, which is worth 1-2 % (8 x 8 measured best); the
+// seven plane accesses of a lane happen once per launch, so their shorter runs do not matter.
+template <int TILE_W>
+__device__ __forceinline__ bool lane_pixel(const RenderArgs &a, long long &pixel)
+{
+    if (TILE_W > 0) {
+        constexpr int tw = TILE_W > 0 ? TILE_W : 64, th = 64 / tw;
+        const int tiles_x = (a.width + tw - 1) / tw;
+        const int tx = (int)(blockIdx.x % (unsigned)tiles_x), ty = (int)(blockIdx.x / (unsigned)tiles_x);
+        const int x = tx * tw + (int)(threadIdx.x % tw), y = ty * th + (int)(threadIdx.x / tw);
+        pixel = (long long)y * a.width + x;
+        return x < a.width && y < a.rows_local;
+    }
+    pixel = (long long)blockIdx.x * kRenderBlock + threadIdx.x;
+    return pixel < (long long)a.rows_local * a.width;
+}
+
+__host__ inline unsigned int tile_grid(const RenderArgs &a, int tw)
+{
+    const int th = 64 / tw;
+    return (unsigned int)(((a.width + tw - 1) / tw) * ((a.rows_local + th - 1) / th));
+}
+
 // ---------------------------------------------------------------------------------------
 // render Inline.  LDS_SCENE: primitives staged in LDS (default) or read straight from
 // global memory through scalar loads (ablation).  MODE selects the loop shape:
@@ -259,7 +284,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned int v)
 // ---------------------------------------------------------------------------------------
 enum { kCached = 0, kRegenerate = 1, kLockstep = 2 };
 
-template <bool LDS_SCENE, int MODE>
+template <bool LDS_SCENE, int MODE, int TILE_W = 0>
 __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_inline_kernel(const RenderArgs a)
 {
     __shared__ float pixel_const[MODE == kCached ? 12 : 1][kRenderBlock];   // kCached: per-lane restart record (see below)
@@ -273,10 +298,10 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_
     const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
     const float4 *M = S + a.scene.geom_f4();
 
-    const long long n_local = (long long)a.rows_local * a.width;
-    const long long pixel = (long long)blockIdx.x * kRenderBlock + threadIdx.x;
+    long long pixel;
+    const bool valid = lane_pixel<TILE_W>(a, pixel);
     unsigned int live = 0;
-    if (pixel < n_local) {
+    if (valid) {
         const int local_row = (int)(pixel / a.width);
         const int col = (int)(pixel - (long long)local_row * a.width);
         int64_t px = col, py = global_row(local_row, a.stripe_rows, a.n_parts, a.part);
@@ -818,7 +843,7 @@ __global__ void __launch_bounds__(kRenderBlock) render_inline_persistent_kernel(
 // ---------------------------------------------------------------------------------------
 constexpr int kStreamsHardCap = 1 << 16;
 
-template <bool LDS_SCENE>
+template <bool LDS_SCENE, int TILE_W = 0>
 __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const RenderArgs a)
 {
     __shared__ float pixel_const[9][kRenderBlock];          // per-lane restart record, as in render_inline_kernel
@@ -832,10 +857,10 @@ __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const R
     const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
     const float4 *M = S + a.scene.geom_f4();
 
-    const long long n_local = (long long)a.rows_local * a.width;
-    const long long pixel = (long long)blockIdx.x * kRenderBlock + threadIdx.x;
+    long long pixel;
+    const bool valid = lane_pixel<TILE_W>(a, pixel);
     unsigned int live = 0, longest = 0;
-    if (pixel < n_local) {
+    if (valid) {
         const int local_row = (int)(pixel / a.width);
         const int col = (int)(pixel - (long long)local_row * a.width);
         const int64_t px = col, py = global_row(local_row, a.stripe_rows, a.n_parts, a.part);
@@ -1230,17 +1255,26 @@ inline unsigned int blocks_for(long long n, int block = kBlock) { return (unsign
 
 }  // namespace
 
+// 8x8 tiles leave lanes idle on the right and bottom edges; rows of 64 leave them idle at the end only
+bool tiles_pay(const RenderArgs &a) { return a.width >= 64 && a.rows_local >= 16; }
+
 hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t stream)
 {
     const long long n_local = (long long)a.rows_local * a.width;
     if (n_local <= 0) return hipSuccess;
     const dim3 grid(blocks_for(n_local, kRenderBlock)), block(kRenderBlock);
     const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
-    // variants: 0 auto | 1 persistent (LDS scene) | 2 lock step | 3 regenerate | 4 cached, static mapping (LDS scene)
+    // variants: 0 auto | 1 persistent (LDS scene) | 2 lock step | 3 regenerate | 4 cached, static row mapping (LDS scene)
     //           5 cached, static, scene through scalar loads | 6 persistent, scene through scalar loads
+    //           10-12 pooled second shade round | 13 = 4 with 8x8 pixel tiles per wave | 14-16 other tile shapes
+    //           17 = 5 with 8x8 tiles
     if (a.bounce_limit <= 0 || a.n_spp <= 0) variant = 2;   // degenerate counts: the plain loop handles them
-    if (variant == 0) variant = lds <= kMaxSceneLds ? 4 : 5;  // static mapping wins at every size measured;
-                                                             // a scene too big to keep 6 waves/SIMD in LDS is read through scalar loads
+    if (variant == 0) {
+        // static mapping wins at every size measured; a scene too big to keep 6 waves/SIMD in LDS is
+        // read through scalar loads; 8x8 tiles once the image is big enough for whole tiles to dominate
+        const bool tiles = tiles_pay(a);
+        variant = lds <= kMaxSceneLds ? (tiles ? 13 : 4) : (tiles ? 17 : 5);
+    }
     if (variant == 1 || variant == 6) {
         // persistent grid; more workgroups than fit would only start late and find the queue empty: cap at 8 per CU
         static int max_blocks = 0;
@@ -1256,6 +1290,19 @@ hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t st
         if (e != hipSuccess) return e;
         if (variant == 1) hipLaunchKernelGGL((render_inline_persistent_kernel<true>), dim3(blocks), block, lds, stream, a);
         else              hipLaunchKernelGGL((render_inline_persistent_kernel<false>), dim3(blocks), block, 0, stream, a);
+        return hipGetLastError();
+    }
+    if (variant == 17) {
+        hipLaunchKernelGGL((render_inline_kernel<false, kCached, 8>), dim3(tile_grid(a, 8)), block, 0, stream, a);
+        return hipGetLastError();
+    }
+    if (variant >= 13 && variant <= 16) {                     // pixel tiles per wave: 8x8 (default) / 16x4 / 4x16 / 32x2
+        const int tw = variant == 13 ? 8 : variant == 14 ? 16 : variant == 15 ? 4 : 32;
+        const dim3 tgrid(tile_grid(a, tw));
+        if (tw == 8)       hipLaunchKernelGGL((render_inline_kernel<true, kCached, 8>), tgrid, block, lds, stream, a);
+        else if (tw == 16) hipLaunchKernelGGL((render_inline_kernel<true, kCached, 16>), tgrid, block, lds, stream, a);
+        else if (tw == 4)  hipLaunchKernelGGL((render_inline_kernel<true, kCached, 4>), tgrid, block, lds, stream, a);
+        else               hipLaunchKernelGGL((render_inline_kernel<true, kCached, 32>), tgrid, block, lds, stream, a);
         return hipGetLastError();
     }
     if (variant >= 10 && variant <= 12) {                    // pooled second shade round, W = 2 / 4 / 8 waves per workgroup
@@ -1285,8 +1332,16 @@ hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t s
     const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
     hipError_t e = hipMemsetAsync(a.stream_iterations, 0, sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
-    if (variant == 5 || variant == 6 || lds > kMaxSceneLds) hipLaunchKernelGGL((render_streams_kernel<false>), grid, block, 0, stream, a);
-    else                              hipLaunchKernelGGL((render_streams_kernel<true>), grid, block, lds, stream, a);
+    const bool scalar_scene = variant == 5 || variant == 6 || variant == 17 || lds > kMaxSceneLds;
+    const bool tiles = variant == 4 || variant == 5 ? false : tiles_pay(a);      // 4 / 5 keep the row mapping (ablation)
+    if (tiles) {
+        const dim3 tgrid(tile_grid(a, 8));
+        if (scalar_scene) hipLaunchKernelGGL((render_streams_kernel<false, 8>), tgrid, block, 0, stream, a);
+        else              hipLaunchKernelGGL((render_streams_kernel<true, 8>), tgrid, block, lds, stream, a);
+    } else {
+        if (scalar_scene) hipLaunchKernelGGL((render_streams_kernel<false>), grid, block, 0, stream, a);
+        else              hipLaunchKernelGGL((render_streams_kernel<true>), grid, block, lds, stream, a);
+    }
     return hipGetLastError();
 }
 

@@ -14,7 +14,7 @@ from conftest import assert_planes_equal, initial_planes
 pytestmark = pytest.mark.gpu
 N_CASES = int(os.environ.get("PTMI_FUZZ_CASES", "600"))        # a longer campaign: PTMI_FUZZ_CASES=30000 PTMI_FUZZ_SEED=...
 SEED = int(os.environ.get("PTMI_FUZZ_SEED", "20260101"))
-INLINE_VARIANTS = [0, 1, 0, 2, 0, 3, 0, 5, 0, 6, 0, 10, 0, 11, 0, 12]
+INLINE_VARIANTS = [0, 1, 0, 2, 0, 3, 0, 5, 0, 6, 0, 10, 0, 11, 0, 12, 0, 4, 0, 13, 0, 17, 0, 14]
 
 
 def random_case(pkg, r):

@@ -43,10 +43,10 @@ def test_render_inline_matches_oracle(ctx, pkg, ora, w, h, limit, spp, scene_nam
     assert stats["nominal_bounces"] == w * h * spp * limit
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 10, 11, 12])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, 15, 16, 17])
 def test_every_kernel_variant_matches_oracle(pkg, ora, variant):
     """All loop shapes (persistent hand-out, lock step, regenerate, cached/static, LDS or scalar-load scene,
-    second shade round pooled over 2 / 4 / 8 waves)
+    second shade round pooled over 2 / 4 / 8 waves, 8x8 / 16x4 / 4x16 / 32x2 pixel tiles per wave)
     compute the same seven planes -- they differ only in how lanes are kept busy."""
     scene = pkg.world.scene16()
     cam = pkg.world.initial_camera()
