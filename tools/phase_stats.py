@@ -22,7 +22,7 @@ def main():
     with pkg.Context(0) as ctx:
         ctx.set_scene(sp, pl)
         ctx.resize(w, h)
-        ctx.set_variant(4)
+        ctx.set_variant(int(os.environ.get("PTMI_PHASE_VARIANT", "13")))     # 13 = the default (8x8 tiles); 4 = row segments
         ctx.init_output(0x5EED1234)
         ctx.reset_stats()
         ctx.render(pkg.world.initial_camera(), 8, spp)
@@ -46,7 +46,7 @@ def main():
     with pkg.Context(0) as ctx:
         ctx.set_scene(sp, pl)
         ctx.resize(w, h)
-        ctx.set_variant(4)
+        ctx.set_variant(int(os.environ.get("PTMI_PHASE_VARIANT", "13")))
         ctx.init_output(0x5EED1234)
         ctx.reset_stats()
         ctx.render(pkg.world.initial_camera(), 8, 8)
