@@ -28,7 +28,7 @@ def main():
         for r in csv.DictReader(open(f)):
             if "render_inline" in r["Kernel_Name"]:
                 durations.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-    out = {"kernel": "render_inline_kernel<true, kCached> (C2: 1920x1080, 64 spp, limit 8, S16), 64-thread workgroups, 6 waves/SIMD",
+    out = {"kernel": "render_inline_kernel<true, kCached, 8> (C2: 1920x1080, 64 spp, limit 8, S16), one wave per workgroup = an 8x8 pixel tile, 6 waves/SIMD",
            "counters_mean_per_launch": counters}
     if durations:
         out["kernel_trace_ms"] = {"n": len(durations), "mean": sum(durations) / len(durations), "min": min(durations)}
