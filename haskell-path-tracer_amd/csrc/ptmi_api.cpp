@@ -49,6 +49,14 @@ struct ptmi_ctx {
     int variant = 0;
     Stager stager;                          // pinned ring + worker threads for host-buffer entry points (ptmi_stage.h)
 
+    // cost-ordered dispatch of the tiled kernels: what every quad of tiles cost in the last launch with this key, and
+    // the order (most expensive first) later launches with the same key use.  order_state = launches made with this key
+    unsigned int *d_quad_cost = nullptr, *d_quad_order = nullptr;
+    unsigned int quad_capacity = 0;
+    int order_state = 0;
+    struct OrderKey { ptmi_camera cam; uint64_t scene_version; int dims[8]; } order_key{};
+    uint64_t scene_version = 0;
+
     // scratch for ptmi_render1 / point queries
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -278,6 +286,33 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
     a.stripe_rows = stripe_rows; a.n_parts = n_parts; a.part = part;
     a.bounce_limit = bounce_limit; a.n_spp = n_spp;
     a.live_counter = c->d_live; a.work_counter = c->d_work; a.stream_iterations = c->d_iters;
+    // Cost-ordered dispatch (ptmi_kernels.hip: lane_pixel): launches with one (camera, scene, shape, limit, algorithm)
+    // record what every quad of tiles costs; later launches with the same key dispatch the most expensive quads first
+    // (sorted on the device).  Everything is enqueued on the stream; results do not depend on it.
+    const bool per_pixel_kernel = algorithm == PTMI_INLINE || !(c->has_glass || c->variant == 9);
+    int next_order_state = c->order_state;
+    if (per_pixel_kernel && uses_quad_order(a, algorithm == PTMI_INLINE, c->variant)) {
+        const unsigned int n_quads = quad_positions(width, rows_local);
+        if (n_quads > c->quad_capacity) {
+            if (c->d_quad_cost) { PTMI_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_quad_cost); (void)hipFree(c->d_quad_order); }
+            c->d_quad_cost = c->d_quad_order = nullptr; c->quad_capacity = 0; c->order_state = 0;
+            PTMI_HIP(c, hipMalloc(&c->d_quad_cost, n_quads * sizeof(unsigned int)));
+            PTMI_HIP(c, hipMalloc(&c->d_quad_order, n_quads * sizeof(unsigned int)));
+            c->quad_capacity = n_quads;
+        }
+        ptmi_ctx::OrderKey key{};
+        key.cam = *camera; key.scene_version = c->scene_version;
+        const int dims[8] = {width, height, rows_local, stripe_rows, n_parts, part, bounce_limit, algorithm};
+        std::memcpy(key.dims, dims, sizeof dims);
+        if (std::memcmp(&key, &c->order_key, sizeof key) != 0) { c->order_key = key; c->order_state = 0; }
+        // order_state counts the launches made with this key.  Every launch adds its costs (a 1-spp launch says little
+        // on its own: the compat entry renders one sample per call); the order is rebuilt before launch 1, 2, 4, 8, ...
+        const int launches = c->order_state;
+        if (launches == 0) PTMI_HIP(c, hipMemsetAsync(c->d_quad_cost, 0, n_quads * sizeof(unsigned int), c->stream));
+        else if ((launches & (launches - 1)) == 0 && launches < (1 << 20)) PTMI_HIP(c, launch_quad_order(c->d_quad_cost, c->d_quad_order, n_quads, c->stream));
+        if (launches > 0) a.quad_order = c->d_quad_order;
+        if (launches < (1 << 20)) { a.quad_cost = c->d_quad_cost; next_order_state = launches + 1; }   // the sums stay far from 2^32
+    }
     if (c->timing) { PTMI_HIP(c, hipEventRecord(c->ev0, c->stream)); }
     if (algorithm == PTMI_INLINE) {
         PTMI_HIP(c, launch_render_inline(a, c->variant, c->stream));
@@ -287,6 +322,7 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
         PTMI_HIP(c, launch_render_streams(a, c->variant, c->stream));
     }
     if (c->timing) { PTMI_HIP(c, hipEventRecord(c->ev1, c->stream)); c->ev_valid = true; }
+    c->order_state = next_order_state;
     const uint64_t px = (uint64_t)rows_local * (uint64_t)width;
     c->samples += px * (uint64_t)(n_spp > 0 ? n_spp : 0);
     c->nominal += px * (uint64_t)(n_spp > 0 ? n_spp : 0) * (uint64_t)(bounce_limit > 0 ? bounce_limit : 0);
@@ -376,6 +412,8 @@ void ptmi_destroy(ptmi_ctx *c)
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->queue_block) (void)hipFree(c->queue_block);
     if (c->d_qcount) (void)hipFree(c->d_qcount);
+    if (c->d_quad_cost) (void)hipFree(c->d_quad_cost);
+    if (c->d_quad_order) (void)hipFree(c->d_quad_order);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -406,6 +444,7 @@ int ptmi_set_scene(ptmi_ctx *c, const ptmi_sphere *spheres, int n_spheres, const
     PTMI_HIP(c, hipMemcpyAsync(c->d_scene, packed.data(), packed.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));               // `packed` dies at return
     c->n_spheres = n_spheres; c->n_planes = n_planes;
+    ++c->scene_version;
     c->has_glass = false;
     for (int i = 0; i < n_spheres; ++i) c->has_glass |= spheres[i].brdf_tag == PTMI_GLASS;
     for (int j = 0; j < n_planes; ++j) c->has_glass |= planes[j].brdf_tag == PTMI_GLASS;

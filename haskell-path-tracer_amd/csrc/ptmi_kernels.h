@@ -36,6 +36,11 @@ struct RenderArgs {
     unsigned long long *live_counter;     // device counter, += live bounces
     unsigned int *work_counter;           // device counter for dynamic pixel hand-out (variants)
     unsigned int *stream_iterations;      // Streams: steps taken by the last sample (max over waves)
+    // Cost-ordered dispatch of the tiled kernels (see lane_pixel in ptmi_kernels.hip).  A "quad" is a run of four
+    // x-adjacent 8x8 tiles.  quad_order: the quad each dispatch position works on (NULL = image order).
+    // quad_cost: where each wave adds the loop trips it paid (NULL = do not record).
+    const unsigned int *quad_order;
+    unsigned int *quad_cost;
 };
 
 // Ray stream of the wavefront Streams path: struct-of-arrays, `capacity` rays (type RayState, Trace.hs:46)
@@ -63,6 +68,9 @@ hipError_t launch_streams_update_seed(Planes p, long long n, int draws, hipStrea
 
 hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t stream);
 hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t stream);
+unsigned int quad_positions(int width, int rows_local);                    // entries of quad_order / quad_cost (0 = tiles not used)
+hipError_t launch_quad_order(const unsigned int *cost, unsigned int *order, unsigned int n, hipStream_t stream);
+bool uses_quad_order(const RenderArgs &a, int algorithm_inline, int variant);
 hipError_t launch_seed(Planes p, int width, int rows_local, int stripe_rows, int n_parts, int part,
                        uint64_t seed0, bool clear_color, hipStream_t stream);
 hipError_t launch_create_with(Planes p, const uint32_t *w0, const uint32_t *w1, const uint32_t *w2,

@@ -255,17 +255,26 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned int v)
 // primitives and their paths have similar lengths, which is worth 1-2 % (8 x 8 measured best); the
 // seven plane accesses of a lane happen once per launch, so their shorter runs do not matter.
 template <int TILE_W>
-__device__ __forceinline__ bool lane_pixel(const RenderArgs &a, long long &pixel)
+__device__ __forceinline__ bool lane_pixel(const RenderArgs &a, long long &pixel, unsigned int &quad)
 {
+    quad = 0;
     if (TILE_W > 0) {
         constexpr int tw = TILE_W > 0 ? TILE_W : 64, th = 64 / tw;
         const int tiles_x = (a.width + tw - 1) / tw;
         // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  A tile row segment is only tw * 4
         // bytes of a 128-byte line, so x-adjacent tiles must meet in ONE L2 or the line is fetched from HBM once per
-        // tile (measured: 232 MB instead of 58 MB per launch): runs of 4 consecutive tiles go to the same XCD, as
-        // consecutive workgroups of that XCD.  The grid is padded to a multiple of 32 so that this is a bijection.
+        // tile (measured: 232 MB instead of 58 MB per launch): runs of 4 consecutive tiles ("quads") go to the same
+        // XCD, as consecutive workgroups of that XCD.  The grid is padded to a multiple of 32 so that this is a bijection.
+        // Which quad a dispatch position gets is the image order, or -- once a launch with the same camera has recorded
+        // what every quad costs -- the most expensive first (quad_order), which shortens the end of the kernel where
+        // the last waves run with the chip half empty.
         const unsigned int xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
-        const unsigned int tile = (((k >> 2) * 8u + xcd) << 2) + (k & 3u);
+        const unsigned int position = (k >> 2) * 8u + xcd;
+        quad = a.quad_order ? a.quad_order[position] : position;
+#if defined(PTMI_TILE_REVERSE)
+        if (!a.quad_order) quad = (gridDim.x >> 2) - 1u - position;   // experiment: bottom of the image first
+#endif
+        const unsigned int tile = (quad << 2) + (k & 3u);
         const int tx = (int)(tile % (unsigned)tiles_x), ty = (int)(tile / (unsigned)tiles_x);
         const int x = tx * tw + (int)(threadIdx.x % tw), y = ty * th + (int)(threadIdx.x / tw);
         pixel = (long long)y * a.width + x;
@@ -273,6 +282,14 @@ __device__ __forceinline__ bool lane_pixel(const RenderArgs &a, long long &pixel
     }
     pixel = (long long)blockIdx.x * kRenderBlock + threadIdx.x;
     return pixel < (long long)a.rows_local * a.width;
+}
+
+// what the wave paid: the loop trips of its slowest lane, added to its quad's cost
+__device__ __forceinline__ void record_cost(const RenderArgs &a, unsigned int quad, unsigned int trips)
+{
+    if (!a.quad_cost) return;
+    for (int off = 32; off > 0; off >>= 1) { const unsigned int other = __shfl_xor(trips, off, 64); trips = other > trips ? other : trips; }
+    if ((threadIdx.x & 63) == 0) atomicAdd(a.quad_cost + quad, trips + 1u);
 }
 
 __host__ inline unsigned int tile_grid(const RenderArgs &a, int tw)
@@ -306,7 +323,8 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_
     const float4 *M = S + a.scene.geom_f4();
 
     long long pixel;
-    const bool valid = lane_pixel<TILE_W>(a, pixel);
+    unsigned int quad, trips = 0;
+    const bool valid = lane_pixel<TILE_W>(a, pixel, quad);
     unsigned int live = 0;
     if (valid) {
         const int local_row = (int)(pixel / a.width);
@@ -371,6 +389,7 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_
                 unsigned long long cyc_a = 0, cyc_b = 0, cyc_c = 0;
 #endif
                 while (pending) {
+                    ++trips;
 #ifdef PTMI_PHASE_STATS
                     ++st_iter;
                     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
@@ -476,6 +495,7 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_
         a.planes.sc[pixel] = seed.c; a.planes.sctr[pixel] = seed.counter;
     }
 
+    if (TILE_W > 0) record_cost(a, quad, trips);
     if (a.live_counter) {
         const unsigned long long total = wave_sum(live);
         if ((threadIdx.x & 63) == 0 && total) atomicAdd(a.live_counter, total);
@@ -865,7 +885,8 @@ __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const R
     const float4 *M = S + a.scene.geom_f4();
 
     long long pixel;
-    const bool valid = lane_pixel<TILE_W>(a, pixel);
+    unsigned int quad, trips = 0;
+    const bool valid = lane_pixel<TILE_W>(a, pixel, quad);
     unsigned int live = 0, longest = 0;
     if (valid) {
         const int local_row = (int)(pixel / a.width);
@@ -908,6 +929,7 @@ __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const R
                 pending = s < n_spp;
             };
             while (pending) {
+                ++trips;
                 for (int round = 0; round < 2; ++round) {
                     if (pending && !has_ray) {
                         const bool dying = near_zero(throughput) || steps + 1u >= (unsigned int)kStreamsHardCap;
@@ -935,6 +957,7 @@ __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const R
         a.planes.sa[pixel] = pixel_seed.a; a.planes.sb[pixel] = pixel_seed.b;
         a.planes.sc[pixel] = pixel_seed.c; a.planes.sctr[pixel] = pixel_seed.counter;
     }
+    if (TILE_W > 0) record_cost(a, quad, trips);
     if (a.live_counter) {
         const unsigned long long total = wave_sum(live);
         if ((threadIdx.x & 63) == 0 && total) atomicAdd(a.live_counter, total);
@@ -1263,7 +1286,55 @@ inline unsigned int blocks_for(long long n, int block = kBlock) { return (unsign
 }  // namespace
 
 // 8x8 tiles leave lanes idle on the right and bottom edges; rows of 64 leave them idle at the end only
-bool tiles_pay(const RenderArgs &a) { return a.width >= 64 && a.rows_local >= 16; }
+static bool tiles_pay_dims(int width, int rows_local) { return width >= 64 && rows_local >= 16; }
+bool tiles_pay(const RenderArgs &a) { return tiles_pay_dims(a.width, a.rows_local); }
+
+unsigned int quad_positions(int width, int rows_local)
+{
+    if (!tiles_pay_dims(width, rows_local)) return 0;
+    const unsigned int tiles = (unsigned int)(((width + 7) / 8) * ((rows_local + 7) / 8));
+    return ((tiles + 31u) & ~31u) / 4u;
+}
+
+// the default (variant 0 = auto) takes the cost order; the explicit variants, 13 and 17 included, keep the image order
+bool uses_quad_order(const RenderArgs &a, int algorithm_inline, int variant)
+{
+    if (variant != 0 || !tiles_pay(a) || a.screen_x) return false;
+    return algorithm_inline ? (a.bounce_limit > 0 && a.n_spp > 0) : true;
+}
+
+namespace {
+// Quads by decreasing recorded cost, in 256 cost classes (order inside a class does not matter): one workgroup,
+// LDS histogram, scan, scatter.  n is a few thousand to a few ten thousand.
+__global__ void __launch_bounds__(1024) quad_order_kernel(const unsigned int *cost, unsigned int *order, unsigned int n)
+{
+    __shared__ unsigned int hist[256], start[256], top;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) top = 1;
+    __syncthreads();
+    unsigned int mine = 0;
+    for (unsigned int i = threadIdx.x; i < n; i += 1024) mine = cost[i] > mine ? cost[i] : mine;
+    atomicMax(&top, mine);
+    __syncthreads();
+    const unsigned long long scale = top;
+    auto bin = [&](unsigned int c) { return 255u - (unsigned int)(((unsigned long long)c * 255ull) / scale); };   // 0 = most expensive
+    for (unsigned int i = threadIdx.x; i < n; i += 1024) atomicAdd(&hist[bin(cost[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int run = 0;
+        for (int b = 0; b < 256; ++b) { start[b] = run; run += hist[b]; }
+    }
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i < n; i += 1024) order[atomicAdd(&start[bin(cost[i])], 1u)] = i;
+}
+}  // namespace
+
+hipError_t launch_quad_order(const unsigned int *cost, unsigned int *order, unsigned int n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(quad_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n);
+    return hipGetLastError();
+}
 
 hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t stream)
 {

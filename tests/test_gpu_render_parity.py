@@ -79,3 +79,37 @@ def test_non_finite_inputs_take_the_literal_fold(ctx, pkg, ora):
         assert np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
     for a, b in zip(got[3:], want[3:]):
         assert np.array_equal(a, b)          # the RNG planes carry no floating point
+
+
+def test_cost_ordered_dispatch_changes_nothing_but_the_order(pkg, ora):
+    """The tiled kernels record what every quad of tiles costs in the first launch with a given camera, sort the quads
+    on the device in the second and dispatch the most expensive first from then on.  Planes must not
+    notice: five launches with one camera, a camera change, back again, a scene change, both algorithms."""
+    sp, pl = pkg.world.scene16()
+    cam1 = pkg.world.initial_camera()
+    cam2 = pkg.world.camera((1.0, 2.0, 3.0), (0.1, -0.2, 0.4), 70)
+    w, h, limit = 200, 120, 8
+    for algorithm, ref in ((pkg.INLINE, ora.render_inline), (pkg.STREAMS, None)):
+        start = initial_planes(ora, w, h)
+        with pkg.Context(0) as c:
+            c.set_scene(sp, pl)
+            c.resize(w, h)
+            c.upload_state(*start)
+            want = start
+            schedule = [(cam1, 2), (cam1, 1), (cam1, 3), (cam1, 1), (cam1, 2), (cam2, 2), (cam2, 2), (cam2, 1), (cam1, 1), (cam1, 2)]
+            for k, (cam, spp) in enumerate(schedule):
+                c.render(cam, limit, spp, algorithm)
+                if algorithm == pkg.INLINE:
+                    want, _ = ora.render_inline(sp, pl, cam, w, h, limit, spp, want)
+                else:
+                    want, _ = ora.render_streams(sp, pl, cam, w, h, 1 << 16, spp, want)
+                assert_planes_equal(c.download_state(), want, "launch %d" % k)
+            sp2, pl2 = pkg.world.main_scene()
+            c.set_scene(sp2, pl2)
+            for k in range(3):
+                c.render(cam1, limit, 2, algorithm)
+                if algorithm == pkg.INLINE:
+                    want, _ = ora.render_inline(sp2, pl2, cam1, w, h, limit, 2, want)
+                else:
+                    want, _ = ora.render_streams(sp2, pl2, cam1, w, h, 1 << 16, 2, want)
+                assert_planes_equal(c.download_state(), want, "after the scene change, launch %d" % k)
