@@ -190,25 +190,35 @@ __device__ __forceinline__ float gen_component(Sfc32 &seed)
 // calcNextRay's direction part (Trace.hs:394-429): the three draws, the rotated direction `next` and the BRDF
 // factor `b`.  Both BRDF arms are evaluated through selects so that Matte and Glossy lanes of one wave do not
 // serialise.  M points at the material records.
+//   Matte:  rotate (anglesToQuaternion $ pi *^ rv) iNormal
+//   Glossy: rotate (anglesToQuaternion $ (1 - p) *^ rv) reflection
+// anglesToQuaternion halves every angle; (k * rv) * 0.5 == (0.5 k) * rv bit for bit (power-of-two scaling).
+__device__ __forceinline__ void bounce_axis(float4 mb, V3 normal, V3 d, V3 &axis, float &hk)
+{
+    const bool matte = f2u(mb.x) == 0u;
+    const float ia = dot(d, normal);
+    const V3 reflection = d - scale_l(2.0f * ia, normal);
+    axis = matte ? normal : reflection;
+    hk = matte ? 0.5f * kPi : mb.w;       // mb.w = 0.5 * (1 - p)  (Trace.hs:424 and Util.hs:62-67), exact halving
+}
+
+__device__ __forceinline__ void next_about_axis(float4 mb, V3 axis, float hk, Sfc32 &seed, V3 &next, float &brdf)
+{
+    const bool matte = f2u(mb.x) == 0u;
+    V3 rv;
+    rv.x = gen_component(seed); rv.y = gen_component(seed); rv.z = gen_component(seed);
+    next = rotate(quaternion_from_half_angles(hk * rv.x, hk * rv.y, hk * rv.z), axis);
+    const float nd = dot(next, axis);
+    brdf = matte ? mb.z * nd : __builtin_fmaxf(0.0f, nd);      // mb.z = p / pi (Trace.hs:411), divided at upload
+}
+
 template <typename ScenePtr>
 __device__ __forceinline__ void next_direction(ScenePtr M, int idx, V3 normal, V3 d, Sfc32 &seed, V3 &next, float &brdf)
 {
     const float4 mb = M[2 * idx + 1];
-    const bool matte = f2u(mb.x) == 0u;
-    const float p_over_pi = mb.z;          // p / pi            (Trace.hs:411), divided at upload
-    const float half_k_glossy = mb.w;      // 0.5 * (1 - p)     (Trace.hs:424 and Util.hs:62-67), exact halving
-    V3 rv;
-    rv.x = gen_component(seed); rv.y = gen_component(seed); rv.z = gen_component(seed);
-    // Matte:  rotate (anglesToQuaternion $ pi *^ rv) iNormal
-    // Glossy: rotate (anglesToQuaternion $ (1 - p) *^ rv) reflection
-    // anglesToQuaternion halves every angle; (k * rv) * 0.5 == (0.5 k) * rv bit for bit (power-of-two scaling).
-    const float ia = dot(d, normal);
-    const V3 reflection = d - scale_l(2.0f * ia, normal);
-    const V3 axis = matte ? normal : reflection;
-    const float hk = matte ? 0.5f * kPi : half_k_glossy;
-    next = rotate(quaternion_from_half_angles(hk * rv.x, hk * rv.y, hk * rv.z), axis);
-    const float nd = dot(next, axis);
-    brdf = matte ? p_over_pi * nd : __builtin_fmaxf(0.0f, nd);
+    V3 axis; float hk;
+    bounce_axis(mb, normal, d, axis, hk);
+    next_about_axis(mb, axis, hk, seed, next, brdf);
 }
 
 // The rest of calcNextRay (Trace.hs:431-435) and computeRay (Trace.hs:374-383) once `next` and `b` are known.
@@ -236,6 +246,25 @@ __device__ __forceinline__ void shade(ScenePtr M, int idx, V3 hit_pos, V3 normal
     V3 next; float brdf;
     next_direction(M, idx, normal, d, seed, next, brdf);
     apply_bounce(M, idx, hit_pos, next, brdf, o, d, throughput, result);
+}
+
+// The first shade of a sample that starts from the pixel's cached primary hit: result = 0, throughput = 1 and the
+// incoming ray is the primary ray, so the rotation axis, the half angle scale and 0 + emittance * 1 are per-pixel
+// constants (evaluated once, by the same operations), and throughput * tmod = 1 * tmod = tmod.
+// ACCUMULATE (render Streams): `result` is the pixel's accumulator and first_term = emittance * 1 is added to it;
+// otherwise (render Inline) first_term = 0 + emittance * 1 is the sample's result so far.
+template <bool ACCUMULATE, typename ScenePtr>
+__device__ __forceinline__ void shade_first(ScenePtr M, int idx, V3 hit_pos, V3 axis, float hk, V3 first_term,
+                                            V3 &o, V3 &d, V3 &throughput, V3 &result, Sfc32 &seed)
+{
+    const float4 ma = M[2 * idx], mb = M[2 * idx + 1];
+    V3 next; float brdf;
+    next_about_axis(mb, axis, hk, seed, next, brdf);
+    constexpr float next_ray_prob = 1.0f / (kPi * 2.0f);
+    o = hit_pos + scale_r(next, kEpsilon);
+    d = next;
+    result = ACCUMULATE ? result + first_term : first_term;
+    throughput = scale_r(mk(ma.x, ma.y, ma.z), brdf * next_ray_prob);
 }
 
 __device__ __forceinline__ int global_row(int local_row, int stripe_rows, int n_parts, int part)
@@ -311,7 +340,7 @@ enum { kCached = 0, kRegenerate = 1, kLockstep = 2 };
 template <bool LDS_SCENE, int MODE, int TILE_W = 0>
 __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_inline_kernel(const RenderArgs a)
 {
-    __shared__ float pixel_const[MODE == kCached ? 12 : 1][kRenderBlock];   // kCached: per-lane restart record (see below)
+    __shared__ float pixel_const[MODE == kCached ? 19 : 1][kRenderBlock];   // kCached: per-lane restart record (see below)
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -369,6 +398,14 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_
                 put(6, primary.x); put(7, primary.y); put(8, primary.z);
                 put(9, acc.x); put(10, acc.y); put(11, acc.z);        // the accumulator is touched once per sample: LDS too
                 const int idx0 = h0.idx;
+                {   // what every first shade of this pixel uses (shade_first)
+                    const float4 ma0 = M[2 * idx0], mb0 = M[2 * idx0 + 1];
+                    V3 axis; float hk;
+                    bounce_axis(mb0, normal, primary, axis, hk);
+                    const V3 first_result = mk(0.0f, 0.0f, 0.0f) + (scale_r(mk(ma0.x, ma0.y, ma0.z), ma0.w) * mk(1.0f, 1.0f, 1.0f));
+                    put(12, axis.x); put(13, axis.y); put(14, axis.z); put(15, hk);
+                    put(16, first_result.x); put(17, first_result.y); put(18, first_result.z);
+                }
                 int s = 0, it = 0, idx = idx0;
                 V3 d = primary;                                       // the ray that produced the hit / the next ray
                 V3 throughput = mk(1.0f, 1.0f, 1.0f), result = mk(0.0f, 0.0f, 0.0f);
@@ -394,21 +431,35 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_
                     ++st_iter;
                     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
 #endif
-                    for (int round = 0; round < 2; ++round) {
-                        if (pending && !has_ray) {
+                    // round A: whatever hit is pending
+                    if (pending && !has_ray) {
 #ifdef PTMI_PHASE_STATS
-                            if (round == 0) ++st_a; else ++st_b;
+                        ++st_a;
 #endif
-                            shade(M, idx, pos, normal, pos, d, throughput, result, seed);
-                            ++it; ++live;
-                            // the next prepareRay would freeze the path (Trace.hs:364-365)
-                            if (it >= limit || near_zero(throughput)) restart();
-                            else { pending = false; has_ray = true; }
-                        }
-#ifdef PTMI_PHASE_STATS
-                        { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); (round == 0 ? cyc_a : cyc_b) += t_now - t_prev; t_prev = t_now; }
-#endif
+                        shade(M, idx, pos, normal, pos, d, throughput, result, seed);
+                        ++it; ++live;
+                        // the next prepareRay would freeze the path (Trace.hs:364-365)
+                        if (it >= limit || near_zero(throughput)) restart();
+                        else { pending = false; has_ray = true; }
                     }
+#ifdef PTMI_PHASE_STATS
+                    { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); cyc_a += t_now - t_prev; t_prev = t_now; }
+#endif
+                    // round B: only lanes that restarted in round A get here with a pending hit, and that hit is the
+                    // cached primary hit with result 0 and throughput 1: the specialised first shade
+                    if (pending && !has_ray) {
+#ifdef PTMI_PHASE_STATS
+                        ++st_b;
+#endif
+                        shade_first<false>(M, idx0, pos, mk(get(12), get(13), get(14)), get(15), mk(get(16), get(17), get(18)),
+                                    pos, d, throughput, result, seed);
+                        ++it; ++live;
+                        if (it >= limit || near_zero(throughput)) restart();
+                        else { pending = false; has_ray = true; }
+                    }
+#ifdef PTMI_PHASE_STATS
+                    { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); cyc_b += t_now - t_prev; t_prev = t_now; }
+#endif
 #ifdef PTMI_PHASE_STATS
                     if (has_ray) ++st_c;
 #endif
@@ -873,7 +924,7 @@ constexpr int kStreamsHardCap = 1 << 16;
 template <bool LDS_SCENE, int TILE_W = 0>
 __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const RenderArgs a)
 {
-    __shared__ float pixel_const[9][kRenderBlock];          // per-lane restart record, as in render_inline_kernel
+    __shared__ float pixel_const[16][kRenderBlock];         // per-lane restart record, as in render_inline_kernel
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -913,6 +964,14 @@ __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const R
             put(3, normal.x); put(4, normal.y); put(5, normal.z);
             put(6, primary.x); put(7, primary.y); put(8, primary.z);
             const int idx0 = h0.idx;
+            {   // what every first shade of this pixel uses (shade_first)
+                const float4 ma0 = M[2 * idx0], mb0 = M[2 * idx0 + 1];
+                V3 axis; float hk;
+                bounce_axis(mb0, normal, primary, axis, hk);
+                const V3 first_term = scale_r(mk(ma0.x, ma0.y, ma0.z), ma0.w) * mk(1.0f, 1.0f, 1.0f);
+                put(9, axis.x); put(10, axis.y); put(11, axis.z); put(12, hk);
+                put(13, first_term.x); put(14, first_term.y); put(15, first_term.z);
+            }
             int s = 0, idx = idx0;
             unsigned int steps = 0;
             V3 d = primary;
@@ -930,15 +989,23 @@ __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const R
             };
             while (pending) {
                 ++trips;
-                for (int round = 0; round < 2; ++round) {
-                    if (pending && !has_ray) {
-                        const bool dying = near_zero(throughput) || steps + 1u >= (unsigned int)kStreamsHardCap;
-                        // results: colour += emittance * throughput for EVERY hit; then the new ray (if any)
-                        shade(M, idx, pos, normal, pos, d, throughput, acc, seed);
-                        ++steps;
-                        if (dying) { end_sample(); }
-                        else { ++live; pending = false; has_ray = true; }
-                    }
+                // round A: whatever hit is pending
+                if (pending && !has_ray) {
+                    const bool dying = near_zero(throughput) || steps + 1u >= (unsigned int)kStreamsHardCap;
+                    // results: colour += emittance * throughput for EVERY hit; then the new ray (if any)
+                    shade(M, idx, pos, normal, pos, d, throughput, acc, seed);
+                    ++steps;
+                    if (dying) { end_sample(); }
+                    else { ++live; pending = false; has_ray = true; }
+                }
+                // round B: only lanes whose sample ended in round A; their hit is the cached primary hit and their
+                // throughput is 1 (never near zero): the specialised first shade
+                if (pending && !has_ray) {
+                    shade_first<true>(M, idx0, pos, mk(get(9), get(10), get(11)), get(12), mk(get(13), get(14), get(15)),
+                                      pos, d, throughput, acc, seed);
+                    ++steps;
+                    if (steps >= (unsigned int)kStreamsHardCap) { end_sample(); }
+                    else { ++live; pending = false; has_ray = true; }
                 }
                 if (has_ray) {
                     const HitSel h = check_hit(S, ns, np, pos, d);
