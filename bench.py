@@ -75,6 +75,24 @@ def load_traffic():
         return None
 
 
+def load_valu_accounting(kernel_ms):
+    """The VALU side of the story (the kernel's real bound), from the committed PMC summary of this workload:
+    wave-instructions per launch and active lanes per instruction are properties of the code, not of the run; the
+    issue rate they imply is computed with THIS run's kernel time.  None if the profile is missing."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)["derived"]
+        instr = float(d["valu_wave_instr_per_launch"])
+        simd_cycles = 1024 * kernel_ms * 1e-3 * 2.4e9            # 256 CUs x 4 SIMDs at the 2.4 GHz the SQ counters show
+        return {"wave_instr_per_launch": round(instr), "active_lanes_per_instr": round(float(d["avg_active_lanes_per_valu_instr"]), 2),
+                "simd_cycles_per_instr": round(simd_cycles / instr, 3),
+                "note": "measured issue cost of the mix: 2 cycles (f32 add/mul, int) to 4 (fma, f64, cmp, cndmask, cvt) -- the VALU pipes are saturated",
+                "source": "profiles/r01_pmc_summary.json"}
+    except Exception:
+        return None
+
+
 def main():
     global WIDTH, HEIGHT, SPP_PER_GPU
     ap = argparse.ArgumentParser()
@@ -236,7 +254,8 @@ def main():
                          "traffic": load_traffic() if (world == 1 and is_c2) else None,
                          "kernel": "render_inline_kernel", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "HBM is the bound BASELINE.json names; the kernel is f32/f64 VALU-bound (DESIGN.md)"},
+                         "note": "HBM is the bound BASELINE.json names; the kernel is f32/f64 VALU-bound (DESIGN.md)",
+                         "valu": load_valu_accounting(kernel_ms) if (world == 1 and is_c2) else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, spheres, planes, cam)
