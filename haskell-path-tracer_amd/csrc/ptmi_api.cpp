@@ -51,7 +51,7 @@ struct ptmi_ctx {
 
     // cost-ordered dispatch of the tiled kernels: what every quad of tiles cost in the last launch with this key, and
     // the order (most expensive first) later launches with the same key use.  order_state = launches made with this key
-    unsigned int *d_quad_cost = nullptr, *d_quad_order = nullptr;
+    unsigned int *d_quad_cost = nullptr, *d_quad_order = nullptr, *d_quad_class = nullptr;
     unsigned int quad_capacity = 0;
     int order_state = 0;
     struct OrderKey { ptmi_camera cam; uint64_t scene_version; int dims[8]; } order_key{};
@@ -294,10 +294,11 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
     if (per_pixel_kernel && uses_quad_order(a, algorithm == PTMI_INLINE, c->variant)) {
         const unsigned int n_quads = quad_positions(width, rows_local);
         if (n_quads > c->quad_capacity) {
-            if (c->d_quad_cost) { PTMI_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_quad_cost); (void)hipFree(c->d_quad_order); }
-            c->d_quad_cost = c->d_quad_order = nullptr; c->quad_capacity = 0; c->order_state = 0;
+            if (c->d_quad_cost) { PTMI_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_quad_cost); (void)hipFree(c->d_quad_order); (void)hipFree(c->d_quad_class); }
+            c->d_quad_cost = c->d_quad_order = c->d_quad_class = nullptr; c->quad_capacity = 0; c->order_state = 0;
             PTMI_HIP(c, hipMalloc(&c->d_quad_cost, n_quads * sizeof(unsigned int)));
             PTMI_HIP(c, hipMalloc(&c->d_quad_order, n_quads * sizeof(unsigned int)));
+            PTMI_HIP(c, hipMalloc(&c->d_quad_class, n_quads * sizeof(unsigned int)));
             c->quad_capacity = n_quads;
         }
         ptmi_ctx::OrderKey key{};
@@ -309,7 +310,7 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
         // on its own: the compat entry renders one sample per call); the order is rebuilt before launch 1, 2, 4, 8, ...
         const int launches = c->order_state;
         if (launches == 0) PTMI_HIP(c, hipMemsetAsync(c->d_quad_cost, 0, n_quads * sizeof(unsigned int), c->stream));
-        else if ((launches & (launches - 1)) == 0 && launches < (1 << 20)) PTMI_HIP(c, launch_quad_order(c->d_quad_cost, c->d_quad_order, n_quads, c->stream));
+        else if ((launches & (launches - 1)) == 0 && launches < (1 << 20)) PTMI_HIP(c, launch_quad_order(c->d_quad_cost, c->d_quad_order, c->d_quad_class, n_quads, c->stream));
         if (launches > 0) a.quad_order = c->d_quad_order;
         if (launches < (1 << 20)) { a.quad_cost = c->d_quad_cost; next_order_state = launches + 1; }   // the sums stay far from 2^32
     }
@@ -414,6 +415,7 @@ void ptmi_destroy(ptmi_ctx *c)
     if (c->d_qcount) (void)hipFree(c->d_qcount);
     if (c->d_quad_cost) (void)hipFree(c->d_quad_cost);
     if (c->d_quad_order) (void)hipFree(c->d_quad_order);
+    if (c->d_quad_class) (void)hipFree(c->d_quad_class);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

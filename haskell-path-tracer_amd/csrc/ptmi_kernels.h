@@ -69,7 +69,7 @@ hipError_t launch_streams_update_seed(Planes p, long long n, int draws, hipStrea
 hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t stream);
 hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t stream);
 unsigned int quad_positions(int width, int rows_local);                    // entries of quad_order / quad_cost (0 = tiles not used)
-hipError_t launch_quad_order(const unsigned int *cost, unsigned int *order, unsigned int n, hipStream_t stream);
+hipError_t launch_quad_order(const unsigned int *cost, unsigned int *order, unsigned int *cls, unsigned int n, hipStream_t stream);
 bool uses_quad_order(const RenderArgs &a, int algorithm_inline, int variant);
 hipError_t launch_seed(Planes p, int width, int rows_local, int stripe_rows, int n_parts, int part,
                        uint64_t seed0, bool clear_color, hipStream_t stream);

@@ -1372,34 +1372,38 @@ bool uses_quad_order(const RenderArgs &a, int algorithm_inline, int variant)
 
 namespace {
 // Quads by decreasing recorded cost, in 256 cost classes (order inside a class does not matter): one workgroup,
-// LDS histogram, scan, scatter.  n is a few thousand to a few ten thousand.
-__global__ void __launch_bounds__(1024) quad_order_kernel(const unsigned int *cost, unsigned int *order, unsigned int n)
+// LDS histogram, scan, scatter.  n is a few thousand to a few ten thousand.  Every cost is read ONCE and its class
+// kept in `cls`, so the result is a permutation even if somebody were still adding to the costs.
+__global__ void __launch_bounds__(1024) quad_order_kernel(const unsigned int *cost, unsigned int *order, unsigned int *cls, unsigned int n)
 {
     __shared__ unsigned int hist[256], start[256], top;
     if (threadIdx.x < 256) hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) top = 1;
     __syncthreads();
     unsigned int mine = 0;
-    for (unsigned int i = threadIdx.x; i < n; i += 1024) mine = cost[i] > mine ? cost[i] : mine;
+    for (unsigned int i = threadIdx.x; i < n; i += 1024) { const unsigned int c = cost[i]; cls[i] = c; mine = c > mine ? c : mine; }
     atomicMax(&top, mine);
     __syncthreads();
     const unsigned long long scale = top;
-    auto bin = [&](unsigned int c) { return 255u - (unsigned int)(((unsigned long long)c * 255ull) / scale); };   // 0 = most expensive
-    for (unsigned int i = threadIdx.x; i < n; i += 1024) atomicAdd(&hist[bin(cost[i])], 1u);
+    for (unsigned int i = threadIdx.x; i < n; i += 1024) {                 // a thread revisits only its own elements
+        const unsigned int b = 255u - (unsigned int)(((unsigned long long)cls[i] * 255ull) / scale);   // 0 = most expensive
+        cls[i] = b;
+        atomicAdd(&hist[b], 1u);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int run = 0;
         for (int b = 0; b < 256; ++b) { start[b] = run; run += hist[b]; }
     }
     __syncthreads();
-    for (unsigned int i = threadIdx.x; i < n; i += 1024) order[atomicAdd(&start[bin(cost[i])], 1u)] = i;
+    for (unsigned int i = threadIdx.x; i < n; i += 1024) order[atomicAdd(&start[cls[i]], 1u)] = i;
 }
 }  // namespace
 
-hipError_t launch_quad_order(const unsigned int *cost, unsigned int *order, unsigned int n, hipStream_t stream)
+hipError_t launch_quad_order(const unsigned int *cost, unsigned int *order, unsigned int *cls, unsigned int n, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(quad_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n);
+    hipLaunchKernelGGL(quad_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, cls, n);
     return hipGetLastError();
 }
 
