@@ -56,7 +56,11 @@ def test_random_scenes_inline_and_streams(ctx, pkg, ora):
         ctx.upload_state(*start)
         ctx.reset_stats()
         ctx.set_variant(variant)
-        ctx.render(cam, limit, spp, pkg.INLINE)
+        if case % 4 == 0 and spp >= 2:                             # two launches: the second runs in the cost order the first recorded
+            ctx.render(cam, limit, 1, pkg.INLINE)
+            ctx.render(cam, limit, spp - 1, pkg.INLINE)
+        else:
+            ctx.render(cam, limit, spp, pkg.INLINE)
         ctx.set_variant(0)
         got = ctx.download_state()
         live_gpu = ctx.stats()["live_bounces"]
