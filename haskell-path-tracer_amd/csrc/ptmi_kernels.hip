@@ -1102,7 +1102,7 @@ __global__ void __launch_bounds__(kBlock) streams_init_kernel(const RenderArgs a
 }
 
 template <bool LDS_SCENE>
-__global__ void __launch_bounds__(kBlock) streams_step_kernel(const RenderArgs a, const RayQueue in, const StreamLayout layout,
+__global__ void __launch_bounds__(kBlock, 6) streams_step_kernel(const RenderArgs a, const RayQueue in, const StreamLayout layout,
                                                               const RayQueue out, unsigned int *counters)
 {
     extern __shared__ float4 lds_scene[];
