@@ -1,21 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path (BASELINE.json: Msamples/s, paths x bounces).
 
-A step = one pass of `render Inline` over the C2 workload: 1920x1080 pixels PER GPU of the
-16-primitive scene, bounce limit 8, 64 samples per pixel.  With N GPUs the image is 1920 x (1080*N),
-row-stripe partitioned over the N ranks, so every rank launches exactly the N = 1 kernel shape
-(per-GPU work fixed: weak scaling; `--weak spp` scales the sample count instead), followed by the
-RCCL gather of the colour planes to rank 0, which overlaps the next step's render.
-Inputs (state planes, scene) are resident in HBM before the timed region starts.
+A step = one pass of `render Inline` over one batch of synthetic input, state resident in HBM.
+
+  N = 1 (default)        C2 = BASELINE.json configs[1]: 1920x1080, 64 spp, bounce limit 8, scene S16.
+  N > 1 (default)        STRONG scaling on C4 = configs[3]: ONE fixed 3840x2160 image at 1024 spp, row stripes
+                         dealt round-robin to the N ranks, RCCL gather of the colour planes to rank 0 every step
+                         (overlapping the next step's render).  `--scaling strong --gpus 1` runs C4 on one GPU.
+  --scaling weak         the round-1 mode: every rank renders 1920x1080 pixels x 64 spp of a 1920 x (1080 N)
+                         image (`--weak spp` grows the sample count instead).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (render_inline_kernel)
-against HBM as BASELINE.json asks, with algorithmic bytes = 56 B per pixel-sample
-(SURVEY.md 8d); `cpu_baseline` times the CPU oracle (a port of the reference's -fcpu path,
-the real Accelerate build is not runnable) on the host cores, on a bounded sample.
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM as BASELINE.json asks, with
+ALGORITHMIC bytes = 56 B per pixel-sample (what one `render` call per sample would move); because the
+sample loop lives inside the kernel the PHYSICAL traffic is 56 B per pixel per launch, reported beside it
+(`physical_*`), and the kernel's real bound -- VALU issue -- is priced in `roofline.valu`.  `cpu_baseline` times the
+CPU oracle (a port of the reference's -fcpu path; the real Accelerate build is not runnable) on the host cores the
+process may use, on a bounded sample of the same image.
 """
 import argparse
 import json
@@ -28,88 +32,138 @@ sys.path.insert(0, ROOT)
 
 import __graft_entry__ as graft  # noqa: E402
 
-WIDTH, HEIGHT, SPP_PER_GPU, BOUNCE_LIMIT = 1920, 1080, 64, 8
 SEED0 = 0x5EED1234
+BOUNCE_LIMIT = 8
+C2 = dict(name="C2", width=1920, height=1080, spp=64)          # BASELINE.json configs[1]
+C4 = dict(name="C4", width=3840, height=2160, spp=1024)        # BASELINE.json configs[3]
 with open(os.path.join(ROOT, "BASELINE.json")) as _f:
     METRIC = json.load(_f)["metric"]
 BYTES_PER_PIXEL_SAMPLE = 56.0        # 2 x (3 x f32 + 4 x u32): read + write of one `render` call
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 
 
-def cpu_baseline(pkg, spheres, planes, cam, budget_s=15.0):
-    """Time the oracle (OpenMP over rows, all host cores) on a bounded sample of the same workload."""
+def usable_cores():
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota."""
+    affinity = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2
+            q, period = f.read().split()
+            if q != "max":
+                quota = float(q) / float(period)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:      # cgroup v1
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = float(f.read())
+            if q > 0:
+                quota = q / period
+        except Exception:
+            pass
+    cores = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
+    return cores, affinity, quota
+
+
+def cpu_baseline(pkg, spheres, planes, cam, width, height, budget_s=12.0):
+    """Time the oracle (OpenMP over rows) on a bounded sample of the SAME image the GPU step renders:
+    every row for the threaded figure, every 4th row of the same image for the single-thread figure."""
     import numpy as np
     ora = graft.load_oracle()
     ora.build()
-    threads = ora.max_threads()
-    seeds = ora.gen_seeds(SEED0, 0, WIDTH * HEIGHT)
-    start = [np.zeros((HEIGHT, WIDTH), np.float32) for _ in range(3)] + [s.reshape(HEIGHT, WIDTH) for s in seeds]
+    cores, affinity, quota = usable_cores()
+    omp_max = ora.max_threads()
+    seeds = ora.gen_seeds(SEED0, 0, width * height)
+    start = [np.zeros((height, width), np.float32) for _ in range(3)] + [s.reshape(height, width) for s in seeds]
     t0 = time.perf_counter()
-    ora.render_inline(spheres, planes, cam, WIDTH, HEIGHT, BOUNCE_LIMIT, 1, start, n_threads=threads)
+    ora.render_inline(spheres, planes, cam, width, height, BOUNCE_LIMIT, 1, start, n_threads=cores)
     t1 = time.perf_counter() - t0
-    spp = max(1, min(4 * SPP_PER_GPU, int(budget_s / max(t1, 1e-3))))
+    spp = max(1, min(256, int(budget_s / max(t1, 1e-3))))
     t0 = time.perf_counter()
-    _, live = ora.render_inline(spheres, planes, cam, WIDTH, HEIGHT, BOUNCE_LIMIT, spp, start, n_threads=threads)
+    _, live = ora.render_inline(spheres, planes, cam, width, height, BOUNCE_LIMIT, spp, start, n_threads=cores)
     dt = time.perf_counter() - t0
-    nominal = WIDTH * HEIGHT * spp * BOUNCE_LIMIT
-    # per-core figure: a quarter of the rows, one sample, one thread (a few seconds)
-    q = max(1, HEIGHT // 4)
+    nominal = width * height * spp * BOUNCE_LIMIT
+    # per-core figure: rows 0, 4, 8, ... of the same image (same camera, same rays), one thread
+    rows = np.arange(0, height, 4, dtype=np.int32)
+    band = [a[rows] for a in start]
+    spp1 = 2
     t0 = time.perf_counter()
-    ora.render_inline(spheres, planes, cam, WIDTH, q, BOUNCE_LIMIT, 1, [a[:q] for a in start], n_threads=1)
-    one = WIDTH * q * BOUNCE_LIMIT / (time.perf_counter() - t0) / 1e6
-    return {"value": round(nominal / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "single_thread_value": round(one, 3),
-            "sample": "%dx%d, scene S16, limit %d, %d spp (the GPU step is %d), %.1f s, C oracle (oracle/pt_oracle.c) with OpenMP"
-                      % (WIDTH, HEIGHT, BOUNCE_LIMIT, spp, SPP_PER_GPU, dt),
+    ora.render_inline(spheres, planes, cam, width, height, BOUNCE_LIMIT, spp1, band, n_threads=1, rows=rows)
+    one = width * len(rows) * spp1 * BOUNCE_LIMIT / (time.perf_counter() - t0) / 1e6
+    value = nominal / dt / 1e6
+    return {"value": round(value, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "single_thread_value": round(one, 3), "parallel_speedup": round(value / one, 2),
+            "affinity_cpus": affinity, "cgroup_cpu_quota": quota, "omp_get_max_threads": omp_max,
+            "sample": "%dx%d, scene S16, limit %d, %d spp (the GPU step is the same image), %.1f s, C oracle "
+                      "(oracle/pt_oracle.c) with OpenMP dynamic row chunks on %d threads; single-thread figure on "
+                      "every 4th row of the same image, %d spp" % (width, height, BOUNCE_LIMIT, spp, dt, cores, spp1),
             "live_fraction": round(live / nominal, 4)}
 
 
+def load_json(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
 def load_traffic():
-    """HBM bytes per launch from the committed PMC profile of this workload, if any (else null)."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+    """HBM bytes per launch of the C2 kernel from the committed PMC profile (profiles/traffic.json), else None."""
+    t = load_json("traffic.json")
+    return t.get("hbm_bytes_per_launch") if t else None
+
+
+def valu_accounting(kernel_ms):
+    """The kernel's real bound.  The instruction mix is a property of the code and the workload, not of the run:
+    profiles/r02_valu_roofline.json holds, for the C2 launch, the VALU wave-instructions per launch (PMC), the issue
+    cycles the measured per-opcode costs (tools/valu_rates.hip) assign to that mix, and the active-lane fraction.
+    frac = the cycles the issued instruction mix needs at one instruction stream per SIMD / the SIMD cycles this run's
+    launch took."""
+    d = load_json("r02_valu_roofline.json")
+    if not d:
+        return None
     try:
-        with open(path) as f:
-            t = json.load(f)
-        return t.get("hbm_bytes_per_launch")
+        clock_hz = float(d["clock_ghz"]) * 1e9
+        measured = d["n_simds"] * kernel_ms * 1e-3 * clock_hz
+        return {"min_issue_cycles": round(d["min_issue_cycles"]), "measured_cycles": round(measured),
+                "frac": round(d["min_issue_cycles"] / measured, 4),
+                "active_lane_frac": round(d["active_lane_frac"], 4),
+                "valu_wave_instr_per_launch": round(d["valu_wave_instr_per_launch"]),
+                "avg_issue_cycles_per_instr": round(d["avg_issue_cycles_per_instr"], 3),
+                "clock_ghz": d["clock_ghz"], "source": "profiles/r02_valu_roofline.json"}
     except Exception:
         return None
 
 
-def load_valu_accounting(kernel_ms):
-    """The VALU side of the story (the kernel's real bound), from the committed PMC summary of this workload:
-    wave-instructions per launch and active lanes per instruction are properties of the code, not of the run; the
-    issue rate they imply is computed with THIS run's kernel time.  None if the profile is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)["derived"]
-        instr = float(d["valu_wave_instr_per_launch"])
-        simd_cycles = 1024 * kernel_ms * 1e-3 * 2.4e9            # 256 CUs x 4 SIMDs at the 2.4 GHz the SQ counters show
-        return {"wave_instr_per_launch": round(instr), "active_lanes_per_instr": round(float(d["avg_active_lanes_per_valu_instr"]), 2),
-                "simd_cycles_per_instr": round(simd_cycles / instr, 3),
-                "note": "measured issue cost of the mix: 2 cycles (f32 add/mul, int) to 4 (fma, f64, cmp, cndmask, cvt) -- the VALU pipes are saturated",
-                "source": "profiles/r01_pmc_summary.json"}
-    except Exception:
-        return None
+def pick_stripe(height, world):
+    """Stripe height that deals every rank the same number of rows, closest to the 8-row tile of the kernel."""
+    for s in (8, 10, 6, 12, 5, 4, 15, 16, 3, 2, 1):
+        if height % (s * world) == 0:
+            return s
+    return 8
 
 
 def main():
-    global WIDTH, HEIGHT, SPP_PER_GPU
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto",
+                    help="auto: C2 on one GPU, strong scaling on C4 when --gpus > 1")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (DESIGN.md); 0 = default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--stripe-rows", type=int, default=0, help="0 = largest stripe <= 8 rows that deals every rank the same number of rows")
-    ap.add_argument("--width", type=int, default=WIDTH, help="experiments only: the headline number is the default C2 workload")
-    ap.add_argument("--height", type=int, default=HEIGHT)
-    ap.add_argument("--spp", type=int, default=SPP_PER_GPU)
+    ap.add_argument("--no-n1-reference", action="store_true", help="strong scaling: skip the one-GPU timing of the same image on rank 0")
+    ap.add_argument("--stripe-rows", type=int, default=0, help="0 = a stripe that deals every rank the same number of rows")
+    ap.add_argument("--width", type=int, default=0, help="experiments only: the headline numbers are the default workloads")
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--scene", choices=["s16", "main", "glass"], default="s16")
     ap.add_argument("--algorithm", choices=["inline", "streams"], default="inline")
-    ap.add_argument("--weak", choices=["rows", "spp"], default="rows", help="what grows with the GPU count")
+    ap.add_argument("--weak", choices=["rows", "spp"], default="rows", help="weak scaling: what grows with the GPU count")
+    ap.add_argument("--streams-form", choices=["auto", "stream"], default="auto",
+                    help="render Streams: per-pixel kernels (auto) or the stream ('wavefront') form")
     args = ap.parse_args()
-    WIDTH, HEIGHT, SPP_PER_GPU = args.width, args.height, args.spp
 
     import torch
     import torch.distributed as dist
@@ -122,6 +176,16 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libptmi has no CPU path")
+
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
+    base = C4 if scaling == "strong" else C2
+    width, height, spp_base = args.width or base["width"], args.height or base["height"], args.spp or base["spp"]
+    named = (width, height, spp_base, args.scene, args.algorithm) == (base["width"], base["height"], base["spp"], "s16", "inline")
+    if args.steps is None:
+        args.steps = 50 if scaling == "weak" else 8          # a C4 step is ~230 ms on one GPU
+    if args.warmup is None:
+        args.warmup = 10 if scaling == "weak" else 2
+
     # Rehearsal on a one-GPU box (never the measured path): all ranks share cuda:0 and talk over gloo.
     rehearsal = os.environ.get("PTMI_BENCH_REHEARSAL") == "1"
     if rehearsal:
@@ -142,21 +206,24 @@ def main():
     spheres, planes = {"s16": pkg.world.scene16, "main": pkg.world.main_scene, "glass": pkg.world.glass_scene}[args.scene]()
     algorithm = pkg.INLINE if args.algorithm == "inline" else pkg.STREAMS
     cam = pkg.world.initial_camera()
-    spp = SPP_PER_GPU * (world if args.weak == "spp" else 1)
-    if args.weak == "rows":
-        HEIGHT = HEIGHT * world                      # 1080 rows per GPU
+    spp = spp_base
+    if scaling == "weak":
+        if args.weak == "spp":
+            spp = spp_base * world
+        else:
+            height = height * world                  # `height` rows per GPU
 
     if args.stripe_rows <= 0:
-        args.stripe_rows = next((s for s in range(8, 0, -1) if HEIGHT % (s * world) == 0), 8)
+        args.stripe_rows = pick_stripe(height, world)
     ctx = pkg.Context(local_rank)
     ctx.set_scene(spheres, planes)
-    part = StripePartition(HEIGHT, world, rank, args.stripe_rows)
+    part = StripePartition(height, world, rank, args.stripe_rows)
     if world > 1:
         ctx.set_partition(args.stripe_rows, world, rank)
-    ctx.resize(WIDTH, HEIGHT)
+    ctx.resize(width, height)
     assert ctx.local_rows == part.local_rows
-    color = torch.zeros((3, ctx.local_rows, WIDTH), dtype=torch.float32, device="cuda")
-    state = torch.zeros((4, ctx.local_rows, WIDTH), dtype=torch.int32, device="cuda")
+    color = torch.zeros((3, ctx.local_rows, width), dtype=torch.float32, device="cuda")
+    state = torch.zeros((4, ctx.local_rows, width), dtype=torch.int32, device="cuda")
     ctx.bind_torch(color, state)
     # One side stream carries the kernels, the torch events that time them and the RCCL gather
     # (the legacy NULL stream would make ptmi fall back to its own stream: include/ptmi.h).
@@ -166,9 +233,11 @@ def main():
     assert stream.cuda_stream != 0
     ctx.set_stream(stream.cuda_stream)
     ctx.set_variant(args.variant)
+    if args.streams_form == "stream":
+        ctx.set_option(pkg.binding.OPT_STREAMS_FORM, pkg.binding.FORM_STREAM)
     ctx.init_output(SEED0)
 
-    gather = ColorGatherer(part, WIDTH, color.dtype, color.device, dst=0) if world > 1 else None
+    gather = ColorGatherer(part, width, color.dtype, color.device, dst=0) if world > 1 else None
 
     def step():
         ctx.render(cam, BOUNCE_LIMIT, spp, algorithm)
@@ -186,7 +255,7 @@ def main():
     # whatever their values.  State is re-initialised afterwards.
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < 0.3:
-        ctx.render(cam, BOUNCE_LIMIT, spp, algorithm)
+        ctx.render(cam, BOUNCE_LIMIT, min(spp, 64), algorithm)
         torch.cuda.synchronize()
     if world > 1:
         gather.overlapped(color)                     # first collective = communicator set-up; not a warm-up step
@@ -223,42 +292,78 @@ def main():
     else:
         live_total = stats["live_bounces"]
 
-    is_c2 = (WIDTH, HEIGHT // (world if args.weak == "rows" else 1), SPP_PER_GPU, args.scene, args.algorithm) == (1920, 1080, 64, "s16", "inline")
+    # Strong scaling: the same whole image on ONE GPU (rank 0 alone, outside the timed region), so that the line
+    # carries the one-GPU time of exactly this workload next to the N-GPU time.
+    n1_ms = None
+    if scaling == "strong" and world > 1 and rank == 0 and not args.no_n1_reference:
+        with pkg.Context(local_rank) as whole:
+            whole.set_scene(spheres, planes)
+            whole.resize(width, height)
+            whole.set_stream(stream.cuda_stream)
+            whole.set_variant(args.variant)
+            whole.init_output(SEED0)
+            times = []
+            for _ in range(3):                       # the second and third run in the recorded cost order
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                whole.render(cam, BOUNCE_LIMIT, spp, algorithm)
+                torch.cuda.synchronize()
+                times.append((time.perf_counter() - t1) * 1e3)
+            n1_ms = min(times)
+    if world > 1:
+        dist.barrier()
+
     if rank == 0:
-        nominal_per_step = WIDTH * HEIGHT * spp * BOUNCE_LIMIT          # whole job, all ranks
+        nominal_per_step = width * height * spp * BOUNCE_LIMIT          # whole job, all ranks
         value = nominal_per_step * args.steps / elapsed / 1e6
         # dominant kernel, per launch on one GPU: pixels held x spp x 56 B / launch duration
-        alg_bytes = ctx.local_rows * WIDTH * spp * BYTES_PER_PIXEL_SAMPLE
+        alg_bytes = ctx.local_rows * width * spp * BYTES_PER_PIXEL_SAMPLE
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        is_c2 = named and scaling == "weak" and world == 1
+        traffic = load_traffic() if is_c2 else None
+        if scaling == "strong":
+            workload = "%s: ONE %dx%d image at %d spp, row-striped over %d GPU(s) (strong scaling)" % (
+                base["name"] if named else "experiment", width, height, spp, world)
+        else:
+            workload = ("C2" if world == 1 else "C2 per GPU (1920x1080 pixels each, weak scaling by %s)" % args.weak) if named else "experiment"
+            workload += ": %dx%d image, %d spp per step" % (width, height, spp)
+        kernel_name = "render_inline_kernel" if args.algorithm == "inline" else \
+            ("streams_level_kernel (stream form)" if args.streams_form == "stream" else
+             ("render_streams_tree_kernel" if args.scene == "glass" else "render_streams_kernel"))
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4),
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "achieved_is": "ALGORITHMIC-equivalent GB/s: 56 B per pixel-sample, what one `render` call per sample "
+                                   "would move (SURVEY.md 8d); the fused sample loop moves 56 B per pixel per LAUNCH",
+                    "physical_GBps": round(traffic / (kernel_ms * 1e-3) / 1e9, 2) if traffic and kernel_ms > 0 else None,
+                    "physical_frac": round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and kernel_ms > 0 else None,
+                    "real_bound": "valu",
+                    "valu": valu_accounting(kernel_ms) if is_c2 else None}
         out = {
             "metric": METRIC,
             "value": round(value, 1), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %dx%d image, %d spp per step, bounce limit 8, scene %s "
-                                   "(%d spheres + %d planes), render %s, seeds from seed0=0x5EED1234"
-                                   % (("C2" if world == 1 else "C2 per GPU (1920x1080 pixels each, weak scaling by %s)" % args.weak) if is_c2 else "experiment",
-                                      WIDTH, HEIGHT, spp, args.scene.upper(),
-                                      len(spheres), len(planes), args.algorithm.capitalize()),
-                       "width": WIDTH, "height": HEIGHT, "spp_per_step": spp, "bounce_limit": BOUNCE_LIMIT,
+            "config": {"workload": "%s, bounce limit %d, scene %s (%d spheres + %d planes), render %s, seeds from seed0=0x5EED1234"
+                                   % (workload, BOUNCE_LIMIT, args.scene.upper(), len(spheres), len(planes), args.algorithm.capitalize()),
+                       "width": width, "height": height, "spp_per_step": spp, "bounce_limit": BOUNCE_LIMIT,
                        "primitives": int(len(spheres) + len(planes)),
                        "parallelism": "row stripes of %d rows over %d GPU(s)%s"
                                       % (args.stripe_rows, world, " + RCCL gather of colour planes" if world > 1 else ""),
-                       "variant": args.variant},
-            "live_bounce_fraction": round(live_total / (nominal_per_step * args.steps), 4),
+                       "rows_per_gpu": ctx.local_rows, "variant": args.variant},
+            "live_bounce_fraction": round(live_total / (nominal_per_step * args.steps), 4) if args.algorithm == "inline" else None,
             "live_Mbounces_per_s": round(live_total / elapsed / 1e6, 1),
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": load_traffic() if (world == 1 and is_c2) else None,
-                         "kernel": "render_inline_kernel", "kernel_ms": round(kernel_ms, 4),
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "HBM is the bound BASELINE.json names; the kernel is f32/f64 VALU-bound (DESIGN.md)",
-                         "valu": load_valu_accounting(kernel_ms) if (world == 1 and is_c2) else None},
+            "roofline": roofline,
         }
+        if n1_ms is not None:
+            out["one_gpu_same_workload"] = {"ms_per_step": round(n1_ms, 3),
+                                            "value": round(nominal_per_step / (n1_ms * 1e-3) / 1e6, 1),
+                                            "note": "the whole image on rank 0's GPU alone, best of 3, outside the timed region"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, spheres, planes, cam)
+            out["cpu_baseline"] = cpu_baseline(pkg, spheres, planes, cam, width, height)
         print(json.dumps(out), flush=True)
 
     ctx.close()

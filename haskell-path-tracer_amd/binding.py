@@ -13,6 +13,9 @@ import numpy as np
 from . import _build
 from .world import CAMERA_DTYPE, PLANE_DTYPE, SPHERE_DTYPE, INLINE, STREAMS
 
+OPT_STREAMS_SEED_RULE, OPT_STREAM_STEP_CAP, OPT_STREAM_CAPACITY, OPT_STREAMS_FORM = 1, 2, 3, 4
+SEED_KEEP_ACCUMULATOR, SEED_FROM_RESULT = 0, 1
+FORM_AUTO, FORM_STREAM = 0, 1
 PTMI_OK, PTMI_EINVAL, PTMI_ENODEVICE, PTMI_EHIP, PTMI_ENOMEM, PTMI_ESTATE, PTMI_ELIMIT = 0, -1, -2, -3, -4, -5, -6
 
 # every symbol include/ptmi.h declares: name -> (restype, argtypes)
@@ -22,7 +25,8 @@ _f32p, _u32p, _i32p, _i64p, _vp = (C.POINTER(C.c_float), C.POINTER(C.c_uint32), 
 
 class Stats(C.Structure):
     _fields_ = [("live_bounces", C.c_uint64), ("nominal_bounces", C.c_uint64), ("samples", C.c_uint64),
-                ("last_render_ms", C.c_float), ("stream_iterations", C.c_uint32), ("stream_rays_dropped", C.c_uint64)]
+                ("last_render_ms", C.c_float), ("stream_iterations", C.c_uint32), ("stream_rays_dropped", C.c_uint64),
+                ("stream_rays_truncated", C.c_uint64)]
 
 
 SYMBOLS = {
@@ -40,6 +44,8 @@ SYMBOLS = {
     "ptmi_set_stream": (C.c_int, [_vp, _vp]),
     "ptmi_set_timing": (C.c_int, [_vp, C.c_int]),
     "ptmi_set_variant": (C.c_int, [_vp, C.c_int]),
+    "ptmi_set_option": (C.c_int, [_vp, C.c_int, C.c_int64]),
+    "ptmi_get_option": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64)]),
     "ptmi_init_output": (C.c_int, [_vp, C.c_uint64]),
     "ptmi_reseed": (C.c_int, [_vp, C.c_uint64]),
     "ptmi_create_with": (C.c_int, [_vp, _vp, _vp, _vp]),
@@ -187,6 +193,14 @@ class Context:
 
     def set_variant(self, variant):
         self._check(self._lib.ptmi_set_variant(self._h, int(variant)))
+
+    def set_option(self, option, value):
+        self._check(self._lib.ptmi_set_option(self._h, int(option), C.c_int64(int(value))))
+
+    def get_option(self, option):
+        v = C.c_int64(0)
+        self._check(self._lib.ptmi_get_option(self._h, int(option), C.byref(v)))
+        return int(v.value)
 
     # -- state -----------------------------------------------------------------------
     def init_output(self, seed0):

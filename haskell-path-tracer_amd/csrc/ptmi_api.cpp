@@ -67,7 +67,15 @@ struct ptmi_ctx {
     size_t queue_capacity = 0;
     unsigned int *d_qcount = nullptr;
     uint64_t rays_dropped = 0;
+    uint64_t rays_truncated = 0;
     uint64_t live_host = 0;        // live rays counted on the host (wavefront path)
+    unsigned long long *d_stream_counters = nullptr;   // kScWords device counters of the per-pixel Streams kernels
+
+    // options of render Streams (ptmi_set_option)
+    int opt_seed_rule = PTMI_SEED_KEEP_ACCUMULATOR;
+    int opt_step_cap = kStreamStepCapDefault;
+    int opt_capacity = 4;
+    int opt_form = PTMI_FORM_AUTO;
 };
 
 namespace {
@@ -197,8 +205,8 @@ void pack_scene(const ptmi_sphere *sph, int ns, const ptmi_plane *pl, int np, st
     for (int j = 0; j < np; ++j) mat(pl[j].color, pl[j].illuminance, pl[j].brdf_tag, pl[j].brdf_param);
 }
 
-constexpr int kStreamCapacityFactor = 4;     // next stream holds at most 4 rays per pixel-sample; excess children are dropped and counted
-constexpr int kStreamBatch = 4;              // samples that share one stream when the scene holds GLASS
+constexpr size_t kStreamQueueBudget = 8ull << 30;   // bytes the two ray streams may take together (of 288 GB)
+constexpr int kStreamBatchMax = 16;                 // samples of every pixel that share one stream when rays can split
 
 RayQueue carve_queue(void *block, size_t capacity, int which)
 {
@@ -212,62 +220,110 @@ RayQueue carve_queue(void *block, size_t capacity, int which)
     return q;
 }
 
-// `render Streams` as a stream: awhile (Trace.hs:142-150) on the host, one traceStep launch per iteration, the
-// length of the next stream read back after every step (that read-back is the loop's predicate, `null state`).
+// `render Streams` as a stream: awhile (Trace.hs:142-150) on the host, one launch per LEVEL of the ray tree
+// (streams_level_kernel).  The predicate `null state` is the next stream's length, which lives on the device: the first
+// batch reads it back after every level; later batches launch as many levels as the previous batch needed (+1), each
+// reading its input length from device memory, and read the counters back ONCE per batch -- if the last level still
+// emitted rays the loop simply goes on level by level.  Without GLASS nothing is ever emitted (one child per hit stays in
+// its lane) and a batch is one sample, so that a pixel's additions happen in sample order (bit-identical to the
+// per-pixel kernel); with GLASS the order is undefined anyway and up to 16 samples share a stream.
 int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
 {
     const size_t n = (size_t)a.rows_local * a.width;
     if (n == 0 || n_spp <= 0) return PTMI_OK;
-    // With GLASS the order of a pixel's additions is undefined anyway (several rays per pixel and launch), so up to
-    // kStreamBatch samples share one stream: fewer, larger launches and read-backs.  Without GLASS one sample per
-    // stream keeps the additions in sample order, i.e. bit-identical to the per-pixel kernel.
-    const int batch_max = c->has_glass ? (n * kStreamBatch * kStreamCapacityFactor <= 0xffffffffull ? kStreamBatch : 1) : 1;
-    if (n * kStreamCapacityFactor > 0xffffffffull) return fail(c, PTMI_ELIMIT, "image too large for the wavefront Streams path");
-    const size_t capacity = ((n * batch_max * kStreamCapacityFactor + kStreamShards - 1) / kStreamShards) * kStreamShards;
-    const unsigned int shard_cap = (unsigned int)(capacity / kStreamShards);
+    const size_t cap_factor = (size_t)c->opt_capacity;   // rays per pixel-sample the child streams hold (PTMI_OPT_STREAM_CAPACITY)
+    if (n > 0xfffffff0ull) return fail(c, PTMI_ELIMIT, "image too large for the stream form of Streams");
+    int batch_max = 1;
+    if (c->has_glass) {
+        const size_t per_sample = n * cap_factor * (size_t)kRayQueueWords * 4 * 2;      // both streams
+        size_t fit = kStreamQueueBudget / (per_sample ? per_sample : 1);
+        const size_t index_fit = 0xfffffff0ull / (n * cap_factor);
+        fit = fit < index_fit ? fit : index_fit;
+        batch_max = (int)(fit < 1 ? 1 : (fit > (size_t)kStreamBatchMax ? (size_t)kStreamBatchMax : fit));
+        if (batch_max > n_spp) batch_max = n_spp;
+    }
+    if (n * cap_factor > 0xfffffff0ull) return fail(c, PTMI_ELIMIT, "image too large for the stream form of Streams");
+    static int max_grid = 0;                                 // persistent waves: 6 per SIMD
+    if (!max_grid) {
+        int cus = 0;
+        PTMI_HIP(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        max_grid = (cus > 0 ? cus : 256) * 4 * 6;
+    }
+    const unsigned int first_block = streams_first_block();
+    size_t capacity = n * (size_t)batch_max * cap_factor;
+    if (capacity < (size_t)max_grid * first_block + 256) capacity = (size_t)max_grid * first_block + 256;   // every wave's static block fits
     if (capacity != c->queue_capacity) {
-        if (c->queue_block) { (void)hipFree(c->queue_block); c->queue_block = nullptr; c->queue_capacity = 0; }
+        if (c->queue_block) { PTMI_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->queue_block); c->queue_block = nullptr; c->queue_capacity = 0; }
         PTMI_HIP(c, hipMalloc(&c->queue_block, 2 * (size_t)kRayQueueWords * capacity * 4));
         c->queue_capacity = capacity;
     }
-    constexpr size_t kCounterWords = (size_t)kStreamCounters * kCounterStride;
-    if (!c->d_qcount) PTMI_HIP(c, hipMalloc(&c->d_qcount, kCounterWords * sizeof(unsigned int)));
-    RayQueue q[2] = {carve_queue(c->queue_block, capacity, 0), carve_queue(c->queue_block, capacity, 1)};
-    unsigned int longest = 0;
+    if (!c->d_qcount) PTMI_HIP(c, hipMalloc(&c->d_qcount, (size_t)kLvWords * sizeof(unsigned int)));
+    const RayQueue q[2] = {carve_queue(c->queue_block, capacity, 0), carve_queue(c->queue_block, capacity, 1)};
+    auto grid_for = [&](size_t items) {
+        const size_t chunks = (items + 63) / 64;
+        return (unsigned int)(chunks < 1 ? 1 : (chunks > (size_t)max_grid ? (size_t)max_grid : chunks));
+    };
+    std::vector<unsigned int> raw((size_t)kLvWords);
+    std::vector<unsigned int> seen;                          // stream lengths of the previous batch, per level (level 1 first)
+    // the statistics accumulate on the device over the whole call; the per-level cursors are preset at every launch
+    PTMI_HIP(c, hipMemsetAsync(c->d_qcount, 0, (size_t)kLvCursor * kCounterStride * sizeof(unsigned int), c->stream));
+    uint64_t cut_in_streams = 0;
     for (int s = 0; s < n_spp;) {
         const int batch = n_spp - s < batch_max ? n_spp - s : batch_max;
-        const size_t n_rays = n * (size_t)batch;
-        PTMI_HIP(c, launch_streams_init(a, q[0], batch, c->stream));     // ray j*n + i at linear slot j*n + i: fills shards 0, 1, ... in order
-        unsigned int counts[kStreamShards], raw[kStreamCounters * kCounterStride];
-        for (int k = 0; k < kStreamShards; ++k) {
-            const size_t lo = (size_t)k * shard_cap;
-            counts[k] = n_rays > lo ? (unsigned int)(n_rays - lo < shard_cap ? n_rays - lo : shard_cap) : 0u;
+        auto cursor_of = [&](int level) { return (size_t)(kLvCursor + 2 * (level % kLvMaxLevels)) * kCounterStride; };
+        auto launch_level = [&](int level, size_t expected_items) -> int {
+            LevelArgs lv{};
+            lv.in = q[(level + 1) & 1]; lv.out = q[level & 1];
+            lv.n_px = (unsigned int)n; lv.batch = batch;
+            lv.stats = c->d_qcount;
+            lv.in_count = level == 0 ? nullptr : c->d_qcount + cursor_of(level - 1);
+            lv.out_count = c->d_qcount + cursor_of(level);
+            lv.emitted = lv.out_count + kCounterStride;
+            const unsigned int grid = grid_for(expected_items);
+            PTMI_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(lv.out_count), (int)(grid * first_block), 1, c->stream));
+            PTMI_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(lv.emitted), 0, 1, c->stream));
+            PTMI_HIP(c, launch_streams_level(a, lv, level == 0, grid, c->stream));
+            return PTMI_OK;
+        };
+        int level = 0;
+        if (int rc = launch_level(0, n * (size_t)batch)) return rc;
+        // the levels the previous batch needed, each with a grid that covers the stream it is EXPECTED to read (the length
+        // seen there last time plus a margin; the grid only sets the parallelism, any grid processes any length)
+        for (size_t k = 0; k < seen.size(); ++k) {
+            ++level;
+            if (int rc = launch_level(level, (size_t)seen[k] + (size_t)seen[k] / 2 + 4096)) return rc;
         }
-        unsigned int launches = 0, deepest = 0;
-        int cur = 0;
-        for (;;) {
-            StreamLayout layout;
-            layout.prefix[0] = 0;
-            for (int k = 0; k < kStreamShards; ++k) layout.prefix[k + 1] = layout.prefix[k] + counts[k];
-            if (layout.prefix[kStreamShards] == 0 || launches >= (unsigned int)kStreamStepCap) break;
-            PTMI_HIP(c, hipMemsetAsync(c->d_qcount, 0, kCounterWords * sizeof(unsigned int), c->stream));
-            PTMI_HIP(c, launch_streams_step(a, q[cur], layout, q[cur ^ 1], c->d_qcount, c->stream));
-            PTMI_HIP(c, hipMemcpyAsync(raw, c->d_qcount, kCounterWords * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+        std::vector<unsigned int> now;
+        for (; c->has_glass;) {                               // without GLASS no ray is ever emitted: nothing to ask the device
+            PTMI_HIP(c, hipMemcpyAsync(raw.data(), c->d_qcount, (size_t)kLvWords * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
             PTMI_HIP(c, hipStreamSynchronize(c->stream));
-            c->rays_dropped += raw[kCtrDropped * kCounterStride];
-            for (int k = 0; k < kStreamShards; ++k) {
-                counts[k] = raw[k * kCounterStride] < shard_cap ? raw[k * kCounterStride] : shard_cap;
-                c->live_host += raw[(kCtrLive + k) * kCounterStride];         // rays that took another traceStep
-                const unsigned int deep = raw[(kCtrDeepest + k) * kCounterStride];
-                deepest = deep > deepest ? deep : deepest;
-            }
-            cur ^= 1;
-            ++launches;
+            // `null state` (Trace.hs:166-170): the loop goes on while the last level emitted a child that a further step may trace
+            const bool more = raw[cursor_of(level) + kCounterStride] > 0u && level + 1 < a.stream_step_cap;
+            if (!more) break;
+            const unsigned int cursor = raw[cursor_of(level)];
+            ++level;
+            if (int rc = launch_level(level, cursor < capacity ? cursor : capacity)) return rc;
         }
-        longest = deepest > longest ? deepest : longest;
+        if (c->has_glass) {
+            now.clear();
+            for (int l = 0; l < level; ++l) {                // stream lengths (holes included) the levels 1.. read, while they held rays
+                if (raw[cursor_of(l) + kCounterStride] == 0u) break;
+                const unsigned int cursor = raw[cursor_of(l)];
+                now.push_back(cursor < capacity ? cursor : (unsigned int)capacity);
+            }
+            seen.swap(now);
+            // children of the deepest allowed level sit in a stream no level will read: the cap cut them
+            cut_in_streams += raw[cursor_of(level) + kCounterStride];
+        }
         PTMI_HIP(c, launch_streams_update_seed(a.planes, (long long)n, batch, c->stream));
         s += batch;
     }
+    PTMI_HIP(c, hipMemcpyAsync(raw.data(), c->d_qcount, (size_t)kLvCursor * kCounterStride * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 8; ++k) c->live_host += raw[(size_t)(kLvLive + k) * kCounterStride];
+    c->rays_dropped += raw[(size_t)kLvDropped * kCounterStride];
+    c->rays_truncated += raw[(size_t)kLvCut * kCounterStride] + cut_in_streams;
+    const unsigned int longest = raw[(size_t)kLvDeepest * kCounterStride];      // stream_iterations: the deepest step of this call
     PTMI_HIP(c, hipMemcpyAsync(c->d_iters, &longest, sizeof longest, hipMemcpyHostToDevice, c->stream));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
     return PTMI_OK;
@@ -286,10 +342,13 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
     a.stripe_rows = stripe_rows; a.n_parts = n_parts; a.part = part;
     a.bounce_limit = bounce_limit; a.n_spp = n_spp;
     a.live_counter = c->d_live; a.work_counter = c->d_work; a.stream_iterations = c->d_iters;
+    a.stream_step_cap = c->opt_step_cap; a.seed_from_result = c->opt_seed_rule == PTMI_SEED_FROM_RESULT;
+    a.stream_counters = c->d_stream_counters;
+    const bool stream_form = algorithm == PTMI_STREAMS && (c->opt_form == PTMI_FORM_STREAM || c->variant == 9);
     // Cost-ordered dispatch (ptmi_kernels.hip: lane_pixel): launches with one (camera, scene, shape, limit, algorithm)
     // record what every quad of tiles costs; later launches with the same key dispatch the most expensive quads first
     // (sorted on the device).  Everything is enqueued on the stream; results do not depend on it.
-    const bool per_pixel_kernel = algorithm == PTMI_INLINE || !(c->has_glass || c->variant == 9);
+    const bool per_pixel_kernel = !stream_form;
     int next_order_state = c->order_state;
     if (per_pixel_kernel && uses_quad_order(a, algorithm == PTMI_INLINE, c->variant)) {
         const unsigned int n_quads = quad_positions(width, rows_local);
@@ -317,8 +376,10 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
     if (c->timing) { PTMI_HIP(c, hipEventRecord(c->ev0, c->stream)); }
     if (algorithm == PTMI_INLINE) {
         PTMI_HIP(c, launch_render_inline(a, c->variant, c->stream));
-    } else if (c->has_glass || c->variant == 9) {          // rays may split: the stream form (variant 9 forces it)
+    } else if (stream_form) {                              // rays travel through streams in HBM (PTMI_OPT_STREAMS_FORM; variant 9)
         if (int rc = render_streams_wavefront(c, a, n_spp)) return rc;
+    } else if (c->has_glass) {                             // rays may split: the per-pixel tree walk
+        PTMI_HIP(c, launch_render_streams_tree(a, c->variant, c->stream));
     } else {
         PTMI_HIP(c, launch_render_streams(a, c->variant, c->stream));
     }
@@ -326,7 +387,8 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
     c->order_state = next_order_state;
     const uint64_t px = (uint64_t)rows_local * (uint64_t)width;
     c->samples += px * (uint64_t)(n_spp > 0 ? n_spp : 0);
-    c->nominal += px * (uint64_t)(n_spp > 0 ? n_spp : 0) * (uint64_t)(bounce_limit > 0 ? bounce_limit : 0);
+    if (algorithm == PTMI_INLINE)                          // Streams ignores the limit (Trace.hs:166-170): no nominal count
+        c->nominal += px * (uint64_t)(n_spp > 0 ? n_spp : 0) * (uint64_t)(bounce_limit > 0 ? bounce_limit : 0);
     return PTMI_OK;
 }
 
@@ -340,6 +402,8 @@ int check_render_args(ptmi_ctx *c, const ptmi_camera *camera, int algorithm, int
     // "features that require diverging rays like light refraction" need the stream algorithm (Trace.hs:56-67)
     if (algorithm == PTMI_INLINE && c->has_glass)
         return fail(c, PTMI_EINVAL, "the scene holds a GLASS material: render Inline cannot split rays, use PTMI_STREAMS");
+    if (algorithm == PTMI_STREAMS && c->has_glass && c->opt_seed_rule == PTMI_SEED_FROM_RESULT)
+        return fail(c, PTMI_EINVAL, "PTMI_SEED_FROM_RESULT is undefined when rays split (GLASS): several results race for one pixel's seed");
     return PTMI_OK;
 }
 
@@ -391,6 +455,8 @@ int ptmi_create(ptmi_ctx **out, int device)
     if ((e = hipMalloc(&c->d_live, sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc(&c->d_work, 64 * sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc(&c->d_iters, sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc(&c->d_stream_counters, kScWords * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMemsetAsync(c->d_stream_counters, 0, kScWords * sizeof(unsigned long long), c->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
     // stream-ordered fills: the context's stream is non-blocking, so a NULL-stream hipMemset would race with it
     if ((e = hipMemsetAsync(c->d_live, 0, sizeof(unsigned long long), c->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
     if ((e = hipMemsetAsync(c->d_work, 0, 64 * sizeof(unsigned int), c->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
@@ -410,6 +476,7 @@ void ptmi_destroy(ptmi_ctx *c)
     if (c->d_live) (void)hipFree(c->d_live);
     if (c->d_work) (void)hipFree(c->d_work);
     if (c->d_iters) (void)hipFree(c->d_iters);
+    if (c->d_stream_counters) (void)hipFree(c->d_stream_counters);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->queue_block) (void)hipFree(c->queue_block);
     if (c->d_qcount) (void)hipFree(c->d_qcount);
@@ -484,16 +551,20 @@ int ptmi_resize(ptmi_ctx *c, int width, int height)
     return PTMI_OK;
 }
 
-int ptmi_local_rows(const ptmi_ctx *c)
+int ptmi_local_rows(const ptmi_ctx *cc)
 {
-    if (!c) return PTMI_EINVAL;
+    if (!cc) return PTMI_EINVAL;
+    ptmi_ctx *c = const_cast<ptmi_ctx *>(cc);
+    std::lock_guard<std::mutex> lock(c->mu);
     if (c->width <= 0) return PTMI_ESTATE;
     return c->rows_local;
 }
 
-int ptmi_global_row(const ptmi_ctx *c, int local_row)
+int ptmi_global_row(const ptmi_ctx *cc, int local_row)
 {
-    if (!c) return PTMI_EINVAL;
+    if (!cc) return PTMI_EINVAL;
+    ptmi_ctx *c = const_cast<ptmi_ctx *>(cc);
+    std::lock_guard<std::mutex> lock(c->mu);
     if (c->width <= 0) return PTMI_ESTATE;
     if (local_row < 0 || local_row >= c->rows_local) return PTMI_EINVAL;
     const int s = effective_stripe(c);
@@ -540,6 +611,41 @@ int ptmi_set_variant(ptmi_ctx *c, int variant)
     if (variant < 0 || variant > 17) return fail(c, PTMI_EINVAL, "unknown variant");
     c->variant = variant;
     return PTMI_OK;
+}
+
+int ptmi_set_option(ptmi_ctx *c, int option, int64_t value)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    switch (option) {
+    case PTMI_OPT_STREAMS_SEED_RULE:
+        if (value != PTMI_SEED_KEEP_ACCUMULATOR && value != PTMI_SEED_FROM_RESULT) return fail(c, PTMI_EINVAL, "unknown seed rule");
+        c->opt_seed_rule = (int)value; return PTMI_OK;
+    case PTMI_OPT_STREAM_STEP_CAP:
+        if (value < 1 || value > (1 << 30)) return fail(c, PTMI_EINVAL, "step cap must be in [1, 2^30]");
+        c->opt_step_cap = (int)value; return PTMI_OK;
+    case PTMI_OPT_STREAM_CAPACITY:
+        if (value < 1 || value > 64) return fail(c, PTMI_EINVAL, "stream capacity must be in [1, 64] rays per pixel-sample");
+        c->opt_capacity = (int)value; return PTMI_OK;
+    case PTMI_OPT_STREAMS_FORM:
+        if (value != PTMI_FORM_AUTO && value != PTMI_FORM_STREAM) return fail(c, PTMI_EINVAL, "unknown Streams form");
+        c->opt_form = (int)value; return PTMI_OK;
+    default: return fail(c, PTMI_EINVAL, "unknown option");
+    }
+}
+
+int ptmi_get_option(ptmi_ctx *c, int option, int64_t *value)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!value) return fail(c, PTMI_EINVAL, "value is NULL");
+    switch (option) {
+    case PTMI_OPT_STREAMS_SEED_RULE: *value = c->opt_seed_rule; return PTMI_OK;
+    case PTMI_OPT_STREAM_STEP_CAP:   *value = c->opt_step_cap; return PTMI_OK;
+    case PTMI_OPT_STREAM_CAPACITY:   *value = c->opt_capacity; return PTMI_OK;
+    case PTMI_OPT_STREAMS_FORM:      *value = c->opt_form; return PTMI_OK;
+    default: return fail(c, PTMI_EINVAL, "unknown option");
+    }
 }
 
 static int seed_common(ptmi_ctx *c, uint64_t seed0, bool clear)
@@ -714,13 +820,15 @@ int ptmi_get_stats(ptmi_ctx *c, ptmi_stats *out)
     if (!out) return fail(c, PTMI_EINVAL, "out is NULL");
     PTMI_HIP(c, hipSetDevice(c->device));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
-    unsigned long long live = 0; unsigned int iters = 0;
+    unsigned long long live = 0, sc[kScWords] = {0, 0, 0, 0}; unsigned int iters = 0;
     PTMI_HIP(c, hipMemcpyAsync(&live, c->d_live, sizeof live, hipMemcpyDeviceToHost, c->stream));
+    PTMI_HIP(c, hipMemcpyAsync(sc, c->d_stream_counters, sizeof sc, hipMemcpyDeviceToHost, c->stream));
     PTMI_HIP(c, hipMemcpyAsync(&iters, c->d_iters, sizeof iters, hipMemcpyDeviceToHost, c->stream));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
     out->live_bounces = live + c->live_host; out->nominal_bounces = c->nominal; out->samples = c->samples;
     out->stream_iterations = iters;
-    out->stream_rays_dropped = c->rays_dropped;
+    out->stream_rays_dropped = c->rays_dropped + sc[kScDropped];
+    out->stream_rays_truncated = c->rays_truncated + sc[kScTruncated];
     out->last_render_ms = 0.0f;
     if (c->timing && c->ev_valid) PTMI_HIP(c, hipEventElapsedTime(&out->last_render_ms, c->ev0, c->ev1));
     return PTMI_OK;
@@ -746,7 +854,8 @@ int ptmi_reset_stats(ptmi_ctx *c)
     PTMI_HIP(c, hipMemsetAsync(c->d_live, 0, sizeof(unsigned long long), c->stream));
     PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, sizeof(unsigned int), c->stream));
     PTMI_HIP(c, hipMemsetAsync(c->d_work, 0, 64 * sizeof(unsigned int), c->stream));
-    c->nominal = 0; c->samples = 0; c->rays_dropped = 0; c->live_host = 0;
+    PTMI_HIP(c, hipMemsetAsync(c->d_stream_counters, 0, kScWords * sizeof(unsigned long long), c->stream));
+    c->nominal = 0; c->samples = 0; c->rays_dropped = 0; c->rays_truncated = 0; c->live_host = 0;
     return PTMI_OK;
 }
 

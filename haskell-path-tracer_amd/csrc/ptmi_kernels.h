@@ -41,7 +41,13 @@ struct RenderArgs {
     // quad_cost: where each wave adds the loop trips it paid (NULL = do not record).
     const unsigned int *quad_order;
     unsigned int *quad_cost;
+    // render Streams only
+    int stream_step_cap;                  // traceSteps per ray lineage before the safety cap cuts it (the reference has none)
+    int seed_from_result;                 // PTMI_SEED_FROM_RESULT: a hit's ray seed replaces the pixel's (assumption A5)
+    unsigned long long *stream_counters;  // device: [kScTruncated] rays cut by the cap, [kScDropped] children that found no room
 };
+enum { kScTruncated = 0, kScDropped = 1, kScWords = 4 };
+constexpr int kTreeStackDepth = 16;        // per-pixel tree walk: pending children a lane can hold (render_streams_tree_kernel)
 
 // Ray stream of the wavefront Streams path: struct-of-arrays, `capacity` rays (type RayState, Trace.hs:46)
 struct RayQueue {
@@ -49,25 +55,34 @@ struct RayQueue {
     uint32_t *pixel;        // local pixel index
     uint32_t *seed[4];      // SFC32 a, b, c, counter
     uint32_t *depth;        // traceSteps already taken by the ray's ancestors (= the awhile iteration it belongs to)
-    unsigned int capacity;  // total; split into kStreamShards equal regions, each with its own length counter
+    unsigned int capacity;  // slots
 };
 constexpr int kRayQueueWords = 15;
-constexpr int kStreamShards = 8;            // one append counter per shard: a single counter word serves ~90 requests/us
-constexpr int kCounterStride = 32;          // the shard counters sit 128 B apart (one per cache line)
-constexpr int kStreamStepCap = 64;          // traceSteps per ray lineage; the reference has no bound (Trace.hs:166-170)
-// device counters of one step launch, each kCounterStride words apart:
-//   [0, 8) next-stream length per shard | 8 dropped children | [9, 17) rays continued or emitted per shard | [17, 25) deepest step + 1
-constexpr int kStreamCounters = 3 * kStreamShards + 1;
-constexpr int kCtrDropped = kStreamShards, kCtrLive = kStreamShards + 1, kCtrDeepest = 2 * kStreamShards + 1;
-struct StreamLayout { unsigned int prefix[kStreamShards + 1]; };   // ray i of the input lives in shard k: prefix[k] <= i < prefix[k+1]
+constexpr int kCounterStride = 32;          // device counters sit 128 B apart (one per cache line)
+constexpr int kStreamStepCapDefault = 1 << 16;   // traceSteps per ray lineage; the reference has no bound (Trace.hs:166-170) -- this only guarantees termination
+// Counters of the stream form, each kCounterStride words apart:
+//   [kLvLive, +8) children emitted, sharded by workgroup | kLvCut rays cut by the step cap | kLvDropped children that found
+//   the output stream full | kLvDeepest deepest step + 1 | kLvCursor + 2 l: the reservation cursor of the stream level l WRITES
+//   (= the item count, holes included, of the stream level l + 1 reads) | kLvCursor + 2 l + 1: the children level l stored
+constexpr int kLvLive = 0, kLvCut = 8, kLvDropped = 9, kLvDeepest = 10, kLvCursor = 11, kLvMaxLevels = 64;
+constexpr int kLvWords = (kLvCursor + 2 * kLvMaxLevels) * kCounterStride;
+struct LevelArgs {
+    RayQueue in, out;               // `in` is unused by level 0 (its rays are generated on the fly)
+    const unsigned int *in_count;   // device: the producer level's cursor (NULL for level 0)
+    unsigned int *out_count;        // device: this level's reservation cursor, preset to grid * (first block size)
+    unsigned int *emitted;          // device: children this level stored in `out`
+    unsigned int *stats;            // device: base of the counter block
+    unsigned int n_px;              // pixels held by the context
+    int batch;                      // level 0: samples of every pixel in this stream
+};
 
-hipError_t launch_streams_init(const RenderArgs &a, RayQueue q, int batch, hipStream_t stream);
-hipError_t launch_streams_step(const RenderArgs &a, RayQueue in, StreamLayout layout, RayQueue out,
-                               unsigned int *counters, hipStream_t stream);
+hipError_t launch_streams_level(const RenderArgs &a, const LevelArgs &lv, bool first, unsigned int grid, hipStream_t stream);
+unsigned int streams_first_block();   // output slots every wave of a level owns from the start
 hipError_t launch_streams_update_seed(Planes p, long long n, int draws, hipStream_t stream);
 
 hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t stream);
 hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t stream);
+hipError_t launch_render_streams_tree(const RenderArgs &a, int variant, hipStream_t stream);   // scenes with GLASS: per-pixel tree walk
 unsigned int quad_positions(int width, int rows_local);                    // entries of quad_order / quad_cost (0 = tiles not used)
 hipError_t launch_quad_order(const unsigned int *cost, unsigned int *order, unsigned int *cls, unsigned int n, hipStream_t stream);
 bool uses_quad_order(const RenderArgs &a, int algorithm_inline, int variant);

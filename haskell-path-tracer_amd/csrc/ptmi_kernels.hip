@@ -914,12 +914,15 @@ __global__ void __launch_bounds__(kRenderBlock) render_inline_persistent_kernel(
 //   * every hit adds emittance * throughput straight into the accumulator, also in the step where the
 //     throughput is already near zero (computeResult runs for every intersection, Trace.hs:290-293);
 //   * the ray dies when nearZero throughput || miss (Trace.hs:329-331); there is NO bounce limit -- a
-//     non-empty stream is never stopped by the iteration count (Trace.hs:166-170).  kStreamsHardCap only
-//     guarantees that the kernel terminates;
-//   * the pixel keeps its OLD seed while the sample runs (combine, Trace.hs:179-184) and then advances it
-//     by one draw (updateSeed, Trace.hs:151, :190-191); the ray's own seed chain is discarded.
+//     non-empty stream is never stopped by the iteration count (Trace.hs:166-170).  a.stream_step_cap only
+//     guarantees that the kernel terminates (rays it cuts are counted, stream_counters[kScTruncated]);
+//   * which seed the pixel carries out of `combine` (Trace.hs:179-184) is Accelerate-backend behaviour
+//     (assumption A5).  Default: the pixel keeps its OLD seed while the sample runs;
+//     a.seed_from_result: the seed of the ray that made the sample's LAST hit replaces it -- that ray carried the
+//     sample's start seed advanced by three draws per earlier hit, so the survivor is re-derived from the number
+//     of hits instead of being kept in registers.  Either way updateSeed then advances the pixel's seed by one
+//     draw (Trace.hs:151, :190-191).
 // ---------------------------------------------------------------------------------------
-constexpr int kStreamsHardCap = 1 << 16;
 
 template <bool LDS_SCENE, int TILE_W = 0>
 __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const RenderArgs a)
@@ -938,7 +941,8 @@ __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const R
     long long pixel;
     unsigned int quad, trips = 0;
     const bool valid = lane_pixel<TILE_W>(a, pixel, quad);
-    unsigned int live = 0, longest = 0;
+    unsigned int live = 0, longest = 0, cut = 0;
+    const unsigned int step_cap = (unsigned int)a.stream_step_cap;
     if (valid) {
         const int local_row = (int)(pixel / a.width);
         const int col = (int)(pixel - (long long)local_row * a.width);
@@ -979,6 +983,8 @@ __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const R
             Sfc32 seed = pixel_seed;
             bool pending = n_spp > 0, has_ray = false;
             auto end_sample = [&]() {
+                // combine new old: the seed the last hit's ray carried = start seed + 3 draws per earlier hit
+                if (a.seed_from_result) for (unsigned int k = 3u; k < 3u * steps; ++k) (void)sfc32_next(pixel_seed);
                 (void)random_float(pixel_seed);                   // updateSeed
                 seed = pixel_seed;
                 ++s; longest = steps > longest ? steps : longest; steps = 0;
@@ -991,21 +997,22 @@ __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const R
                 ++trips;
                 // round A: whatever hit is pending
                 if (pending && !has_ray) {
-                    const bool dying = near_zero(throughput) || steps + 1u >= (unsigned int)kStreamsHardCap;
+                    const bool dead = near_zero(throughput), capped = steps + 1u >= step_cap;
                     // results: colour += emittance * throughput for EVERY hit; then the new ray (if any)
                     shade(M, idx, pos, normal, pos, d, throughput, acc, seed);
                     ++steps;
-                    if (dying) { end_sample(); }
-                    else { ++live; pending = false; has_ray = true; }
+                    if (!dead) ++live;                             // the child exists even if the cap then cuts it
+                    if (dead || capped) { cut += (!dead && capped) ? 1u : 0u; end_sample(); }
+                    else { pending = false; has_ray = true; }
                 }
                 // round B: only lanes whose sample ended in round A; their hit is the cached primary hit and their
                 // throughput is 1 (never near zero): the specialised first shade
                 if (pending && !has_ray) {
                     shade_first<true>(M, idx0, pos, mk(get(9), get(10), get(11)), get(12), mk(get(13), get(14), get(15)),
                                       pos, d, throughput, acc, seed);
-                    ++steps;
-                    if (steps >= (unsigned int)kStreamsHardCap) { end_sample(); }
-                    else { ++live; pending = false; has_ray = true; }
+                    ++steps; ++live;
+                    if (steps >= step_cap) { ++cut; end_sample(); }
+                    else { pending = false; has_ray = true; }
                 }
                 if (has_ray) {
                     const HitSel h = check_hit(S, ns, np, pos, d);
@@ -1032,6 +1039,10 @@ __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const R
     if (a.stream_iterations) {
         for (int off = 32; off > 0; off >>= 1) { const unsigned int other = __shfl_xor(longest, off, 64); longest = other > longest ? other : longest; }
         if ((threadIdx.x & 63) == 0 && longest) atomicMax(a.stream_iterations, longest);
+    }
+    if (__any(cut != 0u)) {                                           // rare: only when the safety cap bites
+        const unsigned long long total = wave_sum(cut);
+        if ((threadIdx.x & 63) == 0) atomicAdd(a.stream_counters + kScTruncated, total);
     }
 }
 
@@ -1083,126 +1094,362 @@ __device__ __forceinline__ void glass_children(V3 color, float ior, V3 p, V3 n, 
     s_out[1] = seed;
 }
 
-__global__ void __launch_bounds__(kBlock) streams_init_kernel(const RenderArgs a, RayQueue q, int batch)
+// ---------------------------------------------------------------------------------------
+// render Streams for scenes whose rays SPLIT (the build-defined GLASS extension), per-pixel form: the tree walk.
+// A lane owns a pixel and walks each sample's ray TREE depth first: at a GLASS hit the reflection child continues in
+// the lane and the refraction child waits on a small lane-private stack (scratch memory: pushed and popped by the same
+// lane, L2-resident); when a lineage ends the lane pops the most recent waiting child, and only when the stack is
+// empty does it start the pixel's next sample.  Compared with the stream form below: no ray ever travels through HBM
+// queues, a colour word has ONE adder (no atomics, and the order of a pixel's additions is defined: depth first,
+// reflection before refraction -- oracle: ora_render_streams_tree, bit-exact), the primary hit is cached per pixel and
+// the waves are dispatched by recorded cost, exactly as in render_streams_kernel.  What it gives up is the stream's
+// density: a lane whose pixel's trees are small idles at the end of the wave.  The set of rays traced is the stream
+// algorithm's (same children, same seeds, same step indices); a child that finds the stack full (kTreeStackDepth
+// pending children in one lane) is dropped and counted, like a child that finds the next stream full.
+// ---------------------------------------------------------------------------------------
+template <bool LDS_SCENE, int TILE_W = 0>
+__global__ void __launch_bounds__(kRenderBlock, 5) render_streams_tree_kernel(const RenderArgs a)
 {
-    const long long n_local = (long long)a.rows_local * a.width;
-    const long long pixel = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (pixel >= n_local) return;
-    const int local_row = (int)(pixel / a.width);
-    const int col = (int)(pixel - (long long)local_row * a.width);
-    const V3 primary = primary_direction(a.cam, col, global_row(local_row, a.stripe_rows, a.n_parts, a.part));
-    Sfc32 s;
-    s.a = a.planes.sa[pixel]; s.b = a.planes.sb[pixel]; s.c = a.planes.sc[pixel]; s.counter = a.planes.sctr[pixel];
-    // initialState (Trace.hs:158-162).  `batch` consecutive samples of the pixel share one stream: sample j starts from
-    // the pixel's seed advanced by j draws, which is what j applications of updateSeed leave behind (Trace.hs:190-191).
-    for (int j = 0; j < batch; ++j) {
-        queue_store(q, (unsigned int)((long long)j * n_local + pixel), a.cam.pos, primary, mk(1.0f, 1.0f, 1.0f), (uint32_t)pixel, s, 0u);
-        (void)random_float(s);
-    }
-}
-
-template <bool LDS_SCENE>
-__global__ void __launch_bounds__(kBlock, 6) streams_step_kernel(const RenderArgs a, const RayQueue in, const StreamLayout layout,
-                                                              const RayQueue out, unsigned int *counters)
-{
+    __shared__ float pixel_const[9][kRenderBlock];          // per-lane restart record: primary hit position, normal, primary direction
     extern __shared__ float4 lds_scene[];
-    __shared__ unsigned int wave_kids[2][kBlock / 64];       // children per wave, pass 0 / pass 1
-    __shared__ unsigned int wave_live[kBlock / 64], wave_deep[kBlock / 64];
-    __shared__ unsigned int block_base;
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
         const int total = a.scene.total_f4();
-        for (int i = threadIdx.x; i < total; i += kBlock) lds_scene[i] = a.scene.packed[i];
+        for (int i = threadIdx.x; i < total; i += kRenderBlock) lds_scene[i] = a.scene.packed[i];
         __syncthreads();
     }
     const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
     const float4 *M = S + a.scene.geom_f4();
-    const unsigned int gi = blockIdx.x * kBlock + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned int shard_cap = in.capacity / kStreamShards;
 
-    int n_kids = 0;
-    V3 ko[2], kd[2], kt[2]; Sfc32 ks[2];
-    uint32_t pixel = 0, depth = 0;
-    unsigned int continued = 0, deepest = 0;
-    if (gi < layout.prefix[kStreamShards]) {
-        int k = 0;
-        while (gi >= layout.prefix[k + 1]) ++k;                            // at most kStreamShards - 1 steps
-        const unsigned int i = (unsigned int)k * shard_cap + (gi - layout.prefix[k]);
-        V3 o = mk(in.f[0][i], in.f[1][i], in.f[2][i]);
-        V3 d = mk(in.f[3][i], in.f[4][i], in.f[5][i]);
-        V3 throughput = mk(in.f[6][i], in.f[7][i], in.f[8][i]);
-        pixel = in.pixel[i];
-        depth = in.depth[i];
-        Sfc32 seed;
-        seed.a = in.seed[0][i]; seed.b = in.seed[1][i]; seed.c = in.seed[2][i]; seed.counter = in.seed[3][i];
-        // A ray whose hit spawns ONE child (Matte, Glossy) keeps that child in this lane and takes its next
-        // traceStep right away; only GLASS hits, which spawn two rays, go through the stream.  The set of
-        // results is that of one traceStep per launch; a pixel's results still arrive in step order from
-        // any one lineage, so scenes without GLASS stay bit-identical to the per-pixel kernel.
-        for (;;) {
-            if (depth >= (uint32_t)kStreamStepCap) break;                  // awhile would have stopped here
-            deepest = depth + 1;
-            const HitSel h = check_hit(S, ns, np, o, d);
-            if (!h.just) break;
-            V3 hit_pos, normal;
-            hit_record(S, ns, h.idx, o, d, h.t, hit_pos, normal);
-            const float4 ma = M[2 * h.idx], mb = M[2 * h.idx + 1];
-            const bool alive = !near_zero(throughput);                      // numNewRays (Trace.hs:329-331)
-            const bool glass = f2u(mb.x) == 2u;
-            V3 contribution;
-            if (glass) {
-                contribution = scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput;
-                if (alive) { glass_children(mk(ma.x, ma.y, ma.z), mb.y, hit_pos, normal, d, throughput, seed, ko, kd, kt, ks); n_kids = 2; }
-            } else {
-                contribution = mk(0.0f, 0.0f, 0.0f);
-                shade(M, h.idx, hit_pos, normal, o, d, throughput, contribution, seed);   // contribution = 0 + emittance * throughput
+    long long pixel;
+    unsigned int quad, trips = 0;
+    const bool valid = lane_pixel<TILE_W>(a, pixel, quad);
+    unsigned int live = 0, longest = 0, cut = 0, dropped = 0;
+    const unsigned int step_cap = (unsigned int)a.stream_step_cap;
+    if (valid) {
+        const int local_row = (int)(pixel / a.width);
+        const int col = (int)(pixel - (long long)local_row * a.width);
+        const int64_t px = col, py = global_row(local_row, a.stripe_rows, a.n_parts, a.part);
+        const V3 origin = a.cam.pos;
+        const V3 primary = primary_direction(a.cam, px, py);
+        V3 acc = mk(a.planes.r[pixel], a.planes.g[pixel], a.planes.b[pixel]);
+        Sfc32 pixel_seed;
+        pixel_seed.a = a.planes.sa[pixel]; pixel_seed.b = a.planes.sb[pixel];
+        pixel_seed.c = a.planes.sc[pixel]; pixel_seed.counter = a.planes.sctr[pixel];
+        const int n_spp = a.n_spp;
+
+        const HitSel h0 = check_hit(S, ns, np, origin, primary);   // same primary ray for every sample
+        if (!h0.just) {
+            for (int s = 0; s < n_spp; ++s) (void)random_float(pixel_seed);     // updateSeed only
+        } else {
+            float *mine = &pixel_const[0][threadIdx.x];
+            auto put = [&](int k, float v) { mine[k * kRenderBlock] = v; };
+            auto get = [&](int k) { return mine[k * kRenderBlock]; };
+            V3 pos, normal;                                       // pos: the hit to shade, then the next ray's origin
+            hit_record(S, ns, h0.idx, origin, primary, h0.t, pos, normal);
+            put(0, pos.x); put(1, pos.y); put(2, pos.z);
+            put(3, normal.x); put(4, normal.y); put(5, normal.z);
+            put(6, primary.x); put(7, primary.y); put(8, primary.z);
+            const int idx0 = h0.idx;
+            // children waiting for this lane: origin, direction, throughput, seed, step index (RayState, Trace.hs:45)
+            float stack_f[kTreeStackDepth][9];
+            uint32_t stack_u[kTreeStackDepth][5];
+            int sp = 0;
+            int s = 0, idx = idx0;
+            unsigned int steps = 0, deepest = 1;                 // deepest: traceSteps of the sample's longest lineage (the primary trace is step 1)
+            V3 d = primary;
+            V3 throughput = mk(1.0f, 1.0f, 1.0f);
+            Sfc32 seed = pixel_seed;
+            bool pending = n_spp > 0, has_ray = false;
+            auto lineage_ended = [&]() {
+                if (sp > 0) {                                     // the most recent waiting child
+                    --sp;
+                    pos = mk(stack_f[sp][0], stack_f[sp][1], stack_f[sp][2]);
+                    d = mk(stack_f[sp][3], stack_f[sp][4], stack_f[sp][5]);
+                    throughput = mk(stack_f[sp][6], stack_f[sp][7], stack_f[sp][8]);
+                    seed.a = stack_u[sp][0]; seed.b = stack_u[sp][1]; seed.c = stack_u[sp][2]; seed.counter = stack_u[sp][3];
+                    steps = stack_u[sp][4];
+                    pending = false; has_ray = true;
+                } else {                                          // the sample's tree is done
+                    (void)random_float(pixel_seed);               // updateSeed
+                    seed = pixel_seed;
+                    ++s; longest = deepest > longest ? deepest : longest; steps = 0; deepest = 1;
+                    throughput = mk(1.0f, 1.0f, 1.0f);
+                    pos = mk(get(0), get(1), get(2)); normal = mk(get(3), get(4), get(5));
+                    d = mk(get(6), get(7), get(8)); idx = idx0;
+                    pending = s < n_spp; has_ray = false;
+                }
+            };
+            while (pending || has_ray) {
+                ++trips;
+                // two shade rounds: a lane whose tree ended in the first starts its next sample (the cached primary hit) in the second
+                for (int round = 0; round < 2; ++round) {
+                    if (pending && !has_ray) {
+                        const float4 ma = M[2 * idx], mb = M[2 * idx + 1];
+                        const bool dead = near_zero(throughput), capped = steps + 1u >= step_cap;   // numNewRays (Trace.hs:329-331)
+                        if (f2u(mb.x) == 2u) {                    // GLASS: two children (extension; spec = the oracle's glass_children)
+                            acc = acc + (scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);           // computeResult (Trace.hs:318-323)
+                            ++steps;
+                            if (dead) { lineage_ended(); }
+                            else {
+                                V3 ko[2], kd[2], kt[2]; Sfc32 ks[2];
+                                glass_children(mk(ma.x, ma.y, ma.z), mb.y, pos, normal, d, throughput, seed, ko, kd, kt, ks);
+                                live += 2u;
+                                if (capped) { cut += 2u; lineage_ended(); }
+                                else {
+                                    if (sp < kTreeStackDepth) {
+                                        stack_f[sp][0] = ko[1].x; stack_f[sp][1] = ko[1].y; stack_f[sp][2] = ko[1].z;
+                                        stack_f[sp][3] = kd[1].x; stack_f[sp][4] = kd[1].y; stack_f[sp][5] = kd[1].z;
+                                        stack_f[sp][6] = kt[1].x; stack_f[sp][7] = kt[1].y; stack_f[sp][8] = kt[1].z;
+                                        stack_u[sp][0] = ks[1].a; stack_u[sp][1] = ks[1].b; stack_u[sp][2] = ks[1].c; stack_u[sp][3] = ks[1].counter;
+                                        stack_u[sp][4] = steps;
+                                        ++sp;
+                                    } else {
+                                        ++dropped;
+                                    }
+                                    pos = ko[0]; d = kd[0]; throughput = kt[0]; seed = ks[0];
+                                    pending = false; has_ray = true;
+                                }
+                            }
+                        } else {
+                            // results: colour += emittance * throughput for EVERY hit; then the new ray (if any)
+                            shade(M, idx, pos, normal, pos, d, throughput, acc, seed);
+                            ++steps;
+                            if (!dead) ++live;
+                            if (dead || capped) { cut += (!dead && capped) ? 1u : 0u; lineage_ended(); }
+                            else { pending = false; has_ray = true; }
+                        }
+                    }
+                }
+                if (has_ray) {
+                    deepest = steps + 1u > deepest ? steps + 1u : deepest;
+                    const HitSel h = check_hit(S, ns, np, pos, d);
+                    has_ray = false;
+                    if (h.just) {
+                        hit_record(S, ns, h.idx, pos, d, h.t, pos, normal);
+                        idx = h.idx;
+                        pending = true;
+                    } else {
+                        lineage_ended();
+                    }
+                }
             }
-            // computeResult + permute (+) (Trace.hs:179-184, :318-323); adding an exact zero changes nothing
-            if (contribution.x != 0.0f) atomicAdd(a.planes.r + pixel, contribution.x);
-            if (contribution.y != 0.0f) atomicAdd(a.planes.g + pixel, contribution.y);
-            if (contribution.z != 0.0f) atomicAdd(a.planes.b + pixel, contribution.z);
-            if (glass || !alive) break;
-            ++depth; ++continued;                                           // the single child: next traceStep, same lane
+        }
+        a.planes.r[pixel] = acc.x; a.planes.g[pixel] = acc.y; a.planes.b[pixel] = acc.z;
+        a.planes.sa[pixel] = pixel_seed.a; a.planes.sb[pixel] = pixel_seed.b;
+        a.planes.sc[pixel] = pixel_seed.c; a.planes.sctr[pixel] = pixel_seed.counter;
+    }
+    if (TILE_W > 0) record_cost(a, quad, trips);
+    if (a.live_counter) {
+        const unsigned long long total = wave_sum(live);
+        if ((threadIdx.x & 63) == 0 && total) atomicAdd(a.live_counter, total);
+    }
+    if (a.stream_iterations) {
+        for (int off = 32; off > 0; off >>= 1) { const unsigned int other = __shfl_xor(longest, off, 64); longest = other > longest ? other : longest; }
+        if ((threadIdx.x & 63) == 0 && longest) atomicMax(a.stream_iterations, longest);
+    }
+    if (__any((cut | dropped) != 0u)) {                               // rare
+        const unsigned long long n_cut = wave_sum(cut), n_dropped = wave_sum(dropped);
+        if ((threadIdx.x & 63) == 0) {
+            if (n_cut) atomicAdd(a.stream_counters + kScTruncated, n_cut);
+            if (n_dropped) atomicAdd(a.stream_counters + kScDropped, n_dropped);
         }
     }
-    // expand (Trace.hs:284-289) for the rays that split: compaction of the children into the next stream.  Wave
-    // level: ballot + popcount prefix; workgroup level: the wave totals meet in LDS and ONE lane appends for the
-    // whole workgroup, to the counter of the shard this workgroup writes (blockIdx & 7: workgroups dealt to the same
-    // XCD share a shard).  Statistics ride on the same pattern: no per-wave atomics on a single word.
-    const unsigned long long mask0 = __ballot(n_kids > 0), mask1 = __ballot(n_kids > 1);
-    const unsigned int wave_cont = (unsigned int)wave_sum(continued);
-    unsigned int wave_max = deepest;
-    for (int off = 32; off > 0; off >>= 1) { const unsigned int other = __shfl_xor(wave_max, off, 64); wave_max = other > wave_max ? other : wave_max; }
-    if (lane == 0) {
-        wave_kids[0][wave] = (unsigned int)__builtin_popcountll(mask0); wave_kids[1][wave] = (unsigned int)__builtin_popcountll(mask1);
-        wave_live[wave] = wave_cont; wave_deep[wave] = wave_max;
+}
+
+// ---------------------------------------------------------------------------------------
+// render Streams as a stream, the kernel.  One launch per LEVEL of the ray tree; a level's input is a compacted stream
+// of ray states in HBM (level 0: the primary rays of `batch` samples of every pixel, generated on the fly -- no init
+// pass writes them out), its output the stream of the children that could not stay in a lane.
+//   * persistent waves: wave w takes the 64-item chunks w, w + G, w + 2G, ... of the input (static striding: every
+//     wave sees the whole image, no hand-out atomics);
+//   * a lane follows its ray's LINEAGE: a Matte / Glossy hit spawns one child, which simply is the lane's next ray; at
+//     a GLASS hit (two children) the reflection stays in the lane and only the refraction goes to the output stream;
+//   * REFILL: when a lineage ends (miss, nearZero throughput) the lane takes the next unprocessed item of the wave's
+//     current chunk -- ballot of the idle lanes + popcount prefix for the rank -- so the trace / shade rounds run dense
+//     although lineages differ in length (the old step kernel idled until the slowest of 64 lineages had ended);
+//   * `expand` (Trace.hs:284-289) = wave-level compaction into the output stream: ballot of the lanes that emit a
+//     child, popcount prefix for the slot, space reserved a BLOCK at a time (the first block of every wave is static,
+//     later ones cost one atomic per 256 children: a single counter word serves only ~90 requests/us).  What is left
+//     of a wave's last block is marked as holes, which the next level skips;
+//   * `permute (+)` (Trace.hs:179-184) = float atomics into the colour planes (exact zeros are skipped).  Without
+//     GLASS a pixel has ONE lineage per launch, hence one adder per colour word in a defined order: bit-identical to
+//     the per-pixel kernel and the oracle.  With GLASS the order of a pixel's additions is undefined, as in Accelerate.
+// Every ray carries its step index (the `awhile` iteration it belongs to), so the safety cap cuts the same rays as in
+// the other forms; cut rays, dropped children (output stream full) and emitted children are counted.
+// ---------------------------------------------------------------------------------------
+constexpr unsigned int kHole = 0xffffffffu;                  // pixel word of an unused output slot
+constexpr unsigned int kFirstBlock = 64, kNextBlock = 256;   // output slots a wave owns at start / reserves per atomic
+
+template <bool LDS_SCENE, bool FIRST>
+__global__ void __launch_bounds__(kRenderBlock, 6) streams_level_kernel(const RenderArgs a, const LevelArgs lv)
+{
+    extern __shared__ float4 lds_scene[];
+    const int ns = a.scene.n_spheres, np = a.scene.n_planes;
+    if (LDS_SCENE) {
+        const int total = a.scene.total_f4();
+        for (int i = threadIdx.x; i < total; i += kRenderBlock) lds_scene[i] = a.scene.packed[i];
+        __syncthreads();
     }
-    __syncthreads();
-    const int shard = blockIdx.x & (kStreamShards - 1);
-    const unsigned int out_cap = out.capacity / kStreamShards;
-    if (threadIdx.x == 0) {
-        unsigned int total = 0, live = 0, deep = 0;
-        for (int w = 0; w < kBlock / 64; ++w) {
-            total += wave_kids[0][w] + wave_kids[1][w]; live += wave_live[w];
-            deep = wave_deep[w] > deep ? wave_deep[w] : deep;
-        }
-        block_base = total ? atomicAdd(counters + shard * kCounterStride, total) : 0u;
-        const unsigned int fit = block_base >= out_cap ? 0u : (out_cap - block_base < total ? out_cap - block_base : total);
-        if (live + fit) atomicAdd(counters + (kCtrLive + shard) * kCounterStride, live + fit);
-        if (total - fit) atomicAdd(counters + kCtrDropped * kCounterStride, total - fit);
-        if (deep) atomicMax(counters + (kCtrDeepest + shard) * kCounterStride, deep);
-    }
-    __syncthreads();
-    unsigned int base = block_base;
-    for (int w = 0; w < wave; ++w) base += wave_kids[0][w] + wave_kids[1][w];
+    const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
+    const float4 *M = S + a.scene.geom_f4();
+    const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (int k = 0; k < 2; ++k) {
-        if (n_kids > k) {
-            const unsigned int slot = base + (k == 0 ? (unsigned int)__builtin_popcountll(mask0 & below)
-                                                     : wave_kids[0][wave] + (unsigned int)__builtin_popcountll(mask1 & below));
-            if (slot < out_cap) queue_store(out, (unsigned int)shard * out_cap + slot, ko[k], kd[k], kt[k], pixel, ks[k], depth + 1u);
+    const unsigned int G = gridDim.x, w = blockIdx.x;
+    const unsigned int step_cap = (unsigned int)a.stream_step_cap;
+
+    // input: level 0 = chunks_per_sample * batch chunks of <= 64 pixels; later levels = ceil(n_in / 64) chunks of the stream
+    const unsigned int n_px = lv.n_px, cps = (n_px + 63u) / 64u;
+    unsigned int n_in = 0, n_chunks;
+    if (FIRST) n_chunks = cps * (unsigned int)lv.batch;
+    else {
+        n_in = *lv.in_count;                                  // the producer's cursor: real items and holes
+        n_in = n_in < lv.in.capacity ? n_in : lv.in.capacity;
+        n_chunks = (n_in + 63u) / 64u;
+    }
+    unsigned int chunk = w, taken = 0;                       // wave-uniform cursor: chunk index, items of it already handed out
+    unsigned int blk = w * kFirstBlock, blk_end = blk + kFirstBlock;   // wave-uniform: the output block being filled
+
+    bool has_ray = false;
+    V3 o = mk(0, 0, 0), d = o, throughput = o;
+    Sfc32 seed; seed.a = seed.b = seed.c = seed.counter = 0;
+    uint32_t pixel = 0, depth = 0, hits = 0;
+    unsigned int live = 0, cut = 0, dropped = 0, deepest = 0, stored = 0;
+
+    // combine new old (PTMI_SEED_FROM_RESULT; never with GLASS): the seed the lineage's last hit carried = the pixel's
+    // seed + 3 draws per earlier hit, written back so that updateSeed advances the survivor
+    auto lineage_ended = [&]() {
+        if (a.seed_from_result && hits > 0u) {
+            Sfc32 sd; sd.a = a.planes.sa[pixel]; sd.b = a.planes.sb[pixel]; sd.c = a.planes.sc[pixel]; sd.counter = a.planes.sctr[pixel];
+            for (unsigned int k = 3u; k < 3u * hits; ++k) (void)sfc32_next(sd);
+            a.planes.sa[pixel] = sd.a; a.planes.sb[pixel] = sd.b; a.planes.sc[pixel] = sd.c; a.planes.sctr[pixel] = sd.counter;
         }
+        has_ray = false;
+    };
+
+    for (;;) {
+        // ---- refill: idle lanes take the next items of the wave's current chunk
+        const unsigned long long idle = __ballot(!has_ray);
+        if (idle && chunk < n_chunks) {                       // wave-uniform
+            const unsigned int chunk_len = FIRST ? (n_px - (chunk % cps) * 64u < 64u ? n_px - (chunk % cps) * 64u : 64u)
+                                                 : (n_in - chunk * 64u < 64u ? n_in - chunk * 64u : 64u);
+            const unsigned int want = (unsigned int)__builtin_popcountll(idle), avail = chunk_len - taken;
+            const unsigned int take = want < avail ? want : avail;
+            const unsigned int rank = (unsigned int)__builtin_popcountll(idle & below);
+            if (!has_ray && rank < take) {
+                const unsigned int k = taken + rank;
+                if (FIRST) {
+                    // initialState (Trace.hs:158-162); sample j of the batch starts from the pixel's seed advanced by j
+                    // draws, which is what j applications of updateSeed leave behind (Trace.hs:190-191)
+                    const unsigned int j = chunk / cps;
+                    pixel = (chunk % cps) * 64u + k;
+                    const int local_row = (int)(pixel / (unsigned int)a.width);
+                    const int col = (int)(pixel - (unsigned int)local_row * (unsigned int)a.width);
+                    o = a.cam.pos;
+                    d = primary_direction(a.cam, col, global_row(local_row, a.stripe_rows, a.n_parts, a.part));
+                    throughput = mk(1.0f, 1.0f, 1.0f);
+                    seed.a = a.planes.sa[pixel]; seed.b = a.planes.sb[pixel]; seed.c = a.planes.sc[pixel]; seed.counter = a.planes.sctr[pixel];
+                    for (unsigned int q = 0; q < j; ++q) (void)random_float(seed);
+                    depth = 0; hits = 0; has_ray = true;
+                } else {
+                    const unsigned int i = chunk * 64u + k;
+                    pixel = lv.in.pixel[i];
+                    if (pixel != kHole) {
+                        o = mk(lv.in.f[0][i], lv.in.f[1][i], lv.in.f[2][i]);
+                        d = mk(lv.in.f[3][i], lv.in.f[4][i], lv.in.f[5][i]);
+                        throughput = mk(lv.in.f[6][i], lv.in.f[7][i], lv.in.f[8][i]);
+                        seed.a = lv.in.seed[0][i]; seed.b = lv.in.seed[1][i]; seed.c = lv.in.seed[2][i]; seed.counter = lv.in.seed[3][i];
+                        depth = lv.in.depth[i]; hits = 0; has_ray = true;
+                    }
+                }
+            }
+            taken += take;
+            if (taken >= chunk_len) { chunk += G; taken = 0; }
+        }
+        if (!__any(has_ray)) {
+            if (chunk >= n_chunks) break;
+            continue;                                         // a chunk of holes: look at the next one
+        }
+
+        // ---- one traceStep (Trace.hs:272-294) for every lane that holds a ray
+        bool emits = false;
+        V3 ko = o, kd = o, kt = o; Sfc32 ks = seed;
+        if (has_ray) {
+            if (depth >= step_cap) {                          // the safety cap (the reference has none): the ray is in the stream, never traced
+                ++cut; lineage_ended();
+            } else {
+                deepest = depth + 1u > deepest ? depth + 1u : deepest;
+                const HitSel h = check_hit(S, ns, np, o, d);
+                if (!h.just) {
+                    lineage_ended();
+                } else {
+                    V3 hit_pos, normal;
+                    hit_record(S, ns, h.idx, o, d, h.t, hit_pos, normal);
+                    const float4 ma = M[2 * h.idx], mb = M[2 * h.idx + 1];
+                    const bool alive = !near_zero(throughput);                  // numNewRays (Trace.hs:329-331)
+                    V3 contribution;
+                    ++hits;
+                    if (f2u(mb.x) == 2u) {                                        // GLASS (extension): reflection stays, refraction is emitted
+                        contribution = scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput;
+                        if (alive) {
+                            V3 co[2], cd[2], ct[2]; Sfc32 cs[2];
+                            glass_children(mk(ma.x, ma.y, ma.z), mb.y, hit_pos, normal, d, throughput, seed, co, cd, ct, cs);
+                            o = co[0]; d = cd[0]; throughput = ct[0]; seed = cs[0];
+                            ko = co[1]; kd = cd[1]; kt = ct[1]; ks = cs[1];
+                            emits = true; live += 2u;
+                        }
+                    } else {
+                        contribution = mk(0.0f, 0.0f, 0.0f);
+                        shade(M, h.idx, hit_pos, normal, o, d, throughput, contribution, seed);   // contribution = 0 + emittance * throughput
+                        if (alive) ++live;
+                    }
+                    // computeResult + permute (+) (Trace.hs:179-184, :318-323); adding an exact zero changes nothing
+                    if (contribution.x != 0.0f) atomicAdd(a.planes.r + pixel, contribution.x);
+                    if (contribution.y != 0.0f) atomicAdd(a.planes.g + pixel, contribution.y);
+                    if (contribution.z != 0.0f) atomicAdd(a.planes.b + pixel, contribution.z);
+                    if (alive) ++depth; else lineage_ended();
+                }
+            }
+        }
+        // ---- expand: compaction of the emitted children into the output stream
+        const unsigned long long kids = __ballot(emits);
+        if (kids) {                                           // wave-uniform
+            const unsigned int cnt = (unsigned int)__builtin_popcountll(kids), rank = (unsigned int)__builtin_popcountll(kids & below);
+            const unsigned int room = blk_end - blk;
+            unsigned int slot = blk + rank;
+            if (cnt > room) {                                 // the block is full: one atomic reserves the next for the whole wave
+                unsigned int fresh = 0;
+                if (lane == 0) fresh = atomicAdd(lv.out_count, kNextBlock);
+                fresh = (unsigned int)__builtin_amdgcn_readfirstlane((int)fresh);
+                if (rank >= room) slot = fresh + (rank - room);
+                blk = fresh + (cnt - room); blk_end = fresh + kNextBlock;
+            } else {
+                blk += cnt;
+            }
+            if (emits) {
+                if (slot < lv.out.capacity) { queue_store(lv.out, slot, ko, kd, kt, pixel, ks, depth); ++stored; }   // depth: already the child's step index
+                else ++dropped;
+            }
+        }
+    }
+    // what is left of this wave's last block: holes
+    {
+        const unsigned int end = blk_end < lv.out.capacity ? blk_end : lv.out.capacity;
+        for (unsigned int i = blk + (unsigned int)lane; i < end; i += 64u) lv.out.pixel[i] = kHole;
+    }
+    // statistics: one set of atomics per wave, on counters sharded by workgroup
+    const unsigned long long n_live = wave_sum(live), n_stored = wave_sum(stored);
+    unsigned int deep = deepest;
+    for (int off = 32; off > 0; off >>= 1) { const unsigned int other = __shfl_xor(deep, off, 64); deep = other > deep ? other : deep; }
+    const bool rare = __any((cut | dropped) != 0u);
+    const unsigned long long n_cut = rare ? wave_sum(cut) : 0ull, n_dropped = rare ? wave_sum(dropped) : 0ull;
+    if (lane == 0) {
+        unsigned int *st = lv.stats;
+        if (n_live) atomicAdd(st + (kLvLive + (w & 7u)) * kCounterStride, (unsigned int)n_live);
+        if (n_stored) atomicAdd(lv.emitted, (unsigned int)n_stored);
+        if (deep) atomicMax(st + kLvDeepest * kCounterStride, deep);
+        if (n_cut) atomicAdd(st + kLvCut * kCounterStride, (unsigned int)n_cut);
+        if (n_dropped) atomicAdd(st + kLvDropped * kCounterStride, (unsigned int)n_dropped);
     }
 }
 
@@ -1494,23 +1741,44 @@ hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t s
     return hipGetLastError();
 }
 
-hipError_t launch_streams_init(const RenderArgs &a, RayQueue q, int batch, hipStream_t stream)
+hipError_t launch_render_streams_tree(const RenderArgs &a, int variant, hipStream_t stream)
 {
-    const long long n = (long long)a.rows_local * a.width;
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(streams_init_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, a, q, batch);
+    const long long n_local = (long long)a.rows_local * a.width;
+    if (n_local <= 0) return hipSuccess;
+    const dim3 grid(blocks_for(n_local, kRenderBlock)), block(kRenderBlock);
+    const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
+    hipError_t e = hipMemsetAsync(a.stream_iterations, 0, sizeof(unsigned int), stream);
+    if (e != hipSuccess) return e;
+    const bool scalar_scene = variant == 5 || variant == 17 || lds > kMaxSceneLds;
+    const bool tiles = variant == 4 || variant == 5 ? false : tiles_pay(a);
+    if (tiles) {
+        const dim3 tgrid(tile_grid(a, 8));
+        if (scalar_scene) hipLaunchKernelGGL((render_streams_tree_kernel<false, 8>), tgrid, block, 0, stream, a);
+        else              hipLaunchKernelGGL((render_streams_tree_kernel<true, 8>), tgrid, block, lds, stream, a);
+    } else {
+        if (scalar_scene) hipLaunchKernelGGL((render_streams_tree_kernel<false>), grid, block, 0, stream, a);
+        else              hipLaunchKernelGGL((render_streams_tree_kernel<true>), grid, block, lds, stream, a);
+    }
     return hipGetLastError();
 }
 
-hipError_t launch_streams_step(const RenderArgs &a, RayQueue in, StreamLayout layout, RayQueue out,
-                               unsigned int *counters, hipStream_t stream)
+hipError_t launch_streams_level(const RenderArgs &a, const LevelArgs &lv, bool first, unsigned int grid, hipStream_t stream)
 {
-    const unsigned int n_in = layout.prefix[kStreamShards];
-    if (n_in == 0) return hipSuccess;
+    if (grid == 0) return hipSuccess;
     const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
-    hipLaunchKernelGGL((streams_step_kernel<true>), dim3(blocks_for(n_in)), dim3(kBlock), lds, stream, a, in, layout, out, counters);
+    const bool scalar_scene = lds > kMaxSceneLds;              // a scene too big for LDS at this occupancy: scalar loads
+    const dim3 g(grid), b(kRenderBlock);
+    if (first) {
+        if (scalar_scene) hipLaunchKernelGGL((streams_level_kernel<false, true>), g, b, 0, stream, a, lv);
+        else              hipLaunchKernelGGL((streams_level_kernel<true, true>), g, b, lds, stream, a, lv);
+    } else {
+        if (scalar_scene) hipLaunchKernelGGL((streams_level_kernel<false, false>), g, b, 0, stream, a, lv);
+        else              hipLaunchKernelGGL((streams_level_kernel<true, false>), g, b, lds, stream, a, lv);
+    }
     return hipGetLastError();
 }
+
+unsigned int streams_first_block() { return kFirstBlock; }
 
 hipError_t launch_streams_update_seed(Planes p, long long n, int draws, hipStream_t stream)
 {

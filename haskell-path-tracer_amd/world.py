@@ -85,6 +85,21 @@ def glass_scene():
     return spheres, planes
 
 
+def mirror_box():
+    """Test scene for LONG ray lineages (build-defined): a closed box of six inward-facing perfect mirrors
+    (Glossy 1.0: the rotation angles are (1 - p) * rv = 0, so `next` is the exact reflection and no ray leaves) whose
+    colour 6.2 makes a bounce keep 6.2 / (2 pi) = 98.7 % of the throughput -- a lineage takes several hundred
+    traceSteps before nearZero ends it -- around a small emissive sphere.  The camera of initial_camera() is inside."""
+    spheres = np.array([sphere((1.0, -1.0, -8.0), 0.6, (1.0, 0.9, 0.8), 10.0, MATTE, 1.0)], dtype=SPHERE_DTYPE)
+    c, g = (6.2, 6.2, 6.2), GLOSSY
+    planes = np.array([
+        plane((0.0, -4.0, 0.0), (0.0, 1.0, 0.0), c, 0.0, g, 1.0), plane((0.0, 4.0, 0.0), (0.0, -1.0, 0.0), c, 0.0, g, 1.0),
+        plane((-6.0, 0.0, 0.0), (1.0, 0.0, 0.0), c, 0.0, g, 1.0), plane((8.0, 0.0, 0.0), (-1.0, 0.0, 0.0), c, 0.0, g, 1.0),
+        plane((0.0, 0.0, -14.0), (0.0, 0.0, 1.0), c, 0.0, g, 1.0), plane((0.0, 0.0, 2.0), (0.0, 0.0, -1.0), c, 0.0, g, 1.0),
+    ], dtype=PLANE_DTYPE)
+    return spheres, planes
+
+
 def screen_pixels(width, height):
     """screenPixels (src/Util.hs:209-210): Matrix (V2 Int), V2 x y at index (Z :. y :. x)."""
     ys, xs = np.meshgrid(np.arange(height, dtype=np.int64), np.arange(width, dtype=np.int64), indexing="ij")

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PTMI_VERSION 100   /* 0.1.0 */
+#define PTMI_VERSION 200   /* 0.2.0 */
 
 /* ---- error codes ------------------------------------------------------------ */
 enum {
@@ -90,8 +90,9 @@ typedef struct ptmi_stats {
     uint64_t nominal_bounces;      /* pixels x samples x bounce_limit since the last reset                  */
     uint64_t samples;              /* pixels x samples                                                       */
     float    last_render_ms;       /* device time of the last ptmi_render launch(es); 0 unless timing is on */
-    uint32_t stream_iterations;    /* Streams: steps of the last sample's awhile loop                        */
-    uint64_t stream_rays_dropped;  /* wavefront Streams: children that did not fit the next stream (4 rays/pixel) */
+    uint32_t stream_iterations;    /* Streams: the longest chain of traceSteps any ray lineage took (stream form: of the last sample) */
+    uint64_t stream_rays_dropped;  /* Streams with ray splitting: children that found no room (next stream / lane stack full) */
+    uint64_t stream_rays_truncated;/* Streams: rays still alive when PTMI_OPT_STREAM_STEP_CAP cut their lineage (the reference has no cap) */
 } ptmi_stats;
 
 typedef struct ptmi_ctx ptmi_ctx;
@@ -135,6 +136,31 @@ int ptmi_set_timing(ptmi_ctx *ctx, int enabled);
 /* Kernel variant selection for measurements: 0 = default.  See DESIGN.md "kernel variants". */
 int ptmi_set_variant(ptmi_ctx *ctx, int variant);
 
+/* Options of `render Streams` (src/Scene/Trace.hs:141-191).  None of them changes `render Inline`. */
+enum {
+    /* Which seed a pixel carries out of `combine` (Trace.hs:179-184): the combination function keeps the seed of its
+     * FIRST argument and Accelerate's `permute` does not define which of (accumulator element, new value) that is.
+     *   PTMI_SEED_KEEP_ACCUMULATOR (default)  the pixel keeps its seed through the sample; updateSeed advances it one draw
+     *   PTMI_SEED_FROM_RESULT                 every hit replaces it by the seed its ray carried into the hit (computeResult,
+     *                                         Trace.hs:317-321); updateSeed advances the survivor.  Refused for scenes with
+     *                                         GLASS: with several rays per pixel the survivor is a race in Accelerate too. */
+    PTMI_OPT_STREAMS_SEED_RULE = 1,
+    /* Safety cap on the traceSteps of one ray lineage (children inherit their ancestors' count).  The reference has NO
+     * bound (notFinished never stops a non-empty stream, Trace.hs:166-170); the default, 65536, only guarantees
+     * termination, for both forms.  Rays it cuts are counted in ptmi_stats.stream_rays_truncated. */
+    PTMI_OPT_STREAM_STEP_CAP = 2,
+    /* Stream form only: how many rays per pixel-sample the child streams hold (default 4); children beyond are
+     * dropped and counted in ptmi_stats.stream_rays_dropped.  The reference's vectors grow as needed. */
+    PTMI_OPT_STREAM_CAPACITY = 3,
+    /* PTMI_FORM_AUTO (default): the per-pixel kernels (one lane walks its pixel's rays; with GLASS: its ray trees).
+     * PTMI_FORM_STREAM: rays travel through compacted streams in HBM, one traceStep launch per level ("wavefront"). */
+    PTMI_OPT_STREAMS_FORM = 4
+};
+enum { PTMI_SEED_KEEP_ACCUMULATOR = 0, PTMI_SEED_FROM_RESULT = 1 };
+enum { PTMI_FORM_AUTO = 0, PTMI_FORM_STREAM = 1 };
+int ptmi_set_option(ptmi_ctx *ctx, int option, int64_t value);
+int ptmi_get_option(ptmi_ctx *ctx, int option, int64_t *value);
+
 /* ---- state: initialOutput / genSeeds / reseed -------------------------------- */
 /* initialOutput (src/Util.hs:204-205): colour := 0, RNG := genSeeds.  genSeeds draws three
  * words per pixel from OS entropy (src/Util.hs:122-127); here they come from a counter-based
@@ -156,7 +182,9 @@ int ptmi_download_color(ptmi_ctx *ctx, float *r, float *g, float *b);   /* what 
 /* Resident form: equivalent to n_spp successive applications of
  *     render algorithm screenPixels camera            (src/Scene/Trace.hs:135-200)
  * to the planes held by the context.  `bounce_limit` is the `15` of Trace.hs:200 /
- * maxIterations (:80-81) made a parameter.  Asynchronous on the launch stream. */
+ * maxIterations (:80-81) made a parameter; PTMI_STREAMS IGNORES it, as the reference's Streams does (a non-empty
+ * stream is never stopped by the iteration count, Trace.hs:166-170) -- ptmi_stats.nominal_bounces is therefore 0 for
+ * Streams launches and live_bounces counts the child rays they emitted.  Asynchronous on the launch stream. */
 int ptmi_render(ptmi_ctx *ctx, const ptmi_camera *camera, int algorithm,
                 int bounce_limit, int n_spp);
 int ptmi_synchronize(ptmi_ctx *ctx);

@@ -49,6 +49,13 @@ class _Sfc(C.Structure):
     _fields_ = [("a", C.c_uint32), ("b", C.c_uint32), ("c", C.c_uint32), ("counter", C.c_uint32)]
 
 
+class _Opts(C.Structure):
+    _fields_ = [("rows", C.c_void_p), ("n_rows", C.c_int), ("streams_seed_rule", C.c_int)]
+
+
+SEED_KEEP_ACCUMULATOR, SEED_FROM_RESULT = 0, 1        # ORA_SEED_* (assumption A5, pt_oracle.h)
+
+
 def build(force=False):
     src = [os.path.join(HERE, f) for f in ("pt_oracle.c", "pt_oracle.h", "Makefile")]
     if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in src):
@@ -74,11 +81,20 @@ def lib():
         L.ora_render_inline.restype = C.c_int64
         L.ora_render_inline.argtypes = [C.POINTER(_Scene), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p] + [C.c_void_p] * 7 + [C.c_int]
+        L.ora_render_inline_ex.restype = C.c_int64
+        L.ora_render_inline_ex.argtypes = L.ora_render_inline.argtypes + [C.POINTER(_Opts)]
         L.ora_render_streams.restype = C.c_int64
         L.ora_render_streams.argtypes = [C.POINTER(_Scene), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7
         L.ora_render_streams_wavefront.restype = C.c_int64
         L.ora_render_streams_wavefront.argtypes = ([C.POINTER(_Scene), C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 7 +
                                                    [C.POINTER(C.c_int64), C.POINTER(C.c_int)])
+        L.ora_render_streams_ex.restype = C.c_int64
+        L.ora_render_streams_ex.argtypes = L.ora_render_streams.argtypes + [C.POINTER(_Opts), C.POINTER(C.c_int64)]
+        L.ora_render_streams_wavefront_ex.restype = C.c_int64
+        L.ora_render_streams_wavefront_ex.argtypes = (L.ora_render_streams_wavefront.argtypes +
+                                                      [C.POINTER(_Opts), C.POINTER(C.c_int64)])
+        L.ora_render_streams_tree.restype = C.c_int64
+        L.ora_render_streams_tree.argtypes = L.ora_render_streams_wavefront_ex.argtypes
         L.ora_gen_seeds.restype = None
         L.ora_gen_seeds.argtypes = [C.c_uint64, C.c_int64, C.c_int64] + [C.c_void_p] * 4
         L.ora_sfc32_next.restype = C.c_uint32; L.ora_sfc32_next.argtypes = [C.POINTER(_Sfc)]
@@ -178,42 +194,80 @@ def sfc32_seed3(a, b, c):
     return (s.a, s.b, s.c, s.counter)
 
 
+def _opts(rows, seed_rule):
+    """-> (_Opts, keep-alive) for the *_ex functions; rows = image row of every held row (a partition) or None."""
+    o = _Opts(None, 0, int(seed_rule))
+    keep = None
+    if rows is not None:
+        keep = np.ascontiguousarray(rows, np.int32)
+        o.rows, o.n_rows = keep.ctypes.data, keep.size
+    return o, keep
+
+
+def _copies(planes_in, n_rows, width):
+    return [np.array(a, dtype=np.float32, copy=True).reshape(n_rows, width) for a in planes_in[:3]] + \
+           [np.array(a, dtype=np.uint32, copy=True).reshape(n_rows, width) for a in planes_in[3:]]
+
+
 def render_inline(spheres, planes, camera, width, height, bounce_limit, n_spp, planes_in,
-                  screen=None, n_threads=1):
-    """n_spp applications of `render Inline` to copies of the 7 planes; returns (planes_out, live_bounces)."""
+                  screen=None, n_threads=1, rows=None):
+    """n_spp applications of `render Inline` to copies of the 7 planes; returns (planes_out, live_bounces).
+    rows: the image rows the planes hold (default all) -- a row-stripe part of the width x height image."""
     sc, keep = _scene(spheres, planes)
     cam = np.ascontiguousarray(camera, CAMERA_DTYPE)
-    outs = [np.array(a, dtype=np.float32, copy=True).reshape(height, width) for a in planes_in[:3]] + \
-           [np.array(a, dtype=np.uint32, copy=True).reshape(height, width) for a in planes_in[3:]]
+    o, keep_rows = _opts(rows, 0)
+    outs = _copies(planes_in, height if rows is None else len(rows), width)
     sx = sy = None
     if screen is not None:
         sx = np.ascontiguousarray(screen[0], np.int64)
         sy = np.ascontiguousarray(screen[1], np.int64)
-    live = lib().ora_render_inline(C.byref(sc), _p(cam), width, height, bounce_limit, n_spp,
-                                   _p(sx), _p(sy), *[_p(a) for a in outs], n_threads)
+    live = lib().ora_render_inline_ex(C.byref(sc), _p(cam), width, height, bounce_limit, n_spp,
+                                      _p(sx), _p(sy), *[_p(a) for a in outs], n_threads, C.byref(o))
     return tuple(outs), int(live)
 
 
-def render_streams(spheres, planes, camera, width, height, max_iterations, n_spp, planes_in):
+def render_streams(spheres, planes, camera, width, height, max_iterations, n_spp, planes_in,
+                   rows=None, seed_rule=SEED_KEEP_ACCUMULATOR, want_truncated=False):
     sc, keep = _scene(spheres, planes)
     cam = np.ascontiguousarray(camera, CAMERA_DTYPE)
-    outs = [np.array(a, dtype=np.float32, copy=True).reshape(height, width) for a in planes_in[:3]] + \
-           [np.array(a, dtype=np.uint32, copy=True).reshape(height, width) for a in planes_in[3:]]
-    live = lib().ora_render_streams(C.byref(sc), _p(cam), width, height, max_iterations, n_spp,
-                                    *[_p(a) for a in outs])
+    o, keep_rows = _opts(rows, seed_rule)
+    outs = _copies(planes_in, height if rows is None else len(rows), width)
+    truncated = C.c_int64(0)
+    live = lib().ora_render_streams_ex(C.byref(sc), _p(cam), width, height, max_iterations, n_spp,
+                                       *[_p(a) for a in outs], C.byref(o), C.byref(truncated))
+    if want_truncated:
+        return tuple(outs), int(live), int(truncated.value)
     return tuple(outs), int(live)
 
 
-def render_streams_wavefront(spheres, planes, camera, width, height, hard_cap, n_spp, planes_in, capacity_factor=4):
-    """Streams as a stream (supports the build-defined GLASS extension). -> (planes, live, dropped, steps)"""
+def render_streams_wavefront(spheres, planes, camera, width, height, hard_cap, n_spp, planes_in, capacity_factor=4,
+                             rows=None, seed_rule=SEED_KEEP_ACCUMULATOR, want_truncated=False):
+    """Streams as a stream (supports the build-defined GLASS extension). -> (planes, live, dropped, steps[, truncated])"""
     sc, keep = _scene(spheres, planes)
     cam = np.ascontiguousarray(camera, CAMERA_DTYPE)
-    outs = [np.array(a, dtype=np.float32, copy=True).reshape(height, width) for a in planes_in[:3]] + \
-           [np.array(a, dtype=np.uint32, copy=True).reshape(height, width) for a in planes_in[3:]]
-    dropped, steps = C.c_int64(0), C.c_int(0)
-    live = lib().ora_render_streams_wavefront(C.byref(sc), _p(cam), width, height, hard_cap, n_spp, capacity_factor,
-                                              *[_p(a) for a in outs], C.byref(dropped), C.byref(steps))
+    o, keep_rows = _opts(rows, seed_rule)
+    outs = _copies(planes_in, height if rows is None else len(rows), width)
+    dropped, steps, truncated = C.c_int64(0), C.c_int(0), C.c_int64(0)
+    live = lib().ora_render_streams_wavefront_ex(C.byref(sc), _p(cam), width, height, hard_cap, n_spp, capacity_factor,
+                                                 *[_p(a) for a in outs], C.byref(dropped), C.byref(steps),
+                                                 C.byref(o), C.byref(truncated))
+    if want_truncated:
+        return tuple(outs), int(live), int(dropped.value), int(steps.value), int(truncated.value)
     return tuple(outs), int(live), int(dropped.value), int(steps.value)
+
+
+def render_streams_tree(spheres, planes, camera, width, height, hard_cap, n_spp, planes_in, stack_depth=16, rows=None):
+    """Streams with ray splitting visited per pixel, depth first (the device's tree-walk order).
+    -> (planes, live, dropped, longest_lineage, truncated)"""
+    sc, keep = _scene(spheres, planes)
+    cam = np.ascontiguousarray(camera, CAMERA_DTYPE)
+    o, keep_rows = _opts(rows, 0)
+    outs = _copies(planes_in, height if rows is None else len(rows), width)
+    dropped, longest, truncated = C.c_int64(0), C.c_int(0), C.c_int64(0)
+    live = lib().ora_render_streams_tree(C.byref(sc), _p(cam), width, height, hard_cap, n_spp, stack_depth,
+                                         *[_p(a) for a in outs], C.byref(dropped), C.byref(longest),
+                                         C.byref(o), C.byref(truncated))
+    return tuple(outs), int(live), int(dropped.value), int(longest.value), int(truncated.value)
 
 
 def max_threads():

@@ -514,24 +514,29 @@ ora_ray ora_primary_ray(const ora_primary_uniforms *u, int64_t x, int64_t y, int
     return r;
 }
 
-/* Trace.hs:193-200, applied n_spp times */
-int64_t ora_render_inline(const ora_scene *scene, const ora_camera *cam,
-                          int width, int height, int bounce_limit, int n_spp,
-                          const int64_t *screen_x, const int64_t *screen_y,
-                          float *r, float *g, float *b,
-                          uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr,
-                          int n_threads)
+/* Which image row a held row is: rows == NULL means the whole image (row i is image row i). */
+static inline int image_row(const ora_opts *o, int local_row) { return (o && o->rows) ? o->rows[local_row] : local_row; }
+static inline int held_rows(const ora_opts *o, int height) { return (o && o->rows) ? o->n_rows : height; }
+
+/* Trace.hs:193-200, applied n_spp times, on the rows the planes hold (ora_opts.rows; default: all) */
+int64_t ora_render_inline_ex(const ora_scene *scene, const ora_camera *cam,
+                             int width, int height, int bounce_limit, int n_spp,
+                             const int64_t *screen_x, const int64_t *screen_y,
+                             float *r, float *g, float *b,
+                             uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr,
+                             int n_threads, const ora_opts *opts)
 {
     ora_primary_uniforms u = ora_primary_setup(cam, width, height);
     int64_t live_total = 0;
+    const int n_rows = held_rows(opts, height);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 4) reduction(+:live_total) num_threads(n_threads > 1 ? n_threads : 1)
 #endif
-    for (int row = 0; row < height; ++row) {
+    for (int row = 0; row < n_rows; ++row) {
         for (int col = 0; col < width; ++col) {
             int64_t i = (int64_t)row * width + col;
             int64_t px = screen_x ? screen_x[i] : col;
-            int64_t py = screen_y ? screen_y[i] : row;
+            int64_t py = screen_y ? screen_y[i] : image_row(opts, row);
             ora_ray primary = ora_primary_ray(&u, px, py, width, height);
             ora_sfc32 seed = { sa[i], sb[i], sc[i], sctr[i] };
             ora_v3 acc = v3(r[i], g[i], b[i]);
@@ -550,38 +555,56 @@ int64_t ora_render_inline(const ora_scene *scene, const ora_camera *cam,
     return live_total;
 }
 
+int64_t ora_render_inline(const ora_scene *scene, const ora_camera *cam,
+                          int width, int height, int bounce_limit, int n_spp,
+                          const int64_t *screen_x, const int64_t *screen_y,
+                          float *r, float *g, float *b,
+                          uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr,
+                          int n_threads)
+{
+    return ora_render_inline_ex(scene, cam, width, height, bounce_limit, n_spp, screen_x, screen_y,
+                                r, g, b, sa, sb, sc, sctr, n_threads, NULL);
+}
+
 /* Trace.hs:141-191 + 272-331.  Each pixel owns exactly one ray per step
  * (numNewRays is 0 or 1, Trace.hs:329-331), so the stream algorithm is restated
  * per pixel; array-level steps (expand / permute) only move data.
  *   step: hit = checkHit ray                                     (:275-279)
  *         results gets (pixel, emittance*throughput, seed) iff hit  (:290-293, :318-323)
- *         combine: acc = acc + colour, acc keeps its OLD seed        (:179-184)
+ *         combine: acc = acc + colour; WHICH seed survives depends on the order in which
+ *                  Accelerate's permute hands (new value, old value) to the combination
+ *                  function -- see ORA_SEED_* in pt_oracle.h                (:179-184)
  *         new ray iff not (nearZero throughput || isNothing hit)    (:284-289, :329-331)
  *   notFinished never stops a non-empty stream (:166-170) -> `max_iterations` is
- *   only a safety cap here (reference: none); updateSeed advances the ORIGINAL
+ *   only a safety cap here (reference: none); updateSeed advances the pixel's
  *   seed by one draw (:151, :190-191).                                          */
-int64_t ora_render_streams(const ora_scene *scene, const ora_camera *cam,
-                           int width, int height, int max_iterations, int n_spp,
-                           float *r, float *g, float *b,
-                           uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr)
+int64_t ora_render_streams_ex(const ora_scene *scene, const ora_camera *cam,
+                              int width, int height, int max_iterations, int n_spp,
+                              float *r, float *g, float *b,
+                              uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr,
+                              const ora_opts *opts, int64_t *truncated)
 {
     ora_primary_uniforms u = ora_primary_setup(cam, width, height);
-    int64_t live_total = 0;
-    for (int row = 0; row < height; ++row) {
+    int64_t live_total = 0, n_truncated = 0;
+    const int n_rows = held_rows(opts, height);
+    const int from_result = opts && opts->streams_seed_rule == ORA_SEED_FROM_RESULT;
+    for (int row = 0; row < n_rows; ++row) {
         for (int col = 0; col < width; ++col) {
             int64_t i = (int64_t)row * width + col;
-            ora_ray primary = ora_primary_ray(&u, col, row, width, height);
+            ora_ray primary = ora_primary_ray(&u, col, image_row(opts, row), width, height);
             ora_sfc32 pixel_seed = { sa[i], sb[i], sc[i], sctr[i] };
             ora_v3 acc = v3(r[i], g[i], b[i]);
             for (int s = 0; s < n_spp; ++s) {
                 ora_ray ray = primary;
                 ora_v3 throughput = v3(1.0f, 1.0f, 1.0f);
                 ora_sfc32 seed = pixel_seed;
-                for (int it = 0; it < max_iterations; ++it) {
+                int it;
+                for (it = 0; it < max_iterations; ++it) {
                     ora_maybe_hit hit = ora_check_hit(scene, ray);
                     if (hit.is_just) {
                         ora_v3 emittance = v3_scale_r(hit.material.color, hit.material.illuminance);
                         acc = v3_add(acc, v3_mul(emittance, throughput));
+                        if (from_result) pixel_seed = seed;   /* combine new old: the RayResult's seed (:321) replaces the accumulator's */
                     }
                     if (ora_near_zero_v3(throughput) || !hit.is_just) break;
                     ora_ray next_ray; ora_v3 tmod; ora_sfc32 seed2;
@@ -590,13 +613,23 @@ int64_t ora_render_streams(const ora_scene *scene, const ora_camera *cam,
                     ray = next_ray; seed = seed2;
                     ++live_total;
                 }
+                if (it == max_iterations) ++n_truncated;      /* a ray was still alive when the safety cap stopped it */
                 (void)ora_random_float(&pixel_seed);      /* updateSeed */
             }
             r[i] = acc.x; g[i] = acc.y; b[i] = acc.z;
             sa[i] = pixel_seed.a; sb[i] = pixel_seed.b; sc[i] = pixel_seed.c; sctr[i] = pixel_seed.counter;
         }
     }
+    if (truncated) *truncated = n_truncated;
     return live_total;
+}
+
+int64_t ora_render_streams(const ora_scene *scene, const ora_camera *cam,
+                           int width, int height, int max_iterations, int n_spp,
+                           float *r, float *g, float *b,
+                           uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr)
+{
+    return ora_render_streams_ex(scene, cam, width, height, max_iterations, n_spp, r, g, b, sa, sb, sc, sctr, NULL, NULL);
 }
 
 /* ========================================================================== */
@@ -641,21 +674,24 @@ static void glass_children(const ora_material *m, ora_ray normal_p, ora_ray ray,
     out[1].seed = seed;
 }
 
-int64_t ora_render_streams_wavefront(const ora_scene *scene, const ora_camera *cam,
-                                     int width, int height, int hard_cap, int n_spp, int capacity_factor,
-                                     float *r, float *g, float *b,
-                                     uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr,
-                                     int64_t *dropped, int *steps_last_sample)
+int64_t ora_render_streams_wavefront_ex(const ora_scene *scene, const ora_camera *cam,
+                                        int width, int height, int hard_cap, int n_spp, int capacity_factor,
+                                        float *r, float *g, float *b,
+                                        uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr,
+                                        int64_t *dropped, int *steps_last_sample,
+                                        const ora_opts *opts, int64_t *truncated)
 {
-    const int64_t n_px = (int64_t)width * height, cap = n_px * (capacity_factor > 0 ? capacity_factor : 1);
+    const int n_rows = held_rows(opts, height);
+    const int from_result = opts && opts->streams_seed_rule == ORA_SEED_FROM_RESULT;
+    const int64_t n_px = (int64_t)width * n_rows, cap = n_px * (capacity_factor > 0 ? capacity_factor : 1);
     ora_primary_uniforms u = ora_primary_setup(cam, width, height);
     ora_ray_state *cur = malloc(sizeof *cur * (size_t)cap), *nxt = malloc(sizeof *nxt * (size_t)cap);
-    int64_t live_total = 0, n_dropped = 0;
+    int64_t live_total = 0, n_dropped = 0, n_truncated = 0;
     int steps = 0;
     for (int s = 0; s < n_spp; ++s) {
         int64_t n_cur = n_px;                                   /* initialState (Trace.hs:158-162) */
         for (int64_t i = 0; i < n_px; ++i) {
-            cur[i].ray = ora_primary_ray(&u, i % width, i / width, width, height);
+            cur[i].ray = ora_primary_ray(&u, i % width, image_row(opts, (int)(i / width)), width, height);
             cur[i].pixel = i; cur[i].throughput = v3(1.0f, 1.0f, 1.0f);
             cur[i].seed.a = sa[i]; cur[i].seed.b = sb[i]; cur[i].seed.c = sc[i]; cur[i].seed.counter = sctr[i];
         }
@@ -668,6 +704,9 @@ int64_t ora_render_streams_wavefront(const ora_scene *scene, const ora_camera *c
                 ora_v3 emittance = v3_scale_r(hit.material.color, hit.material.illuminance);
                 ora_v3 c = v3_mul(emittance, rs->throughput);                /* computeResult (:318-323) */
                 r[rs->pixel] = r[rs->pixel] + c.x; g[rs->pixel] = g[rs->pixel] + c.y; b[rs->pixel] = b[rs->pixel] + c.z;   /* permute (+) */
+                if (from_result) {                                            /* combine new old: the result's seed survives (:181) */
+                    sa[rs->pixel] = rs->seed.a; sb[rs->pixel] = rs->seed.b; sc[rs->pixel] = rs->seed.c; sctr[rs->pixel] = rs->seed.counter;
+                }
                 if (ora_near_zero_v3(rs->throughput)) continue;              /* numNewRays (:329-331) */
                 ora_ray_state kids[2]; int n_kids;
                 if (hit.material.brdf_tag == ORA_GLASS) {
@@ -686,6 +725,7 @@ int64_t ora_render_streams_wavefront(const ora_scene *scene, const ora_camera *c
             }
             ora_ray_state *t = cur; cur = nxt; nxt = t; n_cur = n_nxt;
         }
+        n_truncated += n_cur;                                                /* rays still in the stream when the safety cap stopped awhile */
         for (int64_t i = 0; i < n_px; ++i) {                                 /* map updateSeed (:151, :190-191) */
             ora_sfc32 sd = { sa[i], sb[i], sc[i], sctr[i] };
             (void)ora_random_float(&sd);
@@ -695,6 +735,99 @@ int64_t ora_render_streams_wavefront(const ora_scene *scene, const ora_camera *c
     free(cur); free(nxt);
     if (dropped) *dropped = n_dropped;
     if (steps_last_sample) *steps_last_sample = steps;
+    if (truncated) *truncated = n_truncated;
+    return live_total;
+}
+
+int64_t ora_render_streams_wavefront(const ora_scene *scene, const ora_camera *cam,
+                                     int width, int height, int hard_cap, int n_spp, int capacity_factor,
+                                     float *r, float *g, float *b,
+                                     uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr,
+                                     int64_t *dropped, int *steps_last_sample)
+{
+    return ora_render_streams_wavefront_ex(scene, cam, width, height, hard_cap, n_spp, capacity_factor,
+                                           r, g, b, sa, sb, sc, sctr, dropped, steps_last_sample, NULL, NULL);
+}
+
+/* Streams with ray splitting, the same rays as ora_render_streams_wavefront_ex but visited per pixel and DEPTH FIRST:
+ * at a GLASS hit the first child (reflection) is followed at once, the second (refraction) waits on a stack and the
+ * most recent waiting child is resumed when a lineage ends.  Every ray carries its step index (the awhile iteration it
+ * belongs to in the stream form), so hard_cap cuts the same rays.  Only the ORDER in which a pixel's contributions are
+ * added differs from the stream form -- Accelerate's permute leaves that order undefined -- which is why the two forms
+ * agree to rounding only.  This is the order the device's tree-walk kernel uses (bit-exact against this function).
+ * stack_depth bounds the waiting children of one pixel (the device holds kTreeStackDepth = 16); a child that finds
+ * the stack full is dropped and counted. */
+int64_t ora_render_streams_tree(const ora_scene *scene, const ora_camera *cam,
+                                int width, int height, int hard_cap, int n_spp, int stack_depth,
+                                float *r, float *g, float *b,
+                                uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr,
+                                int64_t *dropped, int *longest_lineage,
+                                const ora_opts *opts, int64_t *truncated)
+{
+    typedef struct { ora_ray_state rs; int steps; } waiting;
+    const int n_rows = held_rows(opts, height);
+    ora_primary_uniforms u = ora_primary_setup(cam, width, height);
+    waiting *stack = malloc(sizeof *stack * (size_t)(stack_depth > 0 ? stack_depth : 1));
+    int64_t live_total = 0, n_dropped = 0, n_truncated = 0;
+    int longest = 0;
+    for (int row = 0; row < n_rows; ++row) {
+        for (int col = 0; col < width; ++col) {
+            int64_t i = (int64_t)row * width + col;
+            ora_ray primary = ora_primary_ray(&u, col, image_row(opts, row), width, height);
+            ora_sfc32 pixel_seed = { sa[i], sb[i], sc[i], sctr[i] };
+            ora_v3 acc = v3(r[i], g[i], b[i]);
+            for (int s = 0; s < n_spp; ++s) {
+                int sp = 0, steps = 0, have = 1;
+                ora_ray_state cur;
+                cur.ray = primary; cur.pixel = i; cur.throughput = v3(1.0f, 1.0f, 1.0f); cur.seed = pixel_seed;
+                while (have) {
+                    int ended = 1;                                        /* does this lineage end here? */
+                    if (steps >= hard_cap) { ++n_truncated; }             /* awhile had stopped: the ray is never traced */
+                    else {
+                        ora_maybe_hit hit = ora_check_hit(scene, cur.ray);
+                        ++steps;
+                        if (steps > longest) longest = steps;
+                        if (hit.is_just) {
+                            ora_v3 emittance = v3_scale_r(hit.material.color, hit.material.illuminance);
+                            acc = v3_add(acc, v3_mul(emittance, cur.throughput));   /* computeResult + permute (+) */
+                            if (!ora_near_zero_v3(cur.throughput)) {                  /* numNewRays */
+                                if (hit.material.brdf_tag == ORA_GLASS) {
+                                    ora_ray_state kids[2];
+                                    glass_children(&hit.material, hit.normal_p, cur.ray, cur.throughput, cur.seed, kids);
+                                    live_total += 2;
+                                    if (steps >= hard_cap) { n_truncated += 2; }
+                                    else {
+                                        if (sp < stack_depth) { stack[sp].rs = kids[1]; stack[sp].steps = steps; ++sp; }
+                                        else ++n_dropped;
+                                        cur.ray = kids[0].ray; cur.throughput = kids[0].throughput; cur.seed = kids[0].seed;
+                                        ended = 0;
+                                    }
+                                } else {
+                                    ora_ray next_ray; ora_v3 tmod; ora_sfc32 seed2;
+                                    ora_calc_next_ray(&hit.material, hit.normal_p, cur.ray, cur.seed, &next_ray, &tmod, &seed2);
+                                    cur.throughput = v3_mul(cur.throughput, tmod);
+                                    cur.ray = next_ray; cur.seed = seed2;
+                                    ++live_total;
+                                    if (steps >= hard_cap) ++n_truncated; else ended = 0;
+                                }
+                            }
+                        }
+                    }
+                    if (ended) {
+                        if (sp > 0) { --sp; cur = stack[sp].rs; steps = stack[sp].steps; }
+                        else have = 0;
+                    }
+                }
+                (void)ora_random_float(&pixel_seed);                      /* updateSeed */
+            }
+            r[i] = acc.x; g[i] = acc.y; b[i] = acc.z;
+            sa[i] = pixel_seed.a; sb[i] = pixel_seed.b; sc[i] = pixel_seed.c; sctr[i] = pixel_seed.counter;
+        }
+    }
+    free(stack);
+    if (dropped) *dropped = n_dropped;
+    if (longest_lineage) *longest_lineage = longest;
+    if (truncated) *truncated = n_truncated;
     return live_total;
 }
 

@@ -18,6 +18,17 @@
  *     Accelerate toolchain is absent here, and the RNG lives in an un-vendored
  *     dependency (robbert-vdh/sfc-random-accelerate @ 16fe36ec, cabal.project:61-65)
  *     whose algorithm is restated from the published PractRand sfc32.
+ *   - NAMED ASSUMPTIONS the restatement rests on (none can be checked without a GHC
+ *     build; DESIGN.md section 2 lists the one experiment that would settle each):
+ *       A1 sfc32-step      the raw step is PractRand's sfc32 (a, b, c, counter; shifts 9 / 3, rotate 21)
+ *       A2 sfc32-seeding   createWith = PractRand's 3-word seeding: counter = 1, 15 outputs discarded
+ *       A3 plane-order     the four SFC32 planes of a RenderResult are (a, b, c, counter) in that order
+ *       A4 word-to-float   random @Float = mwc-random's wordToFloat: (0, 1], from the word as a signed int
+ *       A5 streams-seed    which seed Accelerate's `permute` keeps in `combine` (Trace.hs:179-184):
+ *                          ORA_SEED_KEEP_ACCUMULATOR (default here) or ORA_SEED_FROM_RESULT; both are built
+ *       A6 ieee-reading    every f32 operation rounded on its own (Accelerate's LLVM backends may contract
+ *                          or reassociate under fast-math; tools/sensitivity.py measures how much that matters)
+ *       A7 libm            sin/cos = glibc 2.35 sinf/cosf (what llvm.sin/cos.f32 lower to on x86-64 Linux)
  *
  * Arithmetic contract (must be honoured by the compiler flags in the Makefile):
  * IEEE-754 binary32, every operation rounded on its own (-ffp-contract=off, no
@@ -118,6 +129,25 @@ ora_primary_uniforms ora_primary_setup(const ora_camera *cam, int width, int hei
 ora_ray ora_primary_ray(const ora_primary_uniforms *u, int64_t x, int64_t y, int width, int height); /* Trace.hs:244-262 */
 
 /* ---- array level ----------------------------------------------------------- */
+/* Streams: which seed the accumulator holds after `combine` (Trace.hs:179-184).  The combination function
+ *     \(T2 lColor seed) (T2 rColor _) -> T2 (lColor + rColor) seed
+ * keeps the seed of its FIRST argument, and Accelerate documents `permute`'s function as commutative, so whether
+ * the first argument is the accumulator's element or the new RayResult is backend behaviour (assumption A5):
+ *   ORA_SEED_KEEP_ACCUMULATOR  combine old new: the pixel keeps its seed for the whole sample; updateSeed then
+ *                              advances it by ONE draw per sample.
+ *   ORA_SEED_FROM_RESULT       combine new old: every hit replaces the pixel's seed by the seed its ray carried
+ *                              into that hit (computeResult's `seed`, Trace.hs:317-321); updateSeed advances the
+ *                              survivor by one draw.  With ray splitting (GLASS) the survivor among several
+ *                              results of one step is the last in element order here and a race on a device. */
+enum { ORA_SEED_KEEP_ACCUMULATOR = 0, ORA_SEED_FROM_RESULT = 1 };
+
+/* Options of the *_ex array functions; NULL = defaults (whole image, ORA_SEED_KEEP_ACCUMULATOR). */
+typedef struct {
+    const int32_t *rows;      /* image row of each row the planes hold (a partition); NULL = rows 0..height-1 */
+    int n_rows;               /* number of held rows when rows != NULL */
+    int streams_seed_rule;    /* ORA_SEED_* */
+} ora_opts;
+
 /* One call of `render Inline` (Trace.hs:193-200) repeated n_spp times on the same
  * state.  Planes are row-major [height][width]; in-place.  screen_x/screen_y may be
  * NULL (then x = column, y = row as Util.hs:209-210) or int64 planes.  n_threads<=1
@@ -129,25 +159,53 @@ int64_t ora_render_inline(const ora_scene *scene, const ora_camera *cam,
                           float *r, float *g, float *b,
                           uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr,
                           int n_threads);
+/* ... on the rows opts->rows names: planes are [n_rows][width], the primary rays those of the full image. */
+int64_t ora_render_inline_ex(const ora_scene *scene, const ora_camera *cam,
+                             int width, int height, int bounce_limit, int n_spp,
+                             const int64_t *screen_x, const int64_t *screen_y,
+                             float *r, float *g, float *b,
+                             uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr,
+                             int n_threads, const ora_opts *opts);
 
-/* `render Streams` (Trace.hs:141-191, 272-331), one sample per call, n_spp calls. */
+/* `render Streams` (Trace.hs:141-191, 272-331), one sample per call, n_spp calls.  max_iterations is a
+ * safety cap on the steps of one sample (the reference has none); *truncated counts the samples it cut. */
 int64_t ora_render_streams(const ora_scene *scene, const ora_camera *cam,
                            int width, int height, int max_iterations, int n_spp,
                            float *r, float *g, float *b,
                            uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr);
+int64_t ora_render_streams_ex(const ora_scene *scene, const ora_camera *cam,
+                              int width, int height, int max_iterations, int n_spp,
+                              float *r, float *g, float *b,
+                              uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr,
+                              const ora_opts *opts, int64_t *truncated);
 
 /* `render Streams` as an actual stream (Trace.hs:141-191, 272-331): a vector of ray states, one
  * traceStep per iteration, `expand` (children appended in element order) and `permute (+)`.  With only
  * Matte / Glossy materials it equals ora_render_streams bit for bit.  It also defines the build's GLASS
  * extension (numNewRays = 2: reflection + refraction children; see pt_oracle.c) -- the reference has no
  * such material (TODOs at Trace.hs:117-118, :306-307, :327-328), so this part has NO reference semantics.
- * The next stream holds at most capacity_factor * width * height rays; excess children are dropped and
- * counted in *dropped.  hard_cap bounds the number of steps (the reference has no bound). */
+ * The next stream holds at most capacity_factor * width * rows rays; excess children are dropped and
+ * counted in *dropped.  hard_cap bounds the number of steps (the reference has no bound); *truncated counts
+ * the rays still in the stream when it stopped the loop. */
 int64_t ora_render_streams_wavefront(const ora_scene *scene, const ora_camera *cam,
                                      int width, int height, int hard_cap, int n_spp, int capacity_factor,
                                      float *r, float *g, float *b,
                                      uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr,
                                      int64_t *dropped, int *steps_last_sample);
+int64_t ora_render_streams_wavefront_ex(const ora_scene *scene, const ora_camera *cam,
+                                        int width, int height, int hard_cap, int n_spp, int capacity_factor,
+                                        float *r, float *g, float *b,
+                                        uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr,
+                                        int64_t *dropped, int *steps_last_sample,
+                                        const ora_opts *opts, int64_t *truncated);
+
+/* The same rays visited per pixel, depth first (see pt_oracle.c): the addition order of the device's tree-walk kernel. */
+int64_t ora_render_streams_tree(const ora_scene *scene, const ora_camera *cam,
+                                int width, int height, int hard_cap, int n_spp, int stack_depth,
+                                float *r, float *g, float *b,
+                                uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr,
+                                int64_t *dropped, int *longest_lineage,
+                                const ora_opts *opts, int64_t *truncated);
 
 /* genSeeds / createWith (Util.hs:122-127) made deterministic: word triple k of pixel i
  * from ora_seed_words(seed0, i), then sfc32 3-word seeding. */

@@ -52,3 +52,25 @@ def assert_planes_equal(got, want, what=""):
             bad = np.flatnonzero(a != b)
             raise AssertionError("%s plane %s: %d of %d elements differ bitwise (first at %d: %#x vs %#x)"
                                  % (what, name, bad.size, a.size, bad[0], a[bad[0]], b[bad[0]]))
+
+
+def sfc32_advance(state, draws):
+    """The four SFC32 planes after `draws` raw steps (numpy, vectorised): what `draws` updateSeeds leave (Trace.hs:190-191)."""
+    a, b, c, ctr = [np.array(p, dtype=np.uint32, copy=True) for p in state]
+    with np.errstate(over="ignore"):
+        for _ in range(draws):
+            tmp = a + b + ctr
+            ctr = ctr + np.uint32(1)
+            a = b ^ (b >> np.uint32(9))
+            b = c + (c << np.uint32(3))
+            c = ((c << np.uint32(21)) | (c >> np.uint32(11))) + tmp
+    return a, b, c, ctr
+
+
+def initial_rows(ora, width, rows, seed0=0x5EED1234):
+    """initialOutput for the image rows `rows` only (a row-stripe part): seeds come from the GLOBAL pixel index."""
+    planes = [np.zeros((len(rows), width), np.float32) for _ in range(3)] + [np.empty((len(rows), width), np.uint32) for _ in range(4)]
+    for k, row in enumerate(rows):
+        for plane, s in zip(planes[3:], ora.gen_seeds(seed0, int(row) * width, width)):
+            plane[k] = s
+    return planes

@@ -276,6 +276,24 @@ def test_large_scenes_up_to_the_primitive_limit(ctx, pkg, ora, n_spheres, n_plan
     ctx.render(cam, 6, 1, pkg.STREAMS)
     want_s, _ = ora.render_streams(spheres, planes, cam, wd, ht, 1 << 16, 1, start)
     assert_planes_equal(ctx.download_state(), want_s, "streams, %d primitives" % (n_spheres + n_planes))
+    # the paths that used to stage the whole scene in LDS whatever its size: the stream form of Streams, the
+    # degenerate-count route (n_spp = 0 / limit = 0) and the lock-step / regenerate / pooled variants
+    ctx.set_option(pkg.binding.OPT_STREAMS_FORM, pkg.binding.FORM_STREAM)
+    ctx.upload_state(*start)
+    ctx.render(cam, 6, 1, pkg.STREAMS)
+    assert_planes_equal(ctx.download_state(), want_s, "streams (stream form), %d primitives" % (n_spheres + n_planes))
+    ctx.set_option(pkg.binding.OPT_STREAMS_FORM, pkg.binding.FORM_AUTO)
+    for limit, spp in ((6, 0), (0, 2)):
+        ctx.upload_state(*start)
+        ctx.render(cam, limit, spp)
+        want_d, _ = ora.render_inline(spheres, planes, cam, wd, ht, limit, spp, start)
+        assert_planes_equal(ctx.download_state(), want_d, "limit %d, spp %d, %d primitives" % (limit, spp, n_spheres + n_planes))
+    for variant in (2, 3, 10):
+        ctx.set_variant(variant)
+        ctx.upload_state(*start)
+        ctx.render(cam, 6, 2)
+        assert_planes_equal(ctx.download_state(), want, "%d+%d primitives, variant %d" % (n_spheres, n_planes, variant))
+    ctx.set_variant(0)
     if n_spheres + n_planes == 1024:
         with pytest.raises(pkg.PtmiError) as e:
             ctx.set_scene(np.concatenate([spheres, spheres[:1]]), planes)

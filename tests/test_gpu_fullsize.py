@@ -1,10 +1,11 @@
-"""BASELINE.json's full sizes on the device.  The oracle bit-checks C2 at a reduced sample count that
+"""BASELINE.json's full sizes on the device: C2 (1080p / 64 spp), C3 (4K / 256 spp), C4 (4K / 1024 spp, one part of 8
+and the whole image) and C5 (glass scene, 4K / 512 spp, one part of 8) at their FULL pixel and sample counts.  The oracle bit-checks C2 at a reduced sample count that
 it finishes in seconds; the full 64 spp (and 4K) are covered by size-independent properties:
 sample-split invariance (k launches of n/k spp == one of n), stripe invariance, determinism."""
 import numpy as np
 import pytest
 
-from conftest import assert_planes_equal, initial_planes
+from conftest import assert_planes_equal, initial_planes, initial_rows, sfc32_advance
 
 pytestmark = pytest.mark.gpu
 W, H = 1920, 1080
@@ -66,3 +67,100 @@ def test_4k_stripes_equal_whole(pkg):
             c.render(cam, 8, 2)
             rows = c.global_rows()
             assert_planes_equal(c.download_state(), [p[rows] for p in whole], "part %d" % part)
+
+
+W4K, H4K = 3840, 2160
+
+
+def test_c3_4k_256spp_split_invariance_and_determinism(pkg):
+    """configs[2] at full size: one 256-spp launch == 4 x 64 spp == a second run, all seven planes bit for bit."""
+    sp, pl = pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    with pkg.Context(0) as c:
+        c.set_scene(sp, pl)
+        c.resize(W4K, H4K)
+        c.init_output(0x5EED1234)
+        c.render(cam, 8, 256)
+        one = c.download_state()
+        st = c.stats()
+        assert st["samples"] == W4K * H4K * 256 and 0 < st["live_bounces"] <= st["nominal_bounces"]
+        c.init_output(0x5EED1234)
+        for _ in range(4):
+            c.render(cam, 8, 64)
+        assert_planes_equal(c.download_state(), one, "4 x 64 spp vs 256 spp at 4K")
+        c.init_output(0x5EED1234)
+        c.render(cam, 8, 256)                                   # runs in the cost order the earlier launches recorded
+        assert_planes_equal(c.download_state(), one, "second 256-spp run at 4K")
+    assert all(np.all(np.isfinite(p)) for p in one[:3])
+
+
+@pytest.mark.parametrize("stripe_rows,part", [(10, 3), (8, 7)])
+def test_c4_part_of_8_at_1024spp_equals_the_whole_image(pkg, stripe_rows, part):
+    """configs[3] at full size: the whole 4K image at 1024 spp on one GPU, and one of the 8 row-stripe parts exactly as
+    its rank renders it (bench.py --scaling strong uses 10-row stripes at 8 ranks; 8 rows leave 272 / 264 rows) -- in one
+    1024-spp launch and as 8 x 128 spp.  The part's rows must equal the whole image's rows bit for bit."""
+    sp, pl = pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    whole = _c4_whole(pkg)
+    with pkg.Context(0) as c:
+        c.set_scene(sp, pl)
+        c.set_partition(stripe_rows, 8, part)
+        c.resize(W4K, H4K)
+        rows = c.global_rows()
+        want = [p[rows] for p in whole]
+        c.init_output(0x5EED1234)
+        c.render(cam, 8, 1024)
+        assert_planes_equal(c.download_state(), want, "C4 part %d (stripes of %d), one launch" % (part, stripe_rows))
+        c.init_output(0x5EED1234)
+        for _ in range(8):
+            c.render(cam, 8, 128)
+        assert_planes_equal(c.download_state(), want, "C4 part %d (stripes of %d), 8 x 128 spp" % (part, stripe_rows))
+
+
+_C4_WHOLE = {}
+
+
+def _c4_whole(pkg):
+    if "planes" not in _C4_WHOLE:
+        sp, pl = pkg.world.scene16()
+        with pkg.Context(0) as c:
+            c.set_scene(sp, pl)
+            c.resize(W4K, H4K)
+            c.init_output(0x5EED1234)
+            c.render(pkg.world.initial_camera(), 8, 1024)
+            _C4_WHOLE["planes"] = c.download_state()
+    return _C4_WHOLE["planes"]
+
+
+def test_c5_glass_4k_512spp_one_part_of_8(pkg, ora):
+    """configs[4] at full size on one of its 8 parts: the glass scene (build-defined GLASS extension: no reference
+    semantics, the repo's oracle is the definition), 3840x2160, 512 spp, `render Streams`.  No child ray may be dropped,
+    the RNG planes are exact (updateSeed: 512 draws per pixel), and a two-row window of the part equals the oracle
+    within north_star's 1e-4 relative (the order of a pixel's additions is undefined, as in Accelerate's permute)."""
+    sp, pl = pkg.world.glass_scene()
+    cam = pkg.world.initial_camera()
+    spp, part = 512, 5
+    with pkg.Context(0) as c:
+        c.set_scene(sp, pl)
+        c.set_partition(10, 8, part)
+        c.resize(W4K, H4K)
+        rows = c.global_rows()
+        c.init_output(0x5EED1234)
+        start = c.download_state()
+        c.reset_stats()
+        c.render(cam, 8, spp, pkg.STREAMS)
+        got = c.download_state()
+        st = c.stats()
+    assert st["stream_rays_dropped"] == 0 and st["stream_rays_truncated"] == 0
+    assert st["samples"] == len(rows) * W4K * spp
+    for a, b in zip(got[3:], sfc32_advance(start[3:], spp)):
+        assert np.array_equal(a, b)
+    pick = [len(rows) // 2, len(rows) // 2 + 1]                 # two rows through the glass spheres
+    window = initial_rows(ora, W4K, rows[pick])
+    for a, b in zip(window[3:], start[3:]):
+        assert np.array_equal(a, b[pick])                        # the device seeded these rows from the global pixel index
+    want = ora.render_streams_wavefront(sp, pl, cam, W4K, H4K, 1 << 16, spp, window, capacity_factor=8, rows=rows[pick])[0]
+    for a, b in zip(got[:3], want[:3]):
+        scale = np.maximum(np.abs(b), 1e-3 * spp)
+        assert np.max(np.abs(a[pick] - b) / scale) <= 1e-4
+    assert not np.array_equal(want[0], np.zeros_like(want[0]))

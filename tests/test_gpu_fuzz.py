@@ -76,8 +76,8 @@ def test_random_scenes_inline_and_streams(ctx, pkg, ora):
             ctx.set_variant(0)
             got = ctx.download_state()
             with np.errstate(all="ignore"):
-                if stream_form:                                    # `awhile` is capped at 64 steps there, 65 536 in the chain
-                    want = ora.render_streams_wavefront(spheres, planes, cam, w, h, 64, spp, start)[0]
+                if stream_form:                                    # both forms share the 65 536-step safety cap
+                    want = ora.render_streams_wavefront(spheres, planes, cam, w, h, 1 << 16, spp, start)[0]
                 else:
                     want, _ = ora.render_streams(spheres, planes, cam, w, h, 1 << 16, spp, start)
             assert_planes_equal(got, want, "fuzz case %d streams (%s)" % (case, "stream form" if stream_form else "per-pixel form"))

@@ -74,3 +74,83 @@ def test_render1_streams(ctx, pkg, ora):
     got = ctx.render1(cam, 15, w, h, start, algorithm=pkg.STREAMS)
     want, _ = ora.render_streams(sp, pl, cam, w, h, CAP, 1, start)
     assert_planes_equal(got, want, "render1 Streams")
+
+
+@pytest.mark.parametrize("stream_form", [False, True])
+@pytest.mark.parametrize("scene_name,w,h,spp", [("main", 96, 64, 3), ("s16", 120, 67, 2)])
+def test_seed_from_result_rule(ctx, pkg, ora, scene_name, w, h, spp, stream_form):
+    """Assumption A5's alternative (PTMI_SEED_FROM_RESULT: permute hands `combine` the new value first) on the device,
+    both forms, against the oracle -- bit for bit, seeds included."""
+    B = pkg.binding
+    scene = pkg.world.main_scene() if scene_name == "main" else pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    start = initial_planes(ora, w, h)
+    ctx.set_scene(*scene)
+    ctx.resize(w, h)
+    ctx.upload_state(*start)
+    ctx.reset_stats()
+    ctx.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_FROM_RESULT)
+    ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM if stream_form else B.FORM_AUTO)
+    try:
+        assert ctx.get_option(B.OPT_STREAMS_SEED_RULE) == B.SEED_FROM_RESULT
+        ctx.render(cam, 15, spp, pkg.STREAMS)
+        got = ctx.download_state()
+        live_gpu = ctx.stats()["live_bounces"]
+    finally:
+        ctx.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_KEEP_ACCUMULATOR)
+        ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_AUTO)
+    want, live = ora.render_streams(scene[0], scene[1], cam, w, h, CAP, spp, start, seed_rule=ora.SEED_FROM_RESULT)
+    assert_planes_equal(got, want, "seed from result, %s" % ("stream form" if stream_form else "per-pixel form"))
+    assert live_gpu == live
+    keep, _ = ora.render_streams(scene[0], scene[1], cam, w, h, CAP, spp, start)
+    assert not np.array_equal(keep[3], want[3])              # the two rules really differ
+
+
+def test_seed_from_result_is_refused_when_rays_split(ctx, pkg):
+    B = pkg.binding
+    ctx.set_scene(*pkg.world.glass_scene())
+    ctx.resize(16, 16)
+    ctx.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_FROM_RESULT)
+    try:
+        with pytest.raises(pkg.PtmiError) as e:
+            ctx.render(pkg.world.initial_camera(), 8, 1, pkg.STREAMS)
+        assert e.value.code == -1
+    finally:
+        ctx.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_KEEP_ACCUMULATOR)
+    with pytest.raises(pkg.PtmiError):
+        ctx.set_option(99, 0)
+    with pytest.raises(pkg.PtmiError):
+        ctx.set_option(B.OPT_STREAM_STEP_CAP, 0)
+
+
+@pytest.mark.parametrize("stream_form", [False, True])
+def test_long_lineages_and_the_step_cap(ctx, pkg, ora, stream_form):
+    """An enclosed mirror box: every lineage takes hundreds of traceSteps (the reference has no bound).  With the
+    default cap (65536, both forms) nothing is cut and the planes equal the oracle; a small cap cuts the same rays in
+    both forms and in the oracle, and the cut rays are COUNTED (ptmi_stats.stream_rays_truncated)."""
+    B = pkg.binding
+    sp, pl = pkg.world.mirror_box()
+    cam = pkg.world.initial_camera()
+    w, h, spp = 40, 24, 2
+    start = initial_planes(ora, w, h)
+    ctx.set_scene(sp, pl)
+    ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM if stream_form else B.FORM_AUTO)
+    try:
+        assert ctx.get_option(B.OPT_STREAM_STEP_CAP) == 1 << 16
+        for cap in (1 << 16, 64, 3, 1):
+            ctx.set_option(B.OPT_STREAM_STEP_CAP, cap)
+            ctx.resize(w, h)
+            ctx.upload_state(*start)
+            ctx.reset_stats()
+            ctx.render(cam, 15, spp, pkg.STREAMS)
+            got, st = ctx.download_state(), ctx.stats()
+            want, live, cut = ora.render_streams(sp, pl, cam, w, h, cap, spp, start, want_truncated=True)
+            assert_planes_equal(got, want, "mirror box, cap %d" % cap)
+            assert st["live_bounces"] == live and st["stream_rays_truncated"] == cut and st["stream_rays_dropped"] == 0
+            if cap == 1 << 16:
+                assert cut == 0 and 200 < st["stream_iterations"] < 5000
+            else:
+                assert cut > 0
+    finally:
+        ctx.set_option(B.OPT_STREAM_STEP_CAP, 1 << 16)
+        ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_AUTO)

@@ -10,10 +10,12 @@ from conftest import assert_planes_equal, initial_planes
 
 pytestmark = pytest.mark.gpu
 REL_TOL = 1e-4
-CAP = 64           # kStreamHardCap
+CAP = 1 << 16      # PTMI_OPT_STREAM_STEP_CAP default, both forms (the reference has no cap, Trace.hs:166-170)
 
 
-def render(ctx, pkg, scene, cam, w, h, spp, start, variant=0):
+def render(ctx, pkg, scene, cam, w, h, spp, start, variant=0, stream_form=False):
+    B = pkg.binding
+    ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM if stream_form else B.FORM_AUTO)
     ctx.set_variant(variant)
     ctx.set_scene(*scene)
     ctx.resize(w, h)
@@ -22,6 +24,7 @@ def render(ctx, pkg, scene, cam, w, h, spp, start, variant=0):
     ctx.render(cam, 15, spp, pkg.STREAMS)
     out, st = ctx.download_state(), ctx.stats()
     ctx.set_variant(0)
+    ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_AUTO)
     return out, st
 
 
@@ -38,12 +41,30 @@ def test_wavefront_without_glass_is_bit_exact(ctx, pkg, ora, scene_name, w, h, s
     assert st["live_bounces"] == live and st["stream_iterations"] == steps and st["stream_rays_dropped"] == 0 == dropped
 
 
-def test_glass_scene_within_tolerance_and_seeds_exact(ctx, pkg, ora):
+def test_glass_scene_tree_walk_is_bit_exact(ctx, pkg, ora):
+    """The default for scenes with GLASS: the per-pixel tree walk.  One adder per colour word, additions in a defined
+    order (depth first, reflection before refraction) -> equal to the oracle's tree order BIT FOR BIT, and within
+    rounding of the stream order."""
+    scene = pkg.world.glass_scene()
+    cam = pkg.world.initial_camera()
+    for w, h, spp in ((128, 72, 3), (61, 33, 5)):
+        start = initial_planes(ora, w, h)
+        got, st = render(ctx, pkg, scene, cam, w, h, spp, start)
+        want, live, dropped, longest, cut = ora.render_streams_tree(scene[0], scene[1], cam, w, h, CAP, spp, start)
+        assert_planes_equal(got, want, "glass tree walk %dx%d" % (w, h))
+        assert st["live_bounces"] == live and st["stream_rays_dropped"] == dropped == 0 and st["stream_rays_truncated"] == cut == 0
+        assert st["stream_iterations"] == longest
+        stream = ora.render_streams_wavefront(scene[0], scene[1], cam, w, h, CAP, spp, start, capacity_factor=8)[0]
+        for a, b in zip(got[:3], stream[:3]):
+            assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) <= REL_TOL
+
+
+def test_glass_scene_stream_form_within_tolerance_and_seeds_exact(ctx, pkg, ora):
     scene = pkg.world.glass_scene()
     cam = pkg.world.initial_camera()
     w, h, spp = 128, 72, 3
     start = initial_planes(ora, w, h)
-    got, st = render(ctx, pkg, scene, cam, w, h, spp, start)
+    got, st = render(ctx, pkg, scene, cam, w, h, spp, start, stream_form=True)
     want, live, dropped, steps = ora.render_streams_wavefront(scene[0], scene[1], cam, w, h, CAP, spp, start)
     for a, b in zip(got[3:], want[3:]):
         assert np.array_equal(a, b)                       # updateSeed: integer, exact
