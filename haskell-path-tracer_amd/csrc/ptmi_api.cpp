@@ -76,6 +76,7 @@ struct ptmi_ctx {
     int opt_step_cap = kStreamStepCapDefault;
     int opt_capacity = 4;
     int opt_form = PTMI_FORM_AUTO;
+    int opt_batch = 0;
 };
 
 namespace {
@@ -233,15 +234,17 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
     if (n == 0 || n_spp <= 0) return PTMI_OK;
     const size_t cap_factor = (size_t)c->opt_capacity;   // rays per pixel-sample the child streams hold (PTMI_OPT_STREAM_CAPACITY)
     if (n > 0xfffffff0ull) return fail(c, PTMI_ELIMIT, "image too large for the stream form of Streams");
-    int batch_max = 1;
-    if (c->has_glass) {
+    int batch_max = c->opt_batch > 0 ? c->opt_batch : 1;
+    if (c->has_glass || c->opt_batch > 0) {
         const size_t per_sample = n * cap_factor * (size_t)kRayQueueWords * 4 * 2;      // both streams
         size_t fit = kStreamQueueBudget / (per_sample ? per_sample : 1);
         const size_t index_fit = 0xfffffff0ull / (n * cap_factor);
         fit = fit < index_fit ? fit : index_fit;
-        batch_max = (int)(fit < 1 ? 1 : (fit > (size_t)kStreamBatchMax ? (size_t)kStreamBatchMax : fit));
+        const size_t wanted = c->opt_batch > 0 ? (size_t)c->opt_batch : (size_t)kStreamBatchMax;
+        batch_max = (int)(fit < 1 ? 1 : (fit > wanted ? wanted : fit));
         if (batch_max > n_spp) batch_max = n_spp;
     }
+    if (a.seed_from_result) batch_max = 1;               // a sample starts from the seed the previous sample's last hit left
     if (n * cap_factor > 0xfffffff0ull) return fail(c, PTMI_ELIMIT, "image too large for the stream form of Streams");
     static int max_grid = 0;                                 // persistent waves: 6 per SIMD
     if (!max_grid) {
@@ -630,6 +633,9 @@ int ptmi_set_option(ptmi_ctx *c, int option, int64_t value)
     case PTMI_OPT_STREAMS_FORM:
         if (value != PTMI_FORM_AUTO && value != PTMI_FORM_STREAM) return fail(c, PTMI_EINVAL, "unknown Streams form");
         c->opt_form = (int)value; return PTMI_OK;
+    case PTMI_OPT_STREAM_BATCH:
+        if (value < 0 || value > 64) return fail(c, PTMI_EINVAL, "stream batch must be in [0, 64] samples");
+        c->opt_batch = (int)value; return PTMI_OK;
     default: return fail(c, PTMI_EINVAL, "unknown option");
     }
 }
@@ -644,6 +650,7 @@ int ptmi_get_option(ptmi_ctx *c, int option, int64_t *value)
     case PTMI_OPT_STREAM_STEP_CAP:   *value = c->opt_step_cap; return PTMI_OK;
     case PTMI_OPT_STREAM_CAPACITY:   *value = c->opt_capacity; return PTMI_OK;
     case PTMI_OPT_STREAMS_FORM:      *value = c->opt_form; return PTMI_OK;
+    case PTMI_OPT_STREAM_BATCH:      *value = c->opt_batch; return PTMI_OK;
     default: return fail(c, PTMI_EINVAL, "unknown option");
     }
 }

@@ -1107,10 +1107,14 @@ __device__ __forceinline__ void glass_children(V3 color, float ior, V3 p, V3 n, 
 // algorithm's (same children, same seeds, same step indices); a child that finds the stack full (kTreeStackDepth
 // pending children in one lane) is dropped and counted, like a child that finds the next stream full.
 // ---------------------------------------------------------------------------------------
+#ifndef PTMI_TREE_WAVES
+#define PTMI_TREE_WAVES 5
+#endif
 template <bool LDS_SCENE, int TILE_W = 0>
-__global__ void __launch_bounds__(kRenderBlock, 5) render_streams_tree_kernel(const RenderArgs a)
+__global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_tree_kernel(const RenderArgs a)
 {
     __shared__ float pixel_const[9][kRenderBlock];          // per-lane restart record: primary hit position, normal, primary direction
+    __shared__ uint32_t stack_bottom[14][kRenderBlock];      // a lane's FIRST waiting child (the common depth); deeper ones go to scratch
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -1151,9 +1155,12 @@ __global__ void __launch_bounds__(kRenderBlock, 5) render_streams_tree_kernel(co
             put(3, normal.x); put(4, normal.y); put(5, normal.z);
             put(6, primary.x); put(7, primary.y); put(8, primary.z);
             const int idx0 = h0.idx;
-            // children waiting for this lane: origin, direction, throughput, seed, step index (RayState, Trace.hs:45)
-            float stack_f[kTreeStackDepth][9];
-            uint32_t stack_u[kTreeStackDepth][5];
+            // children waiting for this lane: origin, direction, throughput, seed, step index (RayState, Trace.hs:45).
+            // Entry 0 lives in a lane-private LDS column, entries 1.. in scratch memory: the reflection that is followed
+            // first rarely meets glass again, so nearly all pushes and pops are LDS traffic (with the whole stack in
+            // scratch the kernel wrote 23 GB per C2-sized launch: every push is 14 partial-line writes).
+            uint32_t stack_w[kTreeStackDepth - 1][14];
+            uint32_t *bottom = &stack_bottom[0][threadIdx.x];
             int sp = 0;
             int s = 0, idx = idx0;
             unsigned int steps = 0, deepest = 1;                 // deepest: traceSteps of the sample's longest lineage (the primary trace is step 1)
@@ -1164,11 +1171,14 @@ __global__ void __launch_bounds__(kRenderBlock, 5) render_streams_tree_kernel(co
             auto lineage_ended = [&]() {
                 if (sp > 0) {                                     // the most recent waiting child
                     --sp;
-                    pos = mk(stack_f[sp][0], stack_f[sp][1], stack_f[sp][2]);
-                    d = mk(stack_f[sp][3], stack_f[sp][4], stack_f[sp][5]);
-                    throughput = mk(stack_f[sp][6], stack_f[sp][7], stack_f[sp][8]);
-                    seed.a = stack_u[sp][0]; seed.b = stack_u[sp][1]; seed.c = stack_u[sp][2]; seed.counter = stack_u[sp][3];
-                    steps = stack_u[sp][4];
+                    uint32_t e[14];
+                    if (sp == 0) { for (int q = 0; q < 14; ++q) e[q] = bottom[q * kRenderBlock]; }
+                    else         { for (int q = 0; q < 14; ++q) e[q] = stack_w[sp - 1][q]; }
+                    pos = mk(u2f(e[0]), u2f(e[1]), u2f(e[2]));
+                    d = mk(u2f(e[3]), u2f(e[4]), u2f(e[5]));
+                    throughput = mk(u2f(e[6]), u2f(e[7]), u2f(e[8]));
+                    seed.a = e[9]; seed.b = e[10]; seed.c = e[11]; seed.counter = e[12];
+                    steps = e[13];
                     pending = false; has_ray = true;
                 } else {                                          // the sample's tree is done
                     (void)random_float(pixel_seed);               // updateSeed
@@ -1198,11 +1208,10 @@ __global__ void __launch_bounds__(kRenderBlock, 5) render_streams_tree_kernel(co
                                 if (capped) { cut += 2u; lineage_ended(); }
                                 else {
                                     if (sp < kTreeStackDepth) {
-                                        stack_f[sp][0] = ko[1].x; stack_f[sp][1] = ko[1].y; stack_f[sp][2] = ko[1].z;
-                                        stack_f[sp][3] = kd[1].x; stack_f[sp][4] = kd[1].y; stack_f[sp][5] = kd[1].z;
-                                        stack_f[sp][6] = kt[1].x; stack_f[sp][7] = kt[1].y; stack_f[sp][8] = kt[1].z;
-                                        stack_u[sp][0] = ks[1].a; stack_u[sp][1] = ks[1].b; stack_u[sp][2] = ks[1].c; stack_u[sp][3] = ks[1].counter;
-                                        stack_u[sp][4] = steps;
+                                        const uint32_t e[14] = {f2u(ko[1].x), f2u(ko[1].y), f2u(ko[1].z), f2u(kd[1].x), f2u(kd[1].y), f2u(kd[1].z),
+                                                                f2u(kt[1].x), f2u(kt[1].y), f2u(kt[1].z), ks[1].a, ks[1].b, ks[1].c, ks[1].counter, steps};
+                                        if (sp == 0) { for (int q = 0; q < 14; ++q) bottom[q * kRenderBlock] = e[q]; }
+                                        else         { for (int q = 0; q < 14; ++q) stack_w[sp - 1][q] = e[q]; }
                                         ++sp;
                                     } else {
                                         ++dropped;
@@ -1280,9 +1289,16 @@ __global__ void __launch_bounds__(kRenderBlock, 5) render_streams_tree_kernel(co
 // ---------------------------------------------------------------------------------------
 constexpr unsigned int kHole = 0xffffffffu;                  // pixel word of an unused output slot
 constexpr unsigned int kFirstBlock = 64, kNextBlock = 256;   // output slots a wave owns at start / reserves per atomic
+#ifndef PTMI_LEVEL_WAVES
+#define PTMI_LEVEL_WAVES 6
+#endif
+#ifndef PTMI_REFILL_BATCH
+#define PTMI_REFILL_BATCH 8
+#endif
+constexpr unsigned int kRefillBatch = PTMI_REFILL_BATCH;     // idle lanes a wave waits for before it runs the refill block
 
 template <bool LDS_SCENE, bool FIRST>
-__global__ void __launch_bounds__(kRenderBlock, 6) streams_level_kernel(const RenderArgs a, const LevelArgs lv)
+__global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_kernel(const RenderArgs a, const LevelArgs lv)
 {
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
@@ -1309,6 +1325,22 @@ __global__ void __launch_bounds__(kRenderBlock, 6) streams_level_kernel(const Re
     }
     unsigned int chunk = w, taken = 0;                       // wave-uniform cursor: chunk index, items of it already handed out
     unsigned int blk = w * kFirstBlock, blk_end = blk + kFirstBlock;   // wave-uniform: the output block being filled
+    // wave-uniform description of the current chunk, recomputed only when the cursor moves to another chunk, so that
+    // the refill below needs no per-lane integer division
+    unsigned int chunk_len = 0, chunk_j = 0, chunk_px0 = 0, chunk_row0 = 0, chunk_col0 = 0;
+    auto open_chunk = [&]() {
+        if (chunk >= n_chunks) { chunk_len = 0; return; }
+        if (FIRST) {
+            chunk_j = chunk / cps;
+            chunk_px0 = (chunk - chunk_j * cps) * 64u;
+            chunk_len = n_px - chunk_px0 < 64u ? n_px - chunk_px0 : 64u;
+            chunk_row0 = chunk_px0 / (unsigned int)a.width;
+            chunk_col0 = chunk_px0 - chunk_row0 * (unsigned int)a.width;
+        } else {
+            chunk_len = n_in - chunk * 64u < 64u ? n_in - chunk * 64u : 64u;
+        }
+    };
+    open_chunk();
 
     bool has_ray = false;
     V3 o = mk(0, 0, 0), d = o, throughput = o;
@@ -1328,11 +1360,10 @@ __global__ void __launch_bounds__(kRenderBlock, 6) streams_level_kernel(const Re
     };
 
     for (;;) {
-        // ---- refill: idle lanes take the next items of the wave's current chunk
+        // ---- refill: idle lanes take the next items of the wave's current chunk.  The block runs for the whole wave
+        // whenever it runs, so it waits until kRefillBatch lanes are idle -- or nothing else is in flight.
         const unsigned long long idle = __ballot(!has_ray);
-        if (idle && chunk < n_chunks) {                       // wave-uniform
-            const unsigned int chunk_len = FIRST ? (n_px - (chunk % cps) * 64u < 64u ? n_px - (chunk % cps) * 64u : 64u)
-                                                 : (n_in - chunk * 64u < 64u ? n_in - chunk * 64u : 64u);
+        if (chunk < n_chunks && ((unsigned int)__builtin_popcountll(idle) >= kRefillBatch || (idle && !~idle))) {   // wave-uniform
             const unsigned int want = (unsigned int)__builtin_popcountll(idle), avail = chunk_len - taken;
             const unsigned int take = want < avail ? want : avail;
             const unsigned int rank = (unsigned int)__builtin_popcountll(idle & below);
@@ -1341,15 +1372,15 @@ __global__ void __launch_bounds__(kRenderBlock, 6) streams_level_kernel(const Re
                 if (FIRST) {
                     // initialState (Trace.hs:158-162); sample j of the batch starts from the pixel's seed advanced by j
                     // draws, which is what j applications of updateSeed leave behind (Trace.hs:190-191)
-                    const unsigned int j = chunk / cps;
-                    pixel = (chunk % cps) * 64u + k;
-                    const int local_row = (int)(pixel / (unsigned int)a.width);
-                    const int col = (int)(pixel - (unsigned int)local_row * (unsigned int)a.width);
+                    pixel = chunk_px0 + k;
+                    unsigned int col = chunk_col0 + k, row = chunk_row0;
+                    while (col >= (unsigned int)a.width) { col -= (unsigned int)a.width; ++row; }
+                    const int image_row = a.n_parts == 1 ? (int)row : global_row((int)row, a.stripe_rows, a.n_parts, a.part);
                     o = a.cam.pos;
-                    d = primary_direction(a.cam, col, global_row(local_row, a.stripe_rows, a.n_parts, a.part));
+                    d = primary_direction(a.cam, (int64_t)col, (int64_t)image_row);
                     throughput = mk(1.0f, 1.0f, 1.0f);
                     seed.a = a.planes.sa[pixel]; seed.b = a.planes.sb[pixel]; seed.c = a.planes.sc[pixel]; seed.counter = a.planes.sctr[pixel];
-                    for (unsigned int q = 0; q < j; ++q) (void)random_float(seed);
+                    for (unsigned int q = 0; q < chunk_j; ++q) (void)random_float(seed);
                     depth = 0; hits = 0; has_ray = true;
                 } else {
                     const unsigned int i = chunk * 64u + k;
@@ -1364,7 +1395,7 @@ __global__ void __launch_bounds__(kRenderBlock, 6) streams_level_kernel(const Re
                 }
             }
             taken += take;
-            if (taken >= chunk_len) { chunk += G; taken = 0; }
+            if (taken >= chunk_len) { chunk += G; taken = 0; open_chunk(); }
         }
         if (!__any(has_ray)) {
             if (chunk >= n_chunks) break;

@@ -154,7 +154,13 @@ enum {
     PTMI_OPT_STREAM_CAPACITY = 3,
     /* PTMI_FORM_AUTO (default): the per-pixel kernels (one lane walks its pixel's rays; with GLASS: its ray trees).
      * PTMI_FORM_STREAM: rays travel through compacted streams in HBM, one traceStep launch per level ("wavefront"). */
-    PTMI_OPT_STREAMS_FORM = 4
+    PTMI_OPT_STREAMS_FORM = 4,
+    /* Stream form only: how many samples of every pixel share one stream (one `awhile` loop).  0 (default) = automatic:
+     * ONE for scenes without GLASS, which keeps a pixel's additions in sample order (bit-identical to the per-pixel
+     * kernels), up to 16 -- memory permitting -- with GLASS, where the order is undefined anyway.  A value > 1 without
+     * GLASS trades that order for fewer, longer launches: colours then agree to rounding only (Accelerate's `permute`
+     * does not define the order either); the RNG planes stay exact. */
+    PTMI_OPT_STREAM_BATCH = 5
 };
 enum { PTMI_SEED_KEEP_ACCUMULATOR = 0, PTMI_SEED_FROM_RESULT = 1 };
 enum { PTMI_FORM_AUTO = 0, PTMI_FORM_STREAM = 1 };

@@ -89,3 +89,24 @@ def test_inline_refuses_glass(ctx, pkg):
     assert e.value.code == -1
     ctx.render(pkg.world.initial_camera(), 8, 1, pkg.STREAMS)
     ctx.synchronize()
+
+
+def test_stream_batch_option_trades_order_for_longer_launches(ctx, pkg, ora):
+    """PTMI_OPT_STREAM_BATCH > 1 without GLASS: several samples of a pixel share one stream, so the order of a pixel's
+    additions is no longer the sample order -- colours agree to rounding, the RNG planes stay exact, nothing is lost."""
+    B = pkg.binding
+    scene = pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    w, h, spp = 120, 67, 7
+    start = initial_planes(ora, w, h)
+    ctx.set_option(B.OPT_STREAM_BATCH, 4)
+    try:
+        got, st = render(ctx, pkg, scene, cam, w, h, spp, start, stream_form=True)
+    finally:
+        ctx.set_option(B.OPT_STREAM_BATCH, 0)
+    want, live = ora.render_streams(scene[0], scene[1], cam, w, h, CAP, spp, start)
+    for a, b in zip(got[3:], want[3:]):
+        assert np.array_equal(a, b)
+    assert st["live_bounces"] == live and st["stream_rays_dropped"] == 0 and st["stream_rays_truncated"] == 0
+    for a, b in zip(got[:3], want[:3]):
+        assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) <= REL_TOL

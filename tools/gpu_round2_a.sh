@@ -1,8 +1,7 @@
 #!/bin/bash
-# GPU pass: bench lines of the Streams forms
 set -o pipefail
-ROOT=$(pwd); OUT=$ROOT/gpurun_out/r02b; rm -rf "$OUT"; mkdir -p "$OUT"
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/r02c; rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp; cd "$ROOT"
-for args in "--scene glass --algorithm streams" "--scene glass --algorithm streams --streams-form stream" "--algorithm streams --streams-form stream" "--algorithm streams"; do
-  timeout -k 10 120 python bench.py $args --steps 5 --warmup 2 --no-cpu-baseline 2>> "$OUT/bench.log" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['config']['workload'][:60], d['roofline']['kernel'], d['ms_per_step'])" | tee -a "$OUT/bench_streams.txt"
-done
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$OUT/s16_stream" --output-format csv -- python3 bench.py --algorithm streams --streams-form stream --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/a.json" 2> "$OUT/a.log"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$OUT/glass_stream" --output-format csv -- python3 bench.py --scene glass --algorithm streams --streams-form stream --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/b.json" 2> "$OUT/b.log"
+find "$OUT" -name "*kernel_stats.csv" | while read f; do echo "== $f"; head -8 "$f"; done
