@@ -611,7 +611,7 @@ int ptmi_set_variant(ptmi_ctx *c, int variant)
 {
     if (!c) return PTMI_EINVAL;
     std::lock_guard<std::mutex> lock(c->mu);
-    if (variant < 0 || variant > 17) return fail(c, PTMI_EINVAL, "unknown variant");
+    if (variant < 0 || variant > 18) return fail(c, PTMI_EINVAL, "unknown variant");
     c->variant = variant;
     return PTMI_OK;
 }

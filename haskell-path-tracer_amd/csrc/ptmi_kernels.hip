@@ -267,6 +267,33 @@ __device__ __forceinline__ void shade_first(ScenePtr M, int idx, V3 hit_pos, V3 
     throughput = scale_r(mk(ma.x, ma.y, ma.z), brdf * next_ray_prob);
 }
 
+// Is the shade that is about to happen CERTAIN to leave a throughput that the next prepareRay freezes (nearZero,
+// Trace.hs:364-365) -- whatever the three random draws turn out to be?  If so its `next` ray and throughput are never
+// looked at again: the only things the reference keeps from that iteration are result += emittance * throughput and
+// the seed after genVec's three draws (Trace.hs:374-383), and the expensive half of the shade (three sin/cos pairs,
+// the quaternion, the rotation) can be skipped without changing any output bit.
+// Bound: next = rotate q axis with |q| = 1 up to rounding, so |next . axis| <= |axis|^2 (1 + 2e-5) <= a2 below; hence
+// |brdf| <= bmax (Matte: |p/pi| a2, Glossy: max(0, nd) <= a2) by monotonicity of rounding, |tmod_c| <= |color_c| (bmax prob)
+// and |throughput'_c| <= |throughput_c| (|color_c| g), formed in the SAME association as the real product so that it
+// overflows exactly when the real one can; 1 % of slack covers the four roundings of the real dot product.  Every
+// comparison is written so that a NaN or an infinity anywhere answers "not certain".
+__device__ __forceinline__ bool surely_frozen_after(float4 ma, float4 mb, V3 axis, V3 throughput)
+{
+    const bool matte = f2u(mb.x) == 0u;
+    const float a2 = dot(axis, axis) * 1.001f + 1e-30f;             // >= |next . axis|, also when the products are denormal
+    const float bmax = matte ? __builtin_fabsf(mb.z) * a2 : a2;
+    const float g = bmax * (1.0f / (kPi * 2.0f));
+    const V3 v = throughput * scale_r(mk(ma.x, ma.y, ma.z), g);
+    return dot(v, v) * 1.01f <= 1e-6f;
+}
+
+// What the reference keeps of an iteration whose throughput is frozen right afterwards: the contribution and the seed.
+__device__ __forceinline__ void finish_frozen(float4 ma, V3 throughput, V3 &result, Sfc32 &seed)
+{
+    result = result + (scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);
+    (void)sfc32_next(seed); (void)sfc32_next(seed); (void)sfc32_next(seed);     // genVec's three draws
+}
+
 __device__ __forceinline__ int global_row(int local_row, int stripe_rows, int n_parts, int part)
 {
     return ((local_row / stripe_rows) * n_parts + part) * stripe_rows + local_row % stripe_rows;
@@ -331,16 +358,17 @@ __host__ inline unsigned int tile_grid(const RenderArgs &a, int tw)
 // ---------------------------------------------------------------------------------------
 // render Inline.  LDS_SCENE: primitives staged in LDS (default) or read straight from
 // global memory through scalar loads (ablation).  MODE selects the loop shape:
-//   kCached      (default) primary hit evaluated once per pixel, two shade rounds per trace round
+//   kCached      (default) primary hit evaluated once per pixel; loop [finish frozen shades + restart][shade][trace]
+//   kCachedR1    round 1's default: primary hit cached, two shade rounds per trace round, every shade in full
 //   kRegenerate  lanes start their next sample as soon as a path ends, one shade per trace
 //   kLockstep    all lanes of the wave run sample s together (what a per-sample launch would do)
 // ---------------------------------------------------------------------------------------
-enum { kCached = 0, kRegenerate = 1, kLockstep = 2 };
+enum { kCached = 0, kRegenerate = 1, kLockstep = 2, kCachedR1 = 3 };   // kCachedR1: round 1's loop [shade][shade][trace], without the frozen-shade shortcut (ablation)
 
 template <bool LDS_SCENE, int MODE, int TILE_W = 0>
-__global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_inline_kernel(const RenderArgs a)
+__global__ void __launch_bounds__(kRenderBlock, (MODE == kCached || MODE == kCachedR1) ? 6 : 4) render_inline_kernel(const RenderArgs a)
 {
-    __shared__ float pixel_const[MODE == kCached ? 19 : 1][kRenderBlock];   // kCached: per-lane restart record (see below)
+    __shared__ float pixel_const[(MODE == kCached || MODE == kCachedR1) ? 19 : 1][kRenderBlock];   // kCached: per-lane restart record (see below)
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -374,13 +402,16 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_
         if (limit <= 0) {
             // iterate 0: every sample returns (0, seed); new + old
             if (n_spp > 0) acc = mk(0.0f, 0.0f, 0.0f) + acc;
-        } else if (MODE == kCached) {
+        } else if (MODE == kCached || MODE == kCachedR1) {
+            constexpr bool kFinish = MODE == kCached;
             // primaryRays has no sub-pixel jitter (Trace.hs:244-262): every sample of a pixel shoots the
             // same primary ray, so its checkHit + hit are evaluated ONCE per pixel and every sample starts
             // from that record.  A sample then costs k shades and k-1 traces (k = its live bounces).
-            // Loop shape: [shade][shade again for lanes whose sample just ended][trace].  A lane that
-            // ends a sample in the first shade round starts the next one in the second, so all lanes
-            // enter the trace round with a ray and the expensive round runs at full occupancy.
+            // Loop shape (kCached): [shade][trace], where the shade round first FINISHES the shades whose outcome the next
+            // prepareRay is certain to freeze (emittance + three draws, no sin/cos, no rotation) and restarts those lanes
+            // on their next sample, so that they take part in the round's full shade with it.  A sample whose path ends
+            // that way -- 64 % of them on C2 -- then costs k-1 full shades and k-1 traces, exactly one of each per trip.
+            // Loop shape (kCachedR1, round 1): [shade][shade again for lanes whose sample just ended][trace], all in full.
             const HitSel h0 = check_hit(S, ns, np, origin, primary);
             if (!h0.just) {
                 if (n_spp > 0) acc = mk(0.0f, 0.0f, 0.0f) + acc;     // every sample: result 0, seed untouched
@@ -420,7 +451,7 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_
                     pending = s < n_spp;
                 };
 #ifdef PTMI_PHASE_STATS
-                unsigned int st_iter = 0, st_a = 0, st_b = 0, st_c = 0;   // this lane's participation per round
+                unsigned int st_iter = 0, st_a = 0, st_b = 0, st_c = 0, st_f = 0;   // this lane's participation per round
 #endif
 #ifdef PTMI_PHASE_STATS
                 unsigned long long cyc_a = 0, cyc_b = 0, cyc_c = 0;
@@ -431,23 +462,49 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_
                     ++st_iter;
                     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
 #endif
-                    // round A: whatever hit is pending
+                    // round A: whatever hit is pending.  First the shades whose outcome is certain to be frozen by the next
+                    // prepareRay (the iteration limit, or a throughput that cannot stay above nearZero: surely_frozen_after)
+                    // -- 29 % of all shades on C2: they only add their emittance and advance the seed, and the lane starts its
+                    // pixel's next sample AT ONCE, so that it takes part in this round's full shade with that sample.
                     if (pending && !has_ray) {
 #ifdef PTMI_PHASE_STATS
                         ++st_a;
 #endif
-                        shade(M, idx, pos, normal, pos, d, throughput, result, seed);
-                        ++it; ++live;
-                        // the next prepareRay would freeze the path (Trace.hs:364-365)
-                        if (it >= limit || near_zero(throughput)) restart();
-                        else { pending = false; has_ray = true; }
+                        float4 mb = M[2 * idx + 1];
+                        V3 axis; float hk;
+                        bounce_axis(mb, normal, d, axis, hk);
+                        if (kFinish) {
+                            const float4 ma = M[2 * idx];
+                            if (it + 1 >= limit || surely_frozen_after(ma, mb, axis, throughput)) {
+                                finish_frozen(ma, throughput, result, seed);
+                                ++it; ++live;
+#ifdef PTMI_PHASE_STATS
+                                ++st_f;
+#endif
+                                restart();                             // the cached primary hit: its axis and half-angle scale are cached too
+                                mb = M[2 * idx0 + 1];
+                                axis = mk(get(12), get(13), get(14)); hk = get(15);
+                            }
+                        }
+                        if (pending) {
+                            V3 next; float brdf;
+                            next_about_axis(mb, axis, hk, seed, next, brdf);
+                            apply_bounce(M, idx, pos, next, brdf, pos, d, throughput, result);
+                            ++it; ++live;
+                            // the next prepareRay would freeze the path (Trace.hs:364-365)
+                            if (it >= limit || near_zero(throughput)) restart();
+                            else { pending = false; has_ray = true; }
+                        }
                     }
 #ifdef PTMI_PHASE_STATS
                     { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); cyc_a += t_now - t_prev; t_prev = t_now; }
 #endif
                     // round B: only lanes that restarted in round A get here with a pending hit, and that hit is the
                     // cached primary hit with result 0 and throughput 1: the specialised first shade
-                    if (pending && !has_ray) {
+                    // (With the frozen-shade shortcut above, 87 % of the restarts happen BEFORE round A's full shade; running a
+                    // second round for the few that happen after it -- an unpredicted nearZero -- costs more than letting
+                    // those lanes wait for the next trip: C2 3.11 ms without it, 3.17 when run for >= 16 lanes, 3.77 always.)
+                    if (!kFinish && pending && !has_ray) {
 #ifdef PTMI_PHASE_STATS
                         ++st_b;
 #endif
@@ -491,7 +548,7 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? 6 : 4) render_
                     unsigned int mx = st_iter;
                     for (int off = 32; off > 0; off >>= 1) { const unsigned int o2 = __shfl_xor(mx, off, 64); mx = o2 > mx ? o2 : mx; }
                     atomicAdd(a.work_counter + 1, st_iter); atomicAdd(a.work_counter + 2, st_a);
-                    atomicAdd(a.work_counter + 3, st_b); atomicAdd(a.work_counter + 4, st_c);
+                    atomicAdd(a.work_counter + 3, st_b); atomicAdd(a.work_counter + 4, st_c); atomicAdd(a.work_counter + 6, st_f);
                     if ((threadIdx.x & 63) == (int)__builtin_ctzll(m)) {
                         atomicAdd(a.work_counter + 5, mx * 64u);
                         // wave cycles spent in rounds A, B, C (the waves of a SIMD interleave, so these are shares, not costs)
@@ -995,24 +1052,25 @@ __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const R
             };
             while (pending) {
                 ++trips;
-                // round A: whatever hit is pending
+                // shade round.  A ray whose throughput is already near zero dies at this hit (numNewRays, Trace.hs:329-331):
+                // the hit still adds its emittance (computeResult runs for every intersection) and nothing else of it
+                // survives -- no child, and the ray's seed is discarded -- so such lanes skip the three sin/cos pairs and the
+                // rotation, end their sample and take part in THIS round's full shade with the pixel's next sample.
                 if (pending && !has_ray) {
-                    const bool dead = near_zero(throughput), capped = steps + 1u >= step_cap;
-                    // results: colour += emittance * throughput for EVERY hit; then the new ray (if any)
-                    shade(M, idx, pos, normal, pos, d, throughput, acc, seed);
-                    ++steps;
-                    if (!dead) ++live;                             // the child exists even if the cap then cuts it
-                    if (dead || capped) { cut += (!dead && capped) ? 1u : 0u; end_sample(); }
-                    else { pending = false; has_ray = true; }
-                }
-                // round B: only lanes whose sample ended in round A; their hit is the cached primary hit and their
-                // throughput is 1 (never near zero): the specialised first shade
-                if (pending && !has_ray) {
-                    shade_first<true>(M, idx0, pos, mk(get(9), get(10), get(11)), get(12), mk(get(13), get(14), get(15)),
-                                      pos, d, throughput, acc, seed);
-                    ++steps; ++live;
-                    if (steps >= step_cap) { ++cut; end_sample(); }
-                    else { pending = false; has_ray = true; }
+                    if (near_zero(throughput)) {
+                        const float4 ma = M[2 * idx];
+                        acc = acc + (scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);
+                        ++steps;
+                        end_sample();
+                    }
+                    if (pending) {                                 // alive: a fresh sample starts with throughput 1
+                        const bool capped = steps + 1u >= step_cap;
+                        // results: colour += emittance * throughput for EVERY hit; then the new ray
+                        shade(M, idx, pos, normal, pos, d, throughput, acc, seed);
+                        ++steps; ++live;                           // the child exists even if the cap then cuts it
+                        if (capped) { ++cut; end_sample(); }
+                        else { pending = false; has_ray = true; }
+                    }
                 }
                 if (has_ray) {
                     const HitSel h = check_hit(S, ns, np, pos, d);
@@ -1192,42 +1250,44 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
             };
             while (pending || has_ray) {
                 ++trips;
-                // two shade rounds: a lane whose tree ended in the first starts its next sample (the cached primary hit) in the second
-                for (int round = 0; round < 2; ++round) {
-                    if (pending && !has_ray) {
-                        const float4 ma = M[2 * idx], mb = M[2 * idx + 1];
-                        const bool dead = near_zero(throughput), capped = steps + 1u >= step_cap;   // numNewRays (Trace.hs:329-331)
-                        if (f2u(mb.x) == 2u) {                    // GLASS: two children (extension; spec = the oracle's glass_children)
-                            acc = acc + (scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);           // computeResult (Trace.hs:318-323)
-                            ++steps;
-                            if (dead) { lineage_ended(); }
-                            else {
-                                V3 ko[2], kd[2], kt[2]; Sfc32 ks[2];
-                                glass_children(mk(ma.x, ma.y, ma.z), mb.y, pos, normal, d, throughput, seed, ko, kd, kt, ks);
-                                live += 2u;
-                                if (capped) { cut += 2u; lineage_ended(); }
-                                else {
-                                    if (sp < kTreeStackDepth) {
-                                        const uint32_t e[14] = {f2u(ko[1].x), f2u(ko[1].y), f2u(ko[1].z), f2u(kd[1].x), f2u(kd[1].y), f2u(kd[1].z),
-                                                                f2u(kt[1].x), f2u(kt[1].y), f2u(kt[1].z), ks[1].a, ks[1].b, ks[1].c, ks[1].counter, steps};
-                                        if (sp == 0) { for (int q = 0; q < 14; ++q) bottom[q * kRenderBlock] = e[q]; }
-                                        else         { for (int q = 0; q < 14; ++q) stack_w[sp - 1][q] = e[q]; }
-                                        ++sp;
-                                    } else {
-                                        ++dropped;
-                                    }
-                                    pos = ko[0]; d = kd[0]; throughput = kt[0]; seed = ks[0];
-                                    pending = false; has_ray = true;
-                                }
+                // shade round.  A ray whose throughput is already near zero dies at this hit (numNewRays): the hit adds its
+                // emittance and nothing else of it survives, so such lanes skip the expensive half, resume their most recent
+                // waiting child or start the pixel's next sample, and -- in the latter case -- take part in this round's full shade.
+                if (pending && !has_ray && near_zero(throughput)) {
+                    const float4 ma = M[2 * idx];
+                    acc = acc + (scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);   // computeResult (Trace.hs:318-323)
+                    ++steps;
+                    lineage_ended();
+                }
+                if (pending && !has_ray) {                         // alive
+                    const float4 ma = M[2 * idx], mb = M[2 * idx + 1];
+                    const bool capped = steps + 1u >= step_cap;
+                    if (f2u(mb.x) == 2u) {                        // GLASS: two children (extension; spec = the oracle's glass_children)
+                        acc = acc + (scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);
+                        ++steps;
+                        V3 ko[2], kd[2], kt[2]; Sfc32 ks[2];
+                        glass_children(mk(ma.x, ma.y, ma.z), mb.y, pos, normal, d, throughput, seed, ko, kd, kt, ks);
+                        live += 2u;
+                        if (capped) { cut += 2u; lineage_ended(); }
+                        else {
+                            if (sp < kTreeStackDepth) {
+                                const uint32_t e[14] = {f2u(ko[1].x), f2u(ko[1].y), f2u(ko[1].z), f2u(kd[1].x), f2u(kd[1].y), f2u(kd[1].z),
+                                                        f2u(kt[1].x), f2u(kt[1].y), f2u(kt[1].z), ks[1].a, ks[1].b, ks[1].c, ks[1].counter, steps};
+                                if (sp == 0) { for (int q = 0; q < 14; ++q) bottom[q * kRenderBlock] = e[q]; }
+                                else         { for (int q = 0; q < 14; ++q) stack_w[sp - 1][q] = e[q]; }
+                                ++sp;
+                            } else {
+                                ++dropped;
                             }
-                        } else {
-                            // results: colour += emittance * throughput for EVERY hit; then the new ray (if any)
-                            shade(M, idx, pos, normal, pos, d, throughput, acc, seed);
-                            ++steps;
-                            if (!dead) ++live;
-                            if (dead || capped) { cut += (!dead && capped) ? 1u : 0u; lineage_ended(); }
-                            else { pending = false; has_ray = true; }
+                            pos = ko[0]; d = kd[0]; throughput = kt[0]; seed = ks[0];
+                            pending = false; has_ray = true;
                         }
+                    } else {
+                        // results: colour += emittance * throughput for EVERY hit; then the new ray
+                        shade(M, idx, pos, normal, pos, d, throughput, acc, seed);
+                        ++steps; ++live;
+                        if (capped) { ++cut; lineage_ended(); }
+                        else { pending = false; has_ray = true; }
                     }
                 }
                 if (has_ray) {
@@ -1717,6 +1777,10 @@ hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t st
         if (e != hipSuccess) return e;
         if (variant == 1) hipLaunchKernelGGL((render_inline_persistent_kernel<true>), dim3(blocks), block, lds, stream, a);
         else              hipLaunchKernelGGL((render_inline_persistent_kernel<false>), dim3(blocks), block, 0, stream, a);
+        return hipGetLastError();
+    }
+    if (variant == 18) {                                      // round 1's loop (no frozen-shade shortcut), 8x8 tiles, LDS scene
+        hipLaunchKernelGGL((render_inline_kernel<true, kCachedR1, 8>), dim3(tile_grid(a, 8)), block, lds, stream, a);
         return hipGetLastError();
     }
     if (variant == 17) {
