@@ -11,5 +11,5 @@ The directory name is not a Python identifier; load it with __graft_entry__.load
 """
 from . import _build, world  # noqa: F401
 from . import binding  # noqa: F401
-from .binding import Context, PtmiError, SYMBOLS, load_library  # noqa: F401
+from .binding import Context, Group, PtmiError, SYMBOLS, load_library  # noqa: F401
 from .world import INLINE, STREAMS, MATTE, GLOSSY, GLASS  # noqa: F401

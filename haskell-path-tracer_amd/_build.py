@@ -11,10 +11,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libptmi.so")
-SOURCES = ["ptmi_api.cpp", "ptmi_stage.cpp", "ptmi_kernels.hip"]
+SOURCES = ["ptmi_api.cpp", "ptmi_stage.cpp", "ptmi_group.cpp", "ptmi_kernels.hip"]
 HEADERS = ["ptmi_core.h", "ptmi_kernels.h", "ptmi_stage.h", os.path.join("..", "..", "include", "ptmi.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-fno-fast-math", "-fno-slp-vectorize", "-DPTMI_SINCOS_FUSED=1", "-Wall", "-pthread"]
+         "-fno-fast-math", "-fno-slp-vectorize", "-DPTMI_SINCOS_FUSED=1", "-Wall", "-pthread", "-ldl"]
 
 
 def hipcc_path():

@@ -41,6 +41,7 @@ SYMBOLS = {
     "ptmi_local_rows": (C.c_int, [_vp]),
     "ptmi_global_row": (C.c_int, [_vp, C.c_int]),
     "ptmi_bind_planes": (C.c_int, [_vp] + [_vp] * 7),
+    "ptmi_get_planes": (C.c_int, [_vp] + [C.POINTER(_vp)] * 7),
     "ptmi_set_stream": (C.c_int, [_vp, _vp]),
     "ptmi_set_timing": (C.c_int, [_vp, C.c_int]),
     "ptmi_set_variant": (C.c_int, [_vp, C.c_int]),
@@ -56,7 +57,24 @@ SYMBOLS = {
     "ptmi_synchronize": (C.c_int, [_vp]),
     "ptmi_render1": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp] + [_vp] * 14),
     "ptmi_present": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "ptmi_snapshot_color": (C.c_int, [_vp, _vp, _vp]),
     "ptmi_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "ptmi_group_create": (C.c_int, [C.POINTER(_vp), _i32p, C.c_int, C.c_int]),
+    "ptmi_group_destroy": (None, [_vp]),
+    "ptmi_group_size": (C.c_int, [_vp]),
+    "ptmi_group_member": (_vp, [_vp, C.c_int]),
+    "ptmi_group_last_error": (C.c_char_p, [_vp]),
+    "ptmi_group_set_scene": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int]),
+    "ptmi_group_resize": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "ptmi_group_init_output": (C.c_int, [_vp, C.c_uint64]),
+    "ptmi_group_reseed": (C.c_int, [_vp, C.c_uint64]),
+    "ptmi_group_render": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
+    "ptmi_group_synchronize": (C.c_int, [_vp]),
+    "ptmi_group_download_color": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "ptmi_group_gather_color": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "ptmi_group_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "ptmi_partition_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ptmi_partition_global_row": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ptmi_reset_stats": (C.c_int, [_vp]),
     "ptmi_debug_counters": (C.c_int, [_vp, _vp]),
     "ptmi_eval_distance_to_sphere": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
@@ -185,6 +203,12 @@ class Context:
         self._check(self._lib.ptmi_bind_planes(self._h, *([None] * 7)))
         self._keep = []
 
+    def device_planes(self):
+        """Device addresses (ints) of the seven planes the context renders into."""
+        ptrs = [_vp() for _ in range(7)]
+        self._check(self._lib.ptmi_get_planes(self._h, *[C.byref(p) for p in ptrs]))
+        return [p.value for p in ptrs]
+
     def set_stream(self, hip_stream):
         self._check(self._lib.ptmi_set_stream(self._h, _vp(hip_stream) if hip_stream else None))
 
@@ -297,3 +321,86 @@ class Context:
         s, c = np.empty_like(x), np.empty_like(x)
         self._check(self._lib.ptmi_eval_sincos(self._h, _ptr(x), x.size, _ptr(s), _ptr(c)))
         return s, c
+
+
+class Group:
+    """One ptmi_group: the GPUs of a node behind one host process (include/ptmi.h, "groups")."""
+
+    def __init__(self, devices, stripe_rows=0):
+        self._lib = load_library()
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        h = _vp()
+        rc = self._lib.ptmi_group_create(C.byref(h), devs.ctypes.data_as(_i32p), devs.size, int(stripe_rows))
+        if rc != PTMI_OK:
+            raise PtmiError(rc, (self._lib.ptmi_last_error(None) or b"").decode())
+        self._h = h
+        self.width = self.height = 0
+
+    def _check(self, rc):
+        if rc != PTMI_OK:
+            raise PtmiError(rc, (self._lib.ptmi_group_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ptmi_group_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def size(self):
+        return self._lib.ptmi_group_size(self._h)
+
+    def member(self, i):
+        """A non-owning Context view of member i (do not close it)."""
+        c = Context.__new__(Context)
+        c._lib, c._h, c._keep = self._lib, _vp(self._lib.ptmi_group_member(self._h, i)), []
+        c.width, c.height = self.width, self.height
+        c.close = lambda: None
+        return c
+
+    def set_scene(self, spheres, planes):
+        s = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
+        p = np.ascontiguousarray(planes, dtype=PLANE_DTYPE)
+        self._check(self._lib.ptmi_group_set_scene(self._h, _ptr(s) if s.size else None, s.size, _ptr(p) if p.size else None, p.size))
+
+    def resize(self, width, height):
+        self._check(self._lib.ptmi_group_resize(self._h, width, height))
+        self.width, self.height = width, height
+
+    def init_output(self, seed0):
+        self._check(self._lib.ptmi_group_init_output(self._h, C.c_uint64(seed0)))
+
+    def reseed(self, seed0):
+        self._check(self._lib.ptmi_group_reseed(self._h, C.c_uint64(seed0)))
+
+    def render(self, camera, bounce_limit, n_spp, algorithm=INLINE):
+        cam = np.ascontiguousarray(camera, dtype=CAMERA_DTYPE)
+        self._check(self._lib.ptmi_group_render(self._h, _ptr(cam), algorithm, bounce_limit, n_spp))
+
+    def synchronize(self):
+        self._check(self._lib.ptmi_group_synchronize(self._h))
+
+    def download_color(self):
+        out = [np.empty((self.height, self.width), np.float32) for _ in range(3)]
+        self._check(self._lib.ptmi_group_download_color(self._h, *[_ptr(a) for a in out]))
+        return tuple(out)
+
+    def gather_color(self, root, r_dev, g_dev, b_dev):
+        """r_dev, g_dev, b_dev: device pointers (int) of [height][width] float planes on member `root`'s device."""
+        self._check(self._lib.ptmi_group_gather_color(self._h, int(root), _vp(r_dev), _vp(g_dev), _vp(b_dev)))
+
+    def stats(self):
+        st = Stats()
+        self._check(self._lib.ptmi_group_get_stats(self._h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in Stats._fields_}

@@ -44,7 +44,7 @@ struct ptmi_ctx {
     uint64_t nominal = 0, samples = 0;
 
     bool timing = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_snap = nullptr;
     bool ev_valid = false;
     int variant = 0;
     Stager stager;                          // pinned ring + worker threads for host-buffer entry points (ptmi_stage.h)
@@ -455,6 +455,7 @@ int ptmi_create(ptmi_ctx **out, int device)
     c->stream = c->own_stream;
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&c->ev_snap, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc(&c->d_live, sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc(&c->d_work, 64 * sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc(&c->d_iters, sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMalloc");
@@ -488,6 +489,7 @@ void ptmi_destroy(ptmi_ctx *c)
     if (c->d_quad_class) (void)hipFree(c->d_quad_class);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_snap) (void)hipEventDestroy(c->ev_snap);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -584,6 +586,17 @@ int ptmi_bind_planes(ptmi_ctx *c, float *r, float *g, float *b, uint32_t *sa, ui
     if (n_null != 0) return fail(c, PTMI_EINVAL, "bind either all seven planes or none");
     c->bound = Planes{r, g, b, sa, sb, sc, sctr};
     c->use_bound = true;
+    return PTMI_OK;
+}
+
+int ptmi_get_planes(ptmi_ctx *c, float **r, float **g, float **b, uint32_t **sa, uint32_t **sb, uint32_t **sc, uint32_t **sctr)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (c->width <= 0) return fail(c, PTMI_ESTATE, "ptmi_resize has not been called");
+    const Planes &p = active(c);
+    if (r) *r = p.r; if (g) *g = p.g; if (b) *b = p.b;
+    if (sa) *sa = p.sa; if (sb) *sb = p.sb; if (sc) *sc = p.sc; if (sctr) *sctr = p.sctr;
     return PTMI_OK;
 }
 
@@ -817,6 +830,26 @@ int ptmi_present(ptmi_ctx *c, int iterations, float *rgb32f_out, uint8_t *rgba8_
     if (rgb32f_out) out[n_out++] = CopySpan{d_rgb, rgb32f_out, n * 12};
     if (rgba8_out) out[n_out++] = CopySpan{d_rgba, rgba8_out, n * 4};
     PTMI_HIP(c, copy_to_host(c, out, n_out));
+    return PTMI_OK;
+}
+
+int ptmi_snapshot_color(ptmi_ctx *c, float *dst_device, void *hip_stream)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (c->width <= 0) return fail(c, PTMI_ESTATE, "ptmi_resize has not been called");
+    if (!dst_device) return fail(c, PTMI_EINVAL, "dst_device is NULL");
+    PTMI_HIP(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->rows_local * c->width * 4;
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    if (s != c->stream) {                                      // order the copy behind the renders already issued
+        PTMI_HIP(c, hipEventRecord(c->ev_snap, c->stream));
+        PTMI_HIP(c, hipStreamWaitEvent(s, c->ev_snap, 0));
+    }
+    Planes &p = active(c);
+    const float *src[3] = {p.r, p.g, p.b};
+    for (int k = 0; k < 3 && bytes; ++k)
+        PTMI_HIP(c, hipMemcpyAsync(reinterpret_cast<char *>(dst_device) + (size_t)k * bytes, src[k], bytes, hipMemcpyDeviceToDevice, s));
     return PTMI_OK;
 }
 

@@ -94,6 +94,9 @@ hipError_t launch_eval_sphere(const float *spheres10, const float *rays, int n,
                               int32_t *is_just, float *t, float *normalp, hipStream_t stream);
 hipError_t launch_eval_plane(const float *planes12, const float *rays, int n,
                              int32_t *is_just, float *t, float *normalp, hipStream_t stream);
+// group read-out: member `part`'s snapshot [3][rows][W] (stripes contiguous) into the whole image's planes [H][W]
+hipError_t launch_stitch(const float *src, int rows, int width, int stripe_rows, int n_parts, int part,
+                         float *r, float *g, float *b, hipStream_t stream);
 hipError_t launch_present(Planes p, long long n, int iterations, float *rgb, uint32_t *rgba, hipStream_t stream);
 hipError_t launch_eval_sincos(const float *x, int n, float *s, float *c, hipStream_t stream);
 

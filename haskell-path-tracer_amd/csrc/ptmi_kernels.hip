@@ -1631,6 +1631,21 @@ __global__ void __launch_bounds__(kBlock) present_kernel(Planes p, long long n, 
 }
 
 // ---------------------------------------------------------------------------------------
+// stitch: a member's rows (local order) into the whole image's planes (group read-out).  16 bytes per lane when aligned.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) stitch_kernel(const float *src, int rows, int width, int stripe_rows, int n_parts, int part,
+                                                        float *r, float *g, float *b)
+{
+    const long long n = (long long)rows * width;
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int local_row = (int)(i / width);
+    const int col = (int)(i - (long long)local_row * width);
+    const long long o = (long long)global_row(local_row, stripe_rows, n_parts, part) * width + col;
+    r[o] = src[i]; g[o] = src[n + i]; b[o] = src[2 * n + i];
+}
+
+// ---------------------------------------------------------------------------------------
 // point queries: the reference's unit-test surface (test/Scene/Intersection/Tests.hs)
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) eval_sphere_kernel(const float *sph, const float *rays, int n,
@@ -1922,6 +1937,15 @@ hipError_t launch_present(Planes p, long long n, int iterations, float *rgb, uin
     const uintptr_t bits = (uintptr_t)p.r | (uintptr_t)p.g | (uintptr_t)p.b | (uintptr_t)rgb | (uintptr_t)rgba;
     hipLaunchKernelGGL(present_kernel, dim3(blocks_for((n + 3) / 4)), dim3(kBlock), 0, stream, p, n, (float)iterations, rgb, rgba,
                        (bits & 15u) == 0 ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_stitch(const float *src, int rows, int width, int stripe_rows, int n_parts, int part,
+                         float *r, float *g, float *b, hipStream_t stream)
+{
+    const long long n = (long long)rows * width;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(stitch_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, src, rows, width, stripe_rows, n_parts, part, r, g, b);
     return hipGetLastError();
 }
 

@@ -129,6 +129,10 @@ int ptmi_global_row(const ptmi_ctx *ctx, int local_row);     /* image row of a h
  * instead of the context's own; pass all NULL to return to the owned planes. */
 int ptmi_bind_planes(ptmi_ctx *ctx, float *r, float *g, float *b,
                      uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr);
+/* The device addresses of the seven planes the context currently renders into (its own or the bound ones), for
+ * interop: a collective, a graphics-API import, another kernel.  Any pointer argument may be NULL. */
+int ptmi_get_planes(ptmi_ctx *ctx, float **r, float **g, float **b,
+                    uint32_t **sa, uint32_t **sb, uint32_t **sc, uint32_t **sctr);
 /* Launch on this HIP stream (a hipStream_t cast to void*; NULL = the context's own). */
 int ptmi_set_stream(ptmi_ctx *ctx, void *hip_stream);
 /* Record HIP events around every ptmi_render on the launch stream (ptmi_stats.last_render_ms). */
@@ -217,11 +221,48 @@ int ptmi_render1(ptmi_ctx *ctx, const ptmi_camera *camera, int algorithm, int bo
  * The text overlay of the iteration counter (fs.glsl:15) is UI and not reproduced. */
 int ptmi_present(ptmi_ctx *ctx, int iterations, float *rgb32f_out, uint8_t *rgba8_out);
 
+/* The three colour planes of the held rows, copied device-to-device into ONE contiguous buffer [3][rows][W] on the
+ * context's device, ordered behind the renders already issued; the copy runs on `hip_stream` (a hipStream_t cast to
+ * void*; NULL = the context's launch stream), so a consumer (a collective, a display interop) can take it from there
+ * while the next render runs.  Asynchronous. */
+int ptmi_snapshot_color(ptmi_ctx *ctx, float *dst_device, void *hip_stream);
+
 int ptmi_get_stats(ptmi_ctx *ctx, ptmi_stats *out);   /* synchronises the launch stream */
 int ptmi_reset_stats(ptmi_ctx *ctx);
 /* Diagnostics: the 64 raw device counters (hand-out counter in [0]; a -DPTMI_PHASE_STATS build of the kernels
  * adds round statistics, see tools/phase_stats.py).  Synchronises the launch stream. */
 int ptmi_debug_counters(ptmi_ctx *ctx, uint32_t out[64]);
+
+/* ---- groups: the GPUs of one node behind ONE host process ------------------------ */
+/* The reference's host is a single process holding one compiled function (app/Main.hs:188-191); a group lets that
+ * process use several GPUs: the image is cut into stripes of `stripe_rows` rows (0 = 8) dealt round-robin to the
+ * devices (ptmi_set_partition), every member renders its rows without any exchange (seeds come from the global pixel
+ * index: the stitched planes equal the single-device image bit for bit), and the one exchange is the read-out of the
+ * colour planes -- to host planes for graphicsLoop (app/Main.hs:346-351), or to a root device over RCCL / xGMI.
+ * (SURVEY.md 8b proposed ptmi_create(out, device_first, n_devices); a group of contexts keeps ptmi_create unchanged.) */
+typedef struct ptmi_group ptmi_group;
+int         ptmi_group_create(ptmi_group **out, const int *devices, int n_devices, int stripe_rows);
+void        ptmi_group_destroy(ptmi_group *group);
+int         ptmi_group_size(const ptmi_group *group);
+ptmi_ctx   *ptmi_group_member(ptmi_group *group, int i);        /* member i's context (options, statistics, planes) */
+const char *ptmi_group_last_error(const ptmi_group *group);
+int ptmi_group_set_scene(ptmi_group *group, const ptmi_sphere *spheres, int n_spheres, const ptmi_plane *planes, int n_planes);
+int ptmi_group_resize(ptmi_group *group, int width, int height);
+int ptmi_group_init_output(ptmi_group *group, uint64_t seed0);
+int ptmi_group_reseed(ptmi_group *group, uint64_t seed0);
+/* ptmi_render on every member; asynchronous: all devices are busy before the call returns. */
+int ptmi_group_render(ptmi_group *group, const ptmi_camera *camera, int algorithm, int bounce_limit, int n_spp);
+int ptmi_group_synchronize(ptmi_group *group);
+/* The whole image's colour planes [height][width] into HOST planes: every member's rows come down through its own
+ * copy path, all members at once, and the stripes are stitched in place.  Synchronous. */
+int ptmi_group_download_color(ptmi_group *group, float *r, float *g, float *b);
+/* The whole image's colour planes into DEVICE planes [height][width] on member `root`'s device: RCCL grouped
+ * ncclSend / ncclRecv over xGMI (every peer has its own link to the root), then a stitch kernel.  Synchronous. */
+int ptmi_group_gather_color(ptmi_group *group, int root, float *r_device, float *g_device, float *b_device);
+int ptmi_group_get_stats(ptmi_group *group, ptmi_stats *sum);  /* sums (maxima for the time and step fields) over the members */
+/* The partition's arithmetic, usable without a device: rows part `part` holds, and the image row of one of them. */
+int ptmi_partition_rows(int height, int stripe_rows, int n_parts, int part);
+int ptmi_partition_global_row(int height, int stripe_rows, int n_parts, int part, int local_row);
 
 /* ---- point queries (the reference's unit-test surface) ------------------------ */
 /* Evaluates distanceTo / hit (src/Scene/Intersection.hs:16-64) on the DEVICE for n independent

@@ -1,0 +1,87 @@
+"""The multi-device entry of the C ABI (ptmi_group_*): partition arithmetic on the CPU; on the GPU a group's stitched
+read-out -- host planes and RCCL gather to a root device -- equals the ungrouped image bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_planes_equal
+
+
+def test_partition_arithmetic_matches_the_python_mirror(pkg):
+    """ptmi_partition_rows / ptmi_partition_global_row (no device needed) against parallel.StripePartition, and the
+    parts of any partition tile the image exactly once."""
+    from haskell_path_tracer_amd.parallel import StripePartition
+    lib = pkg.load_library()
+    for height, stripe, n_parts in [(2160, 10, 8), (2160, 8, 8), (1080, 8, 3), (67, 8, 5), (7, 8, 2), (600, 1, 4), (33, 5, 7)]:
+        seen = np.zeros(height, np.int32)
+        for part in range(n_parts):
+            p = StripePartition(height, n_parts, part, stripe)
+            rows = lib.ptmi_partition_rows(height, stripe, n_parts, part)
+            assert rows == p.local_rows
+            got = np.array([lib.ptmi_partition_global_row(height, stripe, n_parts, part, i) for i in range(rows)], np.int64)
+            assert np.array_equal(got, p.global_rows())
+            seen[got] += 1
+            assert lib.ptmi_partition_global_row(height, stripe, n_parts, part, rows) == -1
+        assert np.all(seen == 1)
+    assert lib.ptmi_partition_rows(0, 8, 2, 0) == -1 and lib.ptmi_partition_rows(10, 8, 2, 2) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,stripe", [([0], 0), ([0, 0], 8), ([0, 0, 0], 5)])
+def test_group_host_readout_equals_the_ungrouped_image(pkg, devices, stripe):
+    """A group of 1 member, and groups of 2 and 3 members that share the one GPU of the test box (each member is a
+    context of its own with its own partition, as on separate devices)."""
+    sp, pl = pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    w, h = 333, 131
+    with pkg.Context(0) as c:
+        c.set_scene(sp, pl)
+        c.resize(w, h)
+        c.init_output(7)
+        c.render(cam, 8, 3)
+        want = c.download_state()
+        live = c.stats()["live_bounces"]
+    with pkg.Group(devices, stripe) as g:
+        assert g.size == len(devices)
+        g.set_scene(sp, pl)
+        g.resize(w, h)
+        g.init_output(7)
+        g.render(cam, 8, 2)
+        g.render(cam, 8, 1)
+        g.synchronize()
+        got = g.download_color()
+        st = g.stats()
+        assert sum(g.member(i).local_rows for i in range(g.size)) == h
+    assert_planes_equal(got, want[:3], "group of %d, host read-out" % len(devices))
+    assert st["live_bounces"] == live and st["samples"] == w * h * 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_rccl", [False, True])
+def test_group_device_gather_one_member(pkg, monkeypatch, force_rccl):
+    """ptmi_group_gather_color on a 1-member group: with PTMI_GROUP_FORCE_RCCL=1 the planes really travel through
+    ncclSend / ncclRecv (to self) on a communicator made by ncclCommInitAll, then through the stitch kernel."""
+    if force_rccl:
+        monkeypatch.setenv("PTMI_GROUP_FORCE_RCCL", "1")
+    sp, pl = pkg.world.main_scene()
+    cam = pkg.world.initial_camera()
+    w, h = 200, 77
+    with pkg.Context(0) as c:
+        c.set_scene(sp, pl)
+        c.resize(w, h)
+        c.init_output(3)
+        c.render(cam, 15, 2)
+        want = c.download_color()
+    with pkg.Group([0]) as g:
+        g.set_scene(sp, pl)
+        g.resize(w, h)
+        g.init_output(3)
+        g.render(cam, 15, 2)
+        with pkg.Context(0) as out:                      # a second context lends its colour planes as the [h][w] destination
+            out.resize(w, h)
+            out.upload_state(*[np.full((h, w), -1.0, np.float32)] * 3)
+            r, gp, b = out.device_planes()[:3]
+            g.gather_color(0, r, gp, b)
+            got = out.download_color()
+    assert_planes_equal(got, want, "device gather (%s)" % ("RCCL" if force_rccl else "copy"))

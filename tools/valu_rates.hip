@@ -44,6 +44,8 @@ struct Stamp { unsigned long long cycles; };
             asm volatile(OP : "+v"(a6) : BCONSTRAINT(b) : CLOB);                                  \
             asm volatile(OP : "+v"(a7) : BCONSTRAINT(b) : CLOB);
 
+#define BODY32(OP, BCONSTRAINT, CLOB) BODY8(OP, BCONSTRAINT, CLOB) BODY8(OP, BCONSTRAINT, CLOB) BODY8(OP, BCONSTRAINT, CLOB) BODY8(OP, BCONSTRAINT, CLOB)
+
 #define DEFX(name, T, OP, BCONSTRAINT, CLOB)                                                              \
     __global__ void __launch_bounds__(256) name(float *out, Stamp *stamps, float seed, int iters)         \
     {                                                                                              \
@@ -52,8 +54,8 @@ struct Stamp { unsigned long long cycles; };
         T b = splat<T>(seed * 0.999f);                                                             \
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                \
         for (int i = 0; i < iters; ++i) {                                                          \
-            BODY8(OP, BCONSTRAINT, CLOB) BODY8(OP, BCONSTRAINT, CLOB)                              \
-            BODY8(OP, BCONSTRAINT, CLOB) BODY8(OP, BCONSTRAINT, CLOB)                              \
+            BODY32(OP, BCONSTRAINT, CLOB) BODY32(OP, BCONSTRAINT, CLOB)                            \
+            BODY32(OP, BCONSTRAINT, CLOB) BODY32(OP, BCONSTRAINT, CLOB)                            \
         }                                                                                          \
         asm volatile("s_nop 0" ::: "memory");                                                     \
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                \
@@ -211,7 +213,7 @@ int main(int argc, char **argv)
     Stamp *d_stamps; hipMalloc(&d_stamps, (size_t)cus * 8 * 4 * sizeof(Stamp));
     std::vector<Stamp> host((size_t)cus * 8 * 4);
     printf("{\n \"device\": \"%s\", \"cus\": %d, \"nominal_clock_mhz\": %.0f,\n", p.gcnArchName, cus, p.clockRate / 1e3);
-    printf(" \"method\": \"per-wave s_memtime stamps around ITERS x 32 independent instructions, >= 50 ms per run, ramped, median of 5 runs; per run the LAST-finishing wave (p99) gives the SIMD busy cycles for the work of its W waves; cost = those cycles / (W x instructions per wave); the scalar loop control is subtracted for W = 1 only (it hides behind other waves otherwise)\",\n");
+    printf(" \"method\": \"per-wave s_memtime stamps around ITERS x 128 independent instructions (8 registers round-robin), >= 50 ms per run, ramped, median of 5 runs; per run the LAST-finishing wave (p99) gives the SIMD busy cycles for the work of its W waves; cost = those cycles / (W x instructions per wave); the scalar loop control is subtracted for W = 1 only (it hides behind other waves otherwise)\",\n");
     printf(" \"results\": {\n");
     bool first_w = true;
     for (int w : wave_counts) {
@@ -229,7 +231,7 @@ int main(int argc, char **argv)
                    first ? "" : ",\n", name, cost, raw, r.ms, r.clock_ghz);
             first = false;
         };
-#define RUN(k, name) report(name, measure(k, w, d_out, d_stamps, host, cus), 32)
+#define RUN(k, name) report(name, measure(k, w, d_out, d_stamps, host, cus), 128)
 #define RUN8(k, name) report(name, measure(k, w, d_out, d_stamps, host, cus), 8)
         RUN(k_add_f32, "v_add_f32"); RUN(k_sub_f32, "v_sub_f32"); RUN(k_mul_f32, "v_mul_f32"); RUN(k_mul_f32_s, "v_mul_f32 (sgpr src)");
         RUN(k_fma_f32, "v_fma_f32"); RUN(k_fmac_f32, "v_fmac_f32"); RUN(k_fma_f32_sgpr, "v_fma_f32 (sgpr srcs)");

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""valu_roofline.py PMC_SUMMARY VALU_RATES [TAG] -- the VALU issue roofline of the C2 launch (profiles/<TAG>_valu_roofline.json).
+
+The kernel's bound is VALU issue, not HBM (its physical traffic is 0.4 % of the HBM peak).  A SIMD issues one wave64
+vector instruction per 2 cycles at best (32 lanes per cycle), one per 4 for half-rate instructions (v_fma_f32, every
+f64 operation, conversions, compares and selects, packed f32) and one per 8 for transcendentals -- the classes
+tools/valu_rates.hip measures on this chip.  The hardware counts the dynamic instruction mix by category
+(SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32, _F64, CVT, INT32, INT64); whatever it does not categorise (moves, compares,
+selects, min/max, lane operations) is priced at the CHEAPEST class, and so is INT32 (which mixes 2- and 4-cycle
+opcodes), so that
+
+    min_issue_cycles = sum over categories of count x class cost        is a LOWER bound on the issue cycles the
+                                                                        instructions of one launch need, and
+    frac = min_issue_cycles / (SIMDs x cycles the launch took)          a lower bound on the VALU issue utilisation.
+
+`priced_with_measured_rates` repeats the sum with the per-opcode costs valu_rates measured at 8 waves per SIMD
+(2.2 / 3.6-4.1 / 8.1 cycles: the microbenchmark's own loop control and issue bubbles are inside those figures, so this
+version errs high)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NOMINAL = {"ADD_F32": 2, "MUL_F32": 2, "FMA_F32": 4, "TRANS_F32": 8, "CVT": 4, "INT32": 2, "INT64": 4,
+           "ADD_F64": 4, "MUL_F64": 4, "FMA_F64": 4, "TRANS_F64": 16, "OTHER": 2}
+MEASURED_OP = {"ADD_F32": "v_add_f32", "MUL_F32": "v_mul_f32", "FMA_F32": "v_fma_f32", "TRANS_F32": "v_sqrt_f32",
+               "CVT": "v_cvt_f64_f32 / v_cvt_f32_f64", "INT32": "v_add_u32", "INT64": "v_lshl_add_u32",
+               "ADD_F64": "v_add_f64", "MUL_F64": "v_mul_f64", "FMA_F64": "v_fma_f64", "TRANS_F64": "v_sqrt_f32", "OTHER": "v_mov_b32"}
+
+
+def main():
+    summary = json.load(open(sys.argv[1]))
+    rates = json.load(open(sys.argv[2]))
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
+    name, rec = next((k, v) for k, v in summary.items() if "render_inline_kernel" in k)
+    c, calls = rec["counters_total"], rec["calls"]
+    per = {k: v / calls for k, v in c.items()}
+    mix = {k.replace("SQ_INSTS_VALU_", ""): per[k] for k in per if k.startswith("SQ_INSTS_VALU_")}
+    total = per["SQ_INSTS_VALU"]
+    mix["OTHER"] = total - sum(mix.values())
+    ops8 = rates["results"]["waves_per_simd_8"]["ops"]
+    nominal = sum(mix[k] * NOMINAL[k] for k in mix)
+    measured_price = sum(mix[k] * ops8[MEASURED_OP[k]]["cycles"] for k in mix)
+    n_simds = 1024
+    cycles_per_xcd = per["GRBM_GUI_ACTIVE"] / 8.0          # the counter is summed over the 8 XCDs
+    kernel_us = rec["avg_us"]
+    clock_ghz = cycles_per_xcd / (kernel_us * 1e3)
+    measured_cycles = n_simds * cycles_per_xcd
+    out = {
+        "kernel": name, "workload": summary.get("_bench", {}).get("workload"),
+        "source": "rocprofv3 --pmc passes of tools/pmc_kernels.sh c2 (means over all launches of the run) + build/valu_rates",
+        "n_simds": n_simds, "clock_ghz": round(clock_ghz, 4), "kernel_us_in_profile": kernel_us,
+        "valu_wave_instr_per_launch": total,
+        "mix_wave_instr_per_launch": {k: round(v) for k, v in sorted(mix.items())},
+        "class_cost_cycles": NOMINAL,
+        "min_issue_cycles": nominal, "measured_cycles_in_profile": measured_cycles,
+        "frac_in_profile": round(nominal / measured_cycles, 4),
+        "avg_issue_cycles_per_instr": round(nominal / total, 4),
+        "measured_simd_cycles_per_instr": round(measured_cycles / total, 4),
+        "priced_with_measured_rates": {"issue_cycles": measured_price, "frac": round(measured_price / measured_cycles, 4),
+                                       "avg_cycles_per_instr": round(measured_price / total, 4),
+                                       "rates": {k: ops8[MEASURED_OP[k]]["cycles"] for k in mix}},
+        "table_min_max_cycles": [min(v["cycles"] for k, v in ops8.items() if k.startswith("v_")),
+                                 max(v["cycles"] for k, v in ops8.items() if k.startswith("v_"))],
+        "active_lane_frac": round(per["SQ_THREAD_CYCLES_VALU"] / total / 64.0, 4),
+        "wave_cycles_waiting_for_issue_share": rec.get("wave_cycles_waiting_share"),
+    }
+    path = os.path.join(ROOT, "profiles", "%s_valu_roofline.json" % tag)
+    json.dump(out, open(path, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
