@@ -2,30 +2,47 @@
 {-# LANGUAGE BangPatterns #-}
 {-# LANGUAGE RecordWildCards #-}
 
--- | Drop-in replacement for the Accelerate-compiled render function of
--- haskell-path-tracer: binds libptmi (include/ptmi.h) and produces the very
--- 'CompiledFunction' that @compileFor@ builds at app/Main.hs:188-191, plus the
--- two array programs that create / replace the RNG planes (app/Main.hs:155,
--- :231, :306).
+-- | Replacement for the Accelerate-compiled render function of haskell-path-tracer on libptmi (include/ptmi.h).
 --
--- SOURCE ONLY: the build container has no GHC, so this module has not been
--- compiled here.  It uses nothing beyond @base@, @vector@ and the packages the
--- application already depends on (accelerate, accelerate-io-vector, linear).
+-- STATUS: SOURCE ONLY, NEVER COMPILED.  The build container and the GPU boxes have no GHC, so no line of this module
+-- has been type-checked; the C++ mirror of the same flows (hostcxx/scene.hpp) is what the tests run.  It uses nothing
+-- beyond @base@, @vector@ and the packages the application already depends on (accelerate, accelerate-io-vector, linear).
 --
--- To switch the application over, in app/Main.hs:
+-- Two wirings are offered:
 --
--- > import qualified Scene.HIP as HIP
--- > ...
--- > hip <- HIP.initialise 0                    -- once, in main, before :154
--- > let compute' = HIP.compileFor hip arguments -- replaces `compileFor arguments` (:154)
--- > seeds <- HIP.initialOutput hip 0x5EED1234   -- replaces `run <$> initialOutput` (:155, :306)
--- > reseeded <- HIP.reseed hip seed0 acc        -- replaces `run <$> (reseed . A.use $ acc)` (:231)
+-- 1. RESIDENT (recommended).  The accumulator and the RNG planes stay on the device; one call renders a whole batch
+--    of samples; only the three colour planes graphicsLoop shows ever cross PCIe.  In app/Main.hs:
 --
--- Everything else (threads, MVar, SDL/GL presentation) stays as it is: the
--- closure still has type Camera -> (Int, RenderResult) -> (Int, RenderResult).
+--    > hip <- HIP.initialise 0 screenWidth screenHeight           -- once in main, before :154 (sizes are run-time values here)
+--    > HIP.resetOutput hip seed0                                   -- replaces `run <$> initialOutput`            (:155, :306)
+--    > -- computationLoop (:199-215): `doTimes batchSize (compute camera) value` becomes ONE device call
+--    > iterations' <- HIP.renderResident hip config camera batchSize iterations    -- = iterations + batchSize
+--    > HIP.reseedResident hip seed0'                               -- replaces `run <$> (reseed . A.use $ acc)`  (:231)
+--    > -- graphicsLoop (:346-351): `A.toVectors texture` + `V.zipWith3 V3` become
+--    > (r, g, b) <- HIP.downloadColor hip          -- the three planes, or
+--    > rgb       <- HIP.presentRGB32F hip iterations   -- interleaved and already divided by the iteration count (fs.glsl:12)
+--
+--    The 'Result' record then carries the iteration count only; 'Handle' is the accumulator.
+--
+-- 2. COMPATIBLE.  'compileFor' builds the very closure of app/Main.hs:188-191,
+--    @Camera -> (Int, RenderResult) -> (Int, RenderResult)@: seven host planes in, seven fresh ones out, one sample per
+--    call (56 bytes per pixel over PCIe each way -- correct, slow; for comparisons with the Accelerate run).
+--
+--    > let compute' = HIP.compileFor hip arguments                 -- replaces `compileFor arguments`            (:154)
+--    > seeds <- HIP.initialOutput hip seed0                        -- replaces `run <$> initialOutput`           (:155, :306)
+--    > reseeded <- HIP.reseed hip seed0' acc                       -- replaces `run <$> (reseed . A.use $ acc)`  (:231)
 module Scene.HIP
   ( Handle
   , initialise
+  , handleSize
+  -- * resident wiring
+  , resetOutput
+  , renderResident
+  , reseedResident
+  , downloadColor
+  , presentRGB32F
+  , synchronize
+  -- * compatible wiring
   , compileFor
   , initialOutput
   , reseed
@@ -51,31 +68,42 @@ import           System.IO.Unsafe               ( unsafePerformIO )
 import           Scene.Objects
 import           Scene.Trace                    ( Algorithm(..) )
 import           Scene.World                    ( mainScene' )   -- see note [scene as data]
-import           Util                           ( screenWidth, screenHeight )
 
 -- Note [scene as data]
--- Scene.World.mainScene is a list of Exp constants baked into the Accelerate
--- kernel (src/Scene/World.hs:15-77).  libptmi takes the scene at run time, so
--- World.hs additionally exports the plain Haskell values it already contains:
+-- Scene.World.mainScene is a list of Exp constants baked into the Accelerate kernel (src/Scene/World.hs:15-77).
+-- libptmi takes the scene at run time, so World.hs additionally exports the plain Haskell values it already contains:
 --
 -- > mainScene' :: ([Sphere], [Plane])
 -- > mainScene' = (spheres', planes')   -- the two where-bound lists, lifted to top level
+--
+-- Note [image size at run time]
+-- The reference fixes the image size at compile time (src/Util.hs:185-188, the author's own TODO).  This module takes
+-- width and height as arguments of 'initialise' and carries them in the 'Handle'; nothing here imports
+-- Util.screenWidth / screenHeight.  The application may keep passing its constants, or a command-line value.
 
 data PtmiCtx
-newtype Handle = Handle (ForeignPtr PtmiCtx)
+-- | The device context plus the image size it was created for.
+data Handle = Handle { handleCtx :: !(ForeignPtr PtmiCtx), handleWidth :: !Int, handleHeight :: !Int }
+
+handleSize :: Handle -> (Int, Int)
+handleSize h = (handleWidth h, handleHeight h)
 
 data PtmiError = PtmiError Int String deriving Show
 instance Exception PtmiError
 
--- ptmi_render1 and friends run for milliseconds to seconds: `safe`, so that the
--- graphics and input threads keep running (app/Main.hs:178-180).
+-- Calls that run for milliseconds to seconds are `safe`, so that the graphics and input threads keep running
+-- (app/Main.hs:178-180).  An address import takes no safety annotation.
 foreign import ccall safe "ptmi.h ptmi_create"      c_create      :: Ptr (Ptr PtmiCtx) -> CInt -> IO CInt
-foreign import ccall safe "ptmi.h &ptmi_destroy"    p_destroy     :: FunPtr (Ptr PtmiCtx -> IO ())
+foreign import ccall      "ptmi.h &ptmi_destroy"    p_destroy     :: FunPtr (Ptr PtmiCtx -> IO ())
 foreign import ccall safe "ptmi.h ptmi_last_error"  c_last_error  :: Ptr PtmiCtx -> IO CString
 foreign import ccall safe "ptmi.h ptmi_set_scene"   c_set_scene   :: Ptr PtmiCtx -> Ptr Float -> CInt -> Ptr Float -> CInt -> IO CInt
 foreign import ccall safe "ptmi.h ptmi_resize"      c_resize      :: Ptr PtmiCtx -> CInt -> CInt -> IO CInt
 foreign import ccall safe "ptmi.h ptmi_init_output" c_init_output :: Ptr PtmiCtx -> Word64 -> IO CInt
 foreign import ccall safe "ptmi.h ptmi_reseed"      c_reseed      :: Ptr PtmiCtx -> Word64 -> IO CInt
+foreign import ccall safe "ptmi.h ptmi_render"      c_render      :: Ptr PtmiCtx -> Ptr CamRec -> CInt -> CInt -> CInt -> IO CInt
+foreign import ccall safe "ptmi.h ptmi_synchronize" c_synchronize :: Ptr PtmiCtx -> IO CInt
+foreign import ccall safe "ptmi.h ptmi_download_color" c_download_color :: Ptr PtmiCtx -> Ptr Float -> Ptr Float -> Ptr Float -> IO CInt
+foreign import ccall safe "ptmi.h ptmi_present"     c_present     :: Ptr PtmiCtx -> CInt -> Ptr Float -> Ptr Word8 -> IO CInt
 foreign import ccall safe "ptmi.h ptmi_upload_state"   c_upload   :: Ptr PtmiCtx -> Ptr Float -> Ptr Float -> Ptr Float -> Ptr Word32 -> Ptr Word32 -> Ptr Word32 -> Ptr Word32 -> IO CInt
 foreign import ccall safe "ptmi.h ptmi_download_state" c_download :: Ptr PtmiCtx -> Ptr Float -> Ptr Float -> Ptr Float -> Ptr Word32 -> Ptr Word32 -> Ptr Word32 -> Ptr Word32 -> IO CInt
 foreign import ccall safe "ptmi.h ptmi_render1"     c_render1
@@ -109,9 +137,18 @@ tagBits (Glossy _) = castWord32ToFloat 1        -- PTMI_GLOSSY
 param (Matte p)  = p
 param (Glossy p) = p
 
--- | Create the context, upload mainScene, size it to screenWidth x screenHeight (src/Util.hs:186-188).
-initialise :: Int -> IO Handle
-initialise device = alloca $ \pp -> do
+algorithmTag :: Algorithm -> CInt
+algorithmTag Streams = 0                        -- PTMI_STREAMS
+algorithmTag Inline  = 1                        -- PTMI_INLINE
+
+-- | The `15` of src/Scene/Trace.hs:200 / maxIterations (:80-81).
+bounceLimit :: CInt
+bounceLimit = 15
+
+-- | Create the context on a device, upload mainScene and size it to @width x height@ (run-time values; the
+-- reference's constants are src/Util.hs:186-188).
+initialise :: Int -> Int -> Int -> IO Handle
+initialise device width height = alloca $ \pp -> do
   rc <- c_create pp (fromIntegral device)
   when (rc /= 0) $ c_last_error nullPtr >>= peekCString >>= throwIO . PtmiError (fromIntegral rc)
   ctx <- peek pp
@@ -121,71 +158,120 @@ initialise device = alloca $ \pp -> do
   withArray (concatMap sphereWords spheres) $ \ps ->
     withArray (concatMap planeWords planes) $ \pp' ->
       c_set_scene ctx ps (fromIntegral $ length spheres) pp' (fromIntegral $ length planes) >>= check ctx
-  c_resize ctx (fromIntegral screenWidth) (fromIntegral screenHeight) >>= check ctx
-  return (Handle fp)
+  c_resize ctx (fromIntegral width) (fromIntegral height) >>= check ctx
+  return (Handle fp width height)
+
+nPixels :: Handle -> Int
+nPixels h = handleWidth h * handleHeight h
+
+-- ---------------------------------------------------------------------------------------------------------------------
+-- Resident wiring
+-- ---------------------------------------------------------------------------------------------------------------------
+
+-- | @run <$> initialOutput@ (src/Util.hs:204-205; app/Main.hs:155, :306) without the read-back: colour := 0, RNG :=
+-- genSeeds, on the device.  The reference seeds from OS entropy (src/Util.hs:122-127); pass any 64-bit seed (e.g. drawn
+-- from System.Random.MWC.createSystemRandom) -- equal seeds give equal images.
+resetOutput :: Handle -> Word64 -> IO ()
+resetOutput h seed0 = withForeignPtr (handleCtx h) $ \ctx -> c_init_output ctx seed0 >>= check ctx
+
+-- | @doTimes n (compute camera)@ (app/Main.hs:208-211, :241-242) as ONE device call: n successive applications of
+-- @render algorithm screenPixels camera@ to the resident accumulator.  Returns the new iteration count.  The launch is
+-- asynchronous; the next 'downloadColor' / 'presentRGB32F' / 'synchronize' waits for it.
+renderResident :: Handle -> Algorithm -> Camera -> Int -> Int -> IO Int
+renderResident h config cam n iterations = withForeignPtr (handleCtx h) $ \ctx -> allocaBytes 32 $ \pc -> do
+  pokeCamera pc cam
+  c_render ctx pc (algorithmTag config) bounceLimit (fromIntegral n) >>= check ctx
+  return (iterations + n)
+
+-- | @run <$> reseed acc@ (src/Util.hs:134-135; app/Main.hs:231) without moving the colour: every RNG state replaced.
+reseedResident :: Handle -> Word64 -> IO ()
+reseedResident h seed0 = withForeignPtr (handleCtx h) $ \ctx -> c_reseed ctx seed0 >>= check ctx
+
+synchronize :: Handle -> IO ()
+synchronize h = withForeignPtr (handleCtx h) $ \ctx -> c_synchronize ctx >>= check ctx
+
+-- | What graphicsLoop takes out of the result (app/Main.hs:346-350): the r, g and b planes, a SUM over the samples.
+downloadColor :: Handle -> IO (V.Vector Float, V.Vector Float, V.Vector Float)
+downloadColor h = withForeignPtr (handleCtx h) $ \ctx -> do
+  [r, g, b] <- mapM (const $ VM.new (nPixels h)) [1 .. 3 :: Int]
+  rc <- VM.unsafeWith r $ \qr -> VM.unsafeWith g $ \qg -> VM.unsafeWith b $ \qb -> c_download_color ctx qr qg qb
+  check ctx rc
+  (,,) <$> V.unsafeFreeze r <*> V.unsafeFreeze g <*> V.unsafeFreeze b
+
+-- | The texture graphicsLoop uploads (app/Main.hs:351, :383-393) with the shader's division already applied
+-- (app/assets/fs.glsl:12): interleaved RGB32F, colour / iterations, produced on the device.
+presentRGB32F :: Handle -> Int -> IO (V.Vector Float)
+presentRGB32F h iterations = withForeignPtr (handleCtx h) $ \ctx -> do
+  rgb <- VM.new (3 * nPixels h)
+  rc  <- VM.unsafeWith rgb $ \q -> c_present ctx (fromIntegral iterations) q nullPtr
+  check ctx rc
+  V.unsafeFreeze rgb
+
+-- ---------------------------------------------------------------------------------------------------------------------
+-- Compatible wiring
+-- ---------------------------------------------------------------------------------------------------------------------
 
 type CompiledFunction = Camera -> (Int, RenderResult) -> (Int, RenderResult)
 
-nPixels :: Int
-nPixels = fromIntegral screenWidth * fromIntegral screenHeight
-
 -- | The seven planes of a RenderResult, in libptmi's order (r, g, b, a, b, c, counter).
--- Accelerate's representation of Matrix (V3 Float, SFC32) as nested pairs of vectors is the one
--- visible at app/Main.hs:350.
+--
+-- ASSUMPTION (unverified, see DESIGN.md section 2, A3): Accelerate represents @Matrix (V3 Float, SFC32)@ as nested pairs
+-- of vectors -- the colour part is visible at app/Main.hs:350, @(((), ((((), r), g), b)), seedPlanes)@ -- and SFC32 as
+-- four Word32 planes nested the same way, in the order (a, b, c, counter) of PractRand's sfc32 state.  The SFC32 type
+-- lives in sfc-random-accelerate, which is not in the reference tree; if its Elt representation orders or nests the
+-- words differently, only the pattern below changes.
 planesOf :: RenderResult -> (V.Vector Float, V.Vector Float, V.Vector Float, V.Vector Word32, V.Vector Word32, V.Vector Word32, V.Vector Word32)
 planesOf acc = let (((), ((((), r), g), b)), (((((), sa), sb), sc), sd)) = toVectors acc in (r, g, b, sa, sb, sc, sd)
 
-fromPlanes :: (V.Vector Float, V.Vector Float, V.Vector Float, V.Vector Word32, V.Vector Word32, V.Vector Word32, V.Vector Word32) -> RenderResult
-fromPlanes (r, g, b, sa, sb, sc, sd) =
-  fromVectors (A.Z A.:. fromIntegral screenHeight A.:. fromIntegral screenWidth)
+fromPlanes :: Handle -> (V.Vector Float, V.Vector Float, V.Vector Float, V.Vector Word32, V.Vector Word32, V.Vector Word32, V.Vector Word32) -> RenderResult
+fromPlanes h (r, g, b, sa, sb, sc, sd) =
+  fromVectors (A.Z A.:. handleHeight h A.:. handleWidth h)         -- screenShape, src/Util.hs:213-214: Z :. height :. width
               (((), ((((), r), g), b)), (((((), sa), sb), sc), sd))
 
 -- | @compileFor@ (app/Main.hs:188-191) on libptmi: one call = one sample, exactly `runN (render config) screenPixels`.
 -- The closure is pure from the caller's point of view, like `dewit`.
 compileFor :: Handle -> Algorithm -> CompiledFunction
-compileFor (Handle fp) !config = \(!c) (!iterations, !acc) ->
+compileFor h !config = \(!c) (!iterations, !acc) ->
   (iterations + 1, unsafePerformIO (render1 c acc))
  where
-  algorithm = case config of { Streams -> 0; Inline -> 1 }   -- PTMI_STREAMS / PTMI_INLINE
-  render1 cam acc = withForeignPtr fp $ \ctx -> allocaBytes 32 $ \pc -> do
+  n = nPixels h
+  render1 cam acc = withForeignPtr (handleCtx h) $ \ctx -> allocaBytes 32 $ \pc -> do
     pokeCamera pc cam
     let (r, g, b, sa, sb, sc, sd) = planesOf acc
-    [r', g', b']        <- mapM (const $ VM.new nPixels) [1 .. 3 :: Int]
-    [sa', sb', sc', sd'] <- mapM (const $ VM.new nPixels) [1 .. 4 :: Int]
+    [r', g', b']        <- mapM (const $ VM.new n) [1 .. 3 :: Int]
+    [sa', sb', sc', sd'] <- mapM (const $ VM.new n) [1 .. 4 :: Int]
     rc <- V.unsafeWith r $ \pr -> V.unsafeWith g $ \pg -> V.unsafeWith b $ \pb ->
           V.unsafeWith sa $ \pa -> V.unsafeWith sb $ \pbb -> V.unsafeWith sc $ \pcc -> V.unsafeWith sd $ \pd ->
           VM.unsafeWith r' $ \qr -> VM.unsafeWith g' $ \qg -> VM.unsafeWith b' $ \qb ->
           VM.unsafeWith sa' $ \qa -> VM.unsafeWith sb' $ \qbb -> VM.unsafeWith sc' $ \qcc -> VM.unsafeWith sd' $ \qd ->
-            c_render1 ctx pc algorithm 15                       -- the `15` of src/Scene/Trace.hs:200
-                      (fromIntegral screenWidth) (fromIntegral screenHeight) nullPtr nullPtr
+            c_render1 ctx pc (algorithmTag config) bounceLimit
+                      (fromIntegral $ handleWidth h) (fromIntegral $ handleHeight h) nullPtr nullPtr
                       pr pg pb pa pbb pcc pd qr qg qb qa qbb qcc qd
     check ctx rc
-    fromPlanes <$> ((,,,,,,) <$> V.unsafeFreeze r' <*> V.unsafeFreeze g' <*> V.unsafeFreeze b'
-                              <*> V.unsafeFreeze sa' <*> V.unsafeFreeze sb' <*> V.unsafeFreeze sc' <*> V.unsafeFreeze sd')
+    fromPlanes h <$> ((,,,,,,) <$> V.unsafeFreeze r' <*> V.unsafeFreeze g' <*> V.unsafeFreeze b'
+                                <*> V.unsafeFreeze sa' <*> V.unsafeFreeze sb' <*> V.unsafeFreeze sc' <*> V.unsafeFreeze sd')
 
-download :: Ptr PtmiCtx -> IO RenderResult
-download ctx = do
-  [r, g, b]        <- mapM (const $ VM.new nPixels) [1 .. 3 :: Int]
-  [sa, sb, sc, sd] <- mapM (const $ VM.new nPixels) [1 .. 4 :: Int]
+download :: Handle -> Ptr PtmiCtx -> IO RenderResult
+download h ctx = do
+  [r, g, b]        <- mapM (const $ VM.new (nPixels h)) [1 .. 3 :: Int]
+  [sa, sb, sc, sd] <- mapM (const $ VM.new (nPixels h)) [1 .. 4 :: Int]
   rc <- VM.unsafeWith r $ \qr -> VM.unsafeWith g $ \qg -> VM.unsafeWith b $ \qb ->
         VM.unsafeWith sa $ \qa -> VM.unsafeWith sb $ \qbb -> VM.unsafeWith sc $ \qcc -> VM.unsafeWith sd $ \qd ->
           c_download ctx qr qg qb qa qbb qcc qd
   check ctx rc
-  fromPlanes <$> ((,,,,,,) <$> V.unsafeFreeze r <*> V.unsafeFreeze g <*> V.unsafeFreeze b
-                            <*> V.unsafeFreeze sa <*> V.unsafeFreeze sb <*> V.unsafeFreeze sc <*> V.unsafeFreeze sd)
+  fromPlanes h <$> ((,,,,,,) <$> V.unsafeFreeze r <*> V.unsafeFreeze g <*> V.unsafeFreeze b
+                              <*> V.unsafeFreeze sa <*> V.unsafeFreeze sb <*> V.unsafeFreeze sc <*> V.unsafeFreeze sd)
 
--- | @run <$> initialOutput@ (src/Util.hs:204-205): zero colour + fresh RNG states, generated on the device.
--- The reference seeds from OS entropy (src/Util.hs:122-127); pass any 64-bit seed (e.g. drawn from
--- System.Random.MWC.createSystemRandom) -- equal seeds give equal images.
+-- | @run <$> initialOutput@ (src/Util.hs:204-205) with the read-back the compatible closure needs.
 initialOutput :: Handle -> Word64 -> IO RenderResult
-initialOutput (Handle fp) seed0 = withForeignPtr fp $ \ctx -> c_init_output ctx seed0 >>= check ctx >> download ctx
+initialOutput h seed0 = withForeignPtr (handleCtx h) $ \ctx -> c_init_output ctx seed0 >>= check ctx >> download h ctx
 
 -- | @run <$> reseed acc@ (src/Util.hs:134-135): keep the colour, replace every RNG state.
 reseed :: Handle -> Word64 -> RenderResult -> IO RenderResult
-reseed (Handle fp) seed0 acc = withForeignPtr fp $ \ctx -> do
+reseed h seed0 acc = withForeignPtr (handleCtx h) $ \ctx -> do
   let (r, g, b, _, _, _, _) = planesOf acc
   rc <- V.unsafeWith r $ \pr -> V.unsafeWith g $ \pg -> V.unsafeWith b $ \pb ->
         c_upload ctx pr pg pb nullPtr nullPtr nullPtr nullPtr
   check ctx rc
   c_reseed ctx seed0 >>= check ctx
-  download ctx
+  download h ctx

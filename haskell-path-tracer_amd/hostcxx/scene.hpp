@@ -179,4 +179,46 @@ inline CompiledFunction compileFor(const Device &dev, Options config)
     };
 }
 
+// ---- the resident flow: the same calls of app/Main.hs with the accumulator left on the device ---------
+// computationLoop renders `doTimes batchSize` samples per turn (app/Main.hs:208-211) and graphicsLoop only ever
+// reads the three colour planes (app/Main.hs:346-351), so nothing but those has to cross PCIe:
+//   Resident r(dev, config);            -- compileFor
+//   r.reset(seed0);                     -- run <$> initialOutput          (:155, and :306 on a camera move)
+//   r.compute(camera, batchSize);       -- doTimes batchSize (compute camera)   = ONE ptmi_render(n_spp = batchSize)
+//   r.reseed(seed0);                    -- run <$> reseed acc             (:231)
+//   r.colour() / r.present(rgb, rgba);  -- A.toVectors texture + zipWith3 V3 (:350-351), fs.glsl's divide
+class Resident {
+public:
+    Resident(const Device &dev, Options config) : dev_(dev), config_(config) {}
+    int iterations() const { return iterations_; }
+    void reset(uint64_t seed0) { dev_.check(ptmi_init_output(dev_.get(), seed0)); iterations_ = 0; }
+    void reseed(uint64_t seed0) { dev_.check(ptmi_reseed(dev_.get(), seed0)); }
+    // \c (iterations, acc) -> (iterations + n, dewit^n (scalar c) acc); asynchronous
+    int compute(const Camera &c, int n = 1)
+    {
+        const ptmi_camera cam{{c.position.x, c.position.y, c.position.z}, {c.rotation.x, c.rotation.y, c.rotation.z}, c.fov};
+        dev_.check(ptmi_render(dev_.get(), &cam, (int)config_, Trace::maxIterations, n));
+        return iterations_ += n;
+    }
+    RenderResult value() const { return Util::download(dev_); }                      // the whole RenderResult (tests, checkpoints)
+    void colour(std::vector<float> &r, std::vector<float> &g, std::vector<float> &b) const
+    {
+        const size_t n = (size_t)dev_.width() * dev_.height();
+        r.resize(n); g.resize(n); b.resize(n);
+        dev_.check(ptmi_download_color(dev_.get(), r.data(), g.data(), b.data()));
+    }
+    void present(std::vector<float> *rgb32f, std::vector<uint8_t> *rgba8) const     // texture.rgb / u_iterations (fs.glsl:12)
+    {
+        const size_t n = (size_t)dev_.width() * dev_.height();
+        if (rgb32f) rgb32f->resize(3 * n);
+        if (rgba8) rgba8->resize(4 * n);
+        dev_.check(ptmi_present(dev_.get(), iterations_, rgb32f ? rgb32f->data() : nullptr, rgba8 ? rgba8->data() : nullptr));
+    }
+
+private:
+    Device dev_;
+    Options config_;
+    int iterations_ = 0;
+};
+
 }  // namespace Scene

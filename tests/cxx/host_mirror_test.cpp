@@ -65,9 +65,51 @@ int main()
         const RenderResult reseeded = Util::reseed(dev, 99, value.second);
         ok &= same(reseeded.r.data(), value.second.r.data(), reseeded.r.size() * 4, "colour after reseed");
         ok &= std::memcmp(reseeded.sfc_a.data(), value.second.sfc_a.data(), reseeded.sfc_a.size() * 4) != 0;
+        // ---- the resident flow at the same size (INTEGRATION.md "resident wiring"): computationLoop's batching
+        // (single samples up to 100 iterations, then doTimes batchSize, app/Main.hs:208-211), a reseed in between
+        // (:231), the read-outs graphicsLoop needs (:346-351) -- against the oracle doing the same sample by sample.
+        {
+            Resident res(dev, Trace::Algorithm::Inline);
+            res.reset(0x5EED1234ull);
+            RenderResult ref = seeds;
+            auto oracle_samples = [&](int n) {
+                ora_render_inline(&scene, &ocam, W, H, 15, n, nullptr, nullptr, ref.r.data(), ref.g.data(), ref.b.data(),
+                                  ref.sfc_a.data(), ref.sfc_b.data(), ref.sfc_c.data(), ref.sfc_counter.data(), ora_max_threads());
+            };
+            res.compute(camera); res.compute(camera); res.compute(camera);          // three single samples
+            res.compute(camera, 30);                                                 // doTimes 30
+            oracle_samples(33);
+            ok &= res.iterations() == 33;
+            RenderResult got = res.value();
+            ok &= same(ref.r.data(), got.r.data(), ref.r.size() * 4, "resident r after 33 samples");
+            ok &= same(ref.sfc_c.data(), got.sfc_c.data(), ref.sfc_c.size() * 4, "resident sfc c after 33 samples");
+            res.reseed(4242);                                                        // run <$> reseed acc
+            ora_gen_seeds(4242, 0, (int64_t)W * H, ref.sfc_a.data(), ref.sfc_b.data(), ref.sfc_c.data(), ref.sfc_counter.data());
+            res.compute(camera, 7);
+            oracle_samples(7);
+            got = res.value();
+            ok &= same(ref.g.data(), got.g.data(), ref.g.size() * 4, "resident g after reseed + 7");
+            ok &= same(ref.sfc_a.data(), got.sfc_a.data(), ref.sfc_a.size() * 4, "resident sfc a after reseed + 7");
+            std::vector<float> cr, cg, cb, rgb; std::vector<uint8_t> rgba;
+            res.colour(cr, cg, cb);
+            ok &= same(ref.b.data(), cb.data(), cb.size() * 4, "colour planes for graphicsLoop");
+            res.present(&rgb, &rgba);
+            bool present_ok = rgb.size() == 3 * ref.r.size() && rgba.size() == 4 * ref.r.size();
+            for (size_t i = 0; present_ok && i < ref.r.size(); i += 997) {           // texture.rgb / u_iterations
+                present_ok &= rgb[3 * i] == ref.r[i] / 40.0f && rgb[3 * i + 1] == ref.g[i] / 40.0f && rgb[3 * i + 2] == ref.b[i] / 40.0f;
+                present_ok &= rgba[4 * i + 3] == 255;
+            }
+            if (!present_ok) std::printf("MISMATCH in present\n");
+            ok &= present_ok;
+            // a camera move: run <$> initialOutput again (app/Main.hs:306), iterations start over
+            res.reset(7);
+            ok &= res.iterations() == 0;
+            res.colour(cr, cg, cb);
+            for (size_t i = 0; i < cr.size(); i += 1013) ok &= cr[i] == 0.0f;
+        }
         // error behaviour: exception with a code, like a Haskell exception out of runN
         try { Device bad(1 << 20); ok = false; } catch (const PtmiError &e) { ok &= e.code == PTMI_ENODEVICE; }
-        std::printf(ok ? "host mirror OK (800x600, 2 samples, 15 bounces, bit-identical to the oracle)\n" : "host mirror FAILED\n");
+        std::printf(ok ? "host mirror OK (800x600, 15 bounces: closure flow 2 samples, resident flow 40 samples with batching, reseed and present -- bit-identical to the oracle)\n" : "host mirror FAILED\n");
         return ok ? 0 : 1;
     } catch (const PtmiError &e) {
         std::printf("PtmiError %d: %s\n", e.code, e.what());
