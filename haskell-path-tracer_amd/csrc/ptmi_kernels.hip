@@ -1771,11 +1771,17 @@ hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t st
     //           10-12 pooled second shade round | 13 = 4 with 8x8 pixel tiles per wave | 14-16 other tile shapes
     //           17 = 5 with 8x8 tiles
     if (a.bounce_limit <= 0 || a.n_spp <= 0) variant = 2;   // degenerate counts: the plain loop handles them
+    const bool big_scene = lds > kMaxSceneLds;               // every route reads such a scene through scalar loads, not LDS
     if (variant == 0) {
         // static mapping wins at every size measured; a scene too big to keep 6 waves/SIMD in LDS is
         // read through scalar loads; 8x8 tiles once the image is big enough for whole tiles to dominate
         const bool tiles = tiles_pay(a);
         variant = lds <= kMaxSceneLds ? (tiles ? 13 : 4) : (tiles ? 17 : 5);
+    }
+    if (big_scene) {                                         // the LDS forms of the ablation variants would not fit or would cap occupancy
+        if (variant == 1) variant = 6;
+        else if (variant == 4 || variant == 7 || variant == 8) variant = 5;
+        else if (variant >= 13 && variant <= 16) variant = 17;
     }
     if (variant == 1 || variant == 6) {
         // persistent grid; more workgroups than fit would only start late and find the queue empty: cap at 8 per CU
@@ -1814,14 +1820,24 @@ hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t st
     if (variant >= 10 && variant <= 12) {                    // pooled second shade round, W = 2 / 4 / 8 waves per workgroup
         const int w = variant == 10 ? 2 : variant == 11 ? 4 : 8;
         const dim3 pgrid(blocks_for(n_local, 64 * w)), pblock(64 * w);
-        if (w == 2)      hipLaunchKernelGGL((render_inline_pooled_kernel<true, 2>), pgrid, pblock, lds, stream, a);
-        else if (w == 4) hipLaunchKernelGGL((render_inline_pooled_kernel<true, 4>), pgrid, pblock, lds, stream, a);
-        else             hipLaunchKernelGGL((render_inline_pooled_kernel<true, 8>), pgrid, pblock, lds, stream, a);
+        if (big_scene) {                                       // a scene too big to stage per workgroup: scalar loads
+            if (w == 2)      hipLaunchKernelGGL((render_inline_pooled_kernel<false, 2>), pgrid, pblock, 0, stream, a);
+            else if (w == 4) hipLaunchKernelGGL((render_inline_pooled_kernel<false, 4>), pgrid, pblock, 0, stream, a);
+            else             hipLaunchKernelGGL((render_inline_pooled_kernel<false, 8>), pgrid, pblock, 0, stream, a);
+        } else {
+            if (w == 2)      hipLaunchKernelGGL((render_inline_pooled_kernel<true, 2>), pgrid, pblock, lds, stream, a);
+            else if (w == 4) hipLaunchKernelGGL((render_inline_pooled_kernel<true, 4>), pgrid, pblock, lds, stream, a);
+            else             hipLaunchKernelGGL((render_inline_pooled_kernel<true, 8>), pgrid, pblock, lds, stream, a);
+        }
         return hipGetLastError();
     }
     switch (variant) {
-    case 2:  hipLaunchKernelGGL((render_inline_kernel<true, kLockstep>), grid, block, lds, stream, a); break;
-    case 3:  hipLaunchKernelGGL((render_inline_kernel<true, kRegenerate>), grid, block, lds, stream, a); break;
+    case 2:  if (big_scene) hipLaunchKernelGGL((render_inline_kernel<false, kLockstep>), grid, block, 0, stream, a);
+             else           hipLaunchKernelGGL((render_inline_kernel<true, kLockstep>), grid, block, lds, stream, a);
+             break;
+    case 3:  if (big_scene) hipLaunchKernelGGL((render_inline_kernel<false, kRegenerate>), grid, block, 0, stream, a);
+             else           hipLaunchKernelGGL((render_inline_kernel<true, kRegenerate>), grid, block, lds, stream, a);
+             break;
     case 5:  hipLaunchKernelGGL((render_inline_kernel<false, kCached>), grid, block, 0, stream, a); break;
     case 7:  hipLaunchKernelGGL((render_inline_kernel<true, kCached>), grid, block, 33 * 1024, stream, a); break;   // 4 waves/SIMD
     case 8:  hipLaunchKernelGGL((render_inline_kernel<true, kCached>), grid, block, 41 * 1024, stream, a); break;   // 3 waves/SIMD
