@@ -54,6 +54,8 @@ struct ptmi_ctx {
     unsigned int *d_quad_cost = nullptr, *d_quad_order = nullptr, *d_quad_class = nullptr;
     unsigned int quad_capacity = 0;
     int order_state = 0;
+    unsigned int *d_chunk_done = nullptr;      // sample chunks of the tiled Inline kernel: one word per tile workgroup
+    unsigned int chunk_capacity = 0;
     struct OrderKey { ptmi_camera cam; uint64_t scene_version; int dims[8]; } order_key{};
     uint64_t scene_version = 0;
 
@@ -77,6 +79,7 @@ struct ptmi_ctx {
     int opt_capacity = 4;
     int opt_form = PTMI_FORM_AUTO;
     int opt_batch = 0;
+    int opt_spp_chunks = 0;                    // 0 = automatic
 };
 
 namespace {
@@ -376,6 +379,17 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
         if (launches > 0) a.quad_order = c->d_quad_order;
         if (launches < (1 << 20)) { a.quad_cost = c->d_quad_cost; next_order_state = launches + 1; }   // the sums stay far from 2^32
     }
+    if (algorithm == PTMI_INLINE) {
+        // one word per tile workgroup for the sample chunks of the tiled kernel (ptmi_kernels.hip)
+        const unsigned int need = ((unsigned int)(((width + 7) / 8) * ((rows_local + 7) / 8)) + 31u) & ~31u;
+        if (need > c->chunk_capacity) {
+            if (c->d_chunk_done) { PTMI_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_chunk_done); c->d_chunk_done = nullptr; c->chunk_capacity = 0; }
+            PTMI_HIP(c, hipMalloc(&c->d_chunk_done, (size_t)need * sizeof(unsigned int)));
+            c->chunk_capacity = need;
+        }
+        a.chunk_done = c->d_chunk_done; a.chunk_capacity = c->chunk_capacity;
+        a.spp_chunks = sx ? 1 : c->opt_spp_chunks;
+    }
     if (c->timing) { PTMI_HIP(c, hipEventRecord(c->ev0, c->stream)); }
     if (algorithm == PTMI_INLINE) {
         PTMI_HIP(c, launch_render_inline(a, c->variant, c->stream));
@@ -487,6 +501,7 @@ void ptmi_destroy(ptmi_ctx *c)
     if (c->d_quad_cost) (void)hipFree(c->d_quad_cost);
     if (c->d_quad_order) (void)hipFree(c->d_quad_order);
     if (c->d_quad_class) (void)hipFree(c->d_quad_class);
+    if (c->d_chunk_done) (void)hipFree(c->d_chunk_done);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_snap) (void)hipEventDestroy(c->ev_snap);
@@ -649,6 +664,9 @@ int ptmi_set_option(ptmi_ctx *c, int option, int64_t value)
     case PTMI_OPT_STREAM_BATCH:
         if (value < 0 || value > 64) return fail(c, PTMI_EINVAL, "stream batch must be in [0, 64] samples");
         c->opt_batch = (int)value; return PTMI_OK;
+    case PTMI_OPT_INLINE_SPP_CHUNKS:
+        if (value < 0 || value > 64) return fail(c, PTMI_EINVAL, "sample chunks must be in [0, 64]");
+        c->opt_spp_chunks = (int)value; return PTMI_OK;
     default: return fail(c, PTMI_EINVAL, "unknown option");
     }
 }
@@ -664,6 +682,7 @@ int ptmi_get_option(ptmi_ctx *c, int option, int64_t *value)
     case PTMI_OPT_STREAM_CAPACITY:   *value = c->opt_capacity; return PTMI_OK;
     case PTMI_OPT_STREAMS_FORM:      *value = c->opt_form; return PTMI_OK;
     case PTMI_OPT_STREAM_BATCH:      *value = c->opt_batch; return PTMI_OK;
+    case PTMI_OPT_INLINE_SPP_CHUNKS: *value = c->opt_spp_chunks; return PTMI_OK;
     default: return fail(c, PTMI_EINVAL, "unknown option");
     }
 }

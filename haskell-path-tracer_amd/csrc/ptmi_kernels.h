@@ -41,6 +41,11 @@ struct RenderArgs {
     // quad_cost: where each wave adds the loop trips it paid (NULL = do not record).
     const unsigned int *quad_order;
     unsigned int *quad_cost;
+    // Sample chunks of the tiled render Inline kernel (see render_inline_kernel): spp_chunks = 0 lets the launcher choose,
+    // 1 switches them off, k >= 2 forces k copies; chunk_done: one word per tile workgroup (capacity words), device memory.
+    int spp_chunks;
+    unsigned int *chunk_done;
+    unsigned int chunk_capacity;
     // render Streams only
     int stream_step_cap;                  // traceSteps per ray lineage before the safety cap cuts it (the reference has none)
     int seed_from_result;                 // PTMI_SEED_FROM_RESULT: a hit's ray seed replaces the pixel's (assumption A5)

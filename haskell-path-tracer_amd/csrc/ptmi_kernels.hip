@@ -311,7 +311,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned int v)
 // primitives and their paths have similar lengths, which is worth 1-2 % (8 x 8 measured best); the
 // seven plane accesses of a lane happen once per launch, so their shorter runs do not matter.
 template <int TILE_W>
-__device__ __forceinline__ bool lane_pixel(const RenderArgs &a, long long &pixel, unsigned int &quad)
+__device__ __forceinline__ bool lane_pixel(const RenderArgs &a, long long &pixel, unsigned int &quad, unsigned int wg = blockIdx.x)
 {
     quad = 0;
     if (TILE_W > 0) {
@@ -324,7 +324,7 @@ __device__ __forceinline__ bool lane_pixel(const RenderArgs &a, long long &pixel
         // Which quad a dispatch position gets is the image order, or -- once a launch with the same camera has recorded
         // what every quad costs -- the most expensive first (quad_order), which shortens the end of the kernel where
         // the last waves run with the chip half empty.
-        const unsigned int xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
+        const unsigned int xcd = wg & 7u, k = wg >> 3;
         const unsigned int position = (k >> 2) * 8u + xcd;
         quad = a.quad_order ? a.quad_order[position] : position;
 #if defined(PTMI_TILE_REVERSE)
@@ -336,7 +336,7 @@ __device__ __forceinline__ bool lane_pixel(const RenderArgs &a, long long &pixel
         pixel = (long long)y * a.width + x;
         return x < a.width && y < a.rows_local;              // also false for the padding tiles (ty beyond the image)
     }
-    pixel = (long long)blockIdx.x * kRenderBlock + threadIdx.x;
+    pixel = (long long)wg * kRenderBlock + threadIdx.x;
     return pixel < (long long)a.rows_local * a.width;
 }
 
@@ -379,9 +379,32 @@ __global__ void __launch_bounds__(kRenderBlock, (MODE == kCached || MODE == kCac
     const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
     const float4 *M = S + a.scene.geom_f4();
 
+    // SAMPLE CHUNKS (a.spp_chunks > 1; tiled kernels only).  A pixel's samples are one serial chain, so a launch has as
+    // many waves as the image has tiles, each as long as n_spp; with few tiles and many samples -- one of 8 parts of a
+    // 4K image at 1024 spp: 16 200 waves for 6 144 slots -- the last round of waves runs on a partly empty chip and
+    // costs 15 %.  The grid is therefore spp_chunks copies of the tile grid: copy c of a tile renders samples
+    // [c S, (c+1) S) of its pixels, after copy c-1 has stored the planes and published done[tile] = c.  Workgroups are
+    // dispatched in index order and copy c-1 has the lower index, so the producer is always resident or finished when the
+    // consumer waits (in practice it finished a whole round earlier: the wait falls through).  The planes travel through
+    // memory between copies: release / acquire at agent scope (L2 write-back, L1 invalidate); copies of one tile run on
+    // the same XCD (the grid of a copy is a multiple of 32).  Results do not depend on the chunking (sample-split invariance).
+    unsigned int wg = blockIdx.x;
+    int chunk = 0, n_spp_chunk = a.n_spp;
+    if (TILE_W > 0 && a.spp_chunks > 1) {
+        const unsigned int per_copy = gridDim.x / (unsigned int)a.spp_chunks;
+        chunk = (int)(wg / per_copy);
+        wg -= (unsigned int)chunk * per_copy;
+        const int per = (a.n_spp + a.spp_chunks - 1) / a.spp_chunks;
+        n_spp_chunk = a.n_spp - chunk * per;
+        n_spp_chunk = n_spp_chunk < 0 ? 0 : (n_spp_chunk > per ? per : n_spp_chunk);
+        if (chunk > 0) {
+            while (__hip_atomic_load(a.chunk_done + wg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)chunk)
+                __builtin_amdgcn_s_sleep(16);
+        }
+    }
     long long pixel;
     unsigned int quad, trips = 0;
-    const bool valid = lane_pixel<TILE_W>(a, pixel, quad);
+    const bool valid = lane_pixel<TILE_W>(a, pixel, quad, wg);
     unsigned int live = 0;
     if (valid) {
         const int local_row = (int)(pixel / a.width);
@@ -397,7 +420,7 @@ __global__ void __launch_bounds__(kRenderBlock, (MODE == kCached || MODE == kCac
         seed.a = a.planes.sa[pixel]; seed.b = a.planes.sb[pixel];
         seed.c = a.planes.sc[pixel]; seed.counter = a.planes.sctr[pixel];
 
-        const int limit = a.bounce_limit, n_spp = a.n_spp;
+        const int limit = a.bounce_limit, n_spp = n_spp_chunk;
 
         if (limit <= 0) {
             // iterate 0: every sample returns (0, seed); new + old
@@ -601,6 +624,10 @@ __global__ void __launch_bounds__(kRenderBlock, (MODE == kCached || MODE == kCac
         a.planes.r[pixel] = acc.x; a.planes.g[pixel] = acc.y; a.planes.b[pixel] = acc.z;
         a.planes.sa[pixel] = seed.a; a.planes.sb[pixel] = seed.b;
         a.planes.sc[pixel] = seed.c; a.planes.sctr[pixel] = seed.counter;
+    }
+    if (TILE_W > 0 && a.spp_chunks > 1 && chunk + 1 < a.spp_chunks) {     // publish: the next copy of this tile may start
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if ((threadIdx.x & 63) == 0) __hip_atomic_store(a.chunk_done + wg, (unsigned int)(chunk + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     if (TILE_W > 0) record_cost(a, quad, trips);
@@ -1804,15 +1831,39 @@ hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t st
         hipLaunchKernelGGL((render_inline_kernel<true, kCachedR1, 8>), dim3(tile_grid(a, 8)), block, lds, stream, a);
         return hipGetLastError();
     }
-    if (variant == 17) {
-        hipLaunchKernelGGL((render_inline_kernel<false, kCached, 8>), dim3(tile_grid(a, 8)), block, 0, stream, a);
+    if (variant == 17 || variant == 13) {
+        // sample chunks (see the kernel): only when the launch has few rounds of waves and every copy keeps >= 64 samples
+        RenderArgs b = a;
+        const unsigned int per_copy = tile_grid(a, 8);
+        b.spp_chunks = 1;
+        if (a.chunk_done && a.chunk_capacity >= per_copy && a.spp_chunks != 1) {
+            static int slots = 0;
+            if (!slots) {
+                int dev = 0, cus = 0;
+                hipError_t e = hipGetDevice(&dev);
+                if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                if (e != hipSuccess) return e;
+                slots = (cus > 0 ? cus : 256) * 4 * 6;
+            }
+            int k = a.spp_chunks > 1 ? a.spp_chunks : (int)((16ull * (unsigned long long)slots + per_copy - 1) / per_copy);   // aim at >= 16 rounds
+            if (a.spp_chunks <= 0 && k > a.n_spp / 64) k = a.n_spp / 64;
+            if (k > a.n_spp) k = a.n_spp;
+            if (k > 64) k = 64;
+            if (k >= 2) {
+                b.spp_chunks = k;
+                hipError_t e = hipMemsetAsync(a.chunk_done, 0, (size_t)per_copy * sizeof(unsigned int), stream);
+                if (e != hipSuccess) return e;
+            }
+        }
+        const dim3 cgrid(per_copy * (unsigned int)b.spp_chunks);
+        if (variant == 17) hipLaunchKernelGGL((render_inline_kernel<false, kCached, 8>), cgrid, block, 0, stream, b);
+        else               hipLaunchKernelGGL((render_inline_kernel<true, kCached, 8>), cgrid, block, lds, stream, b);
         return hipGetLastError();
     }
-    if (variant >= 13 && variant <= 16) {                     // pixel tiles per wave: 8x8 (default) / 16x4 / 4x16 / 32x2
-        const int tw = variant == 13 ? 8 : variant == 14 ? 16 : variant == 15 ? 4 : 32;
+    if (variant >= 14 && variant <= 16) {                     // other pixel tiles per wave: 16x4 / 4x16 / 32x2 (8x8 is handled above)
+        const int tw = variant == 14 ? 16 : variant == 15 ? 4 : 32;
         const dim3 tgrid(tile_grid(a, tw));
-        if (tw == 8)       hipLaunchKernelGGL((render_inline_kernel<true, kCached, 8>), tgrid, block, lds, stream, a);
-        else if (tw == 16) hipLaunchKernelGGL((render_inline_kernel<true, kCached, 16>), tgrid, block, lds, stream, a);
+        if (tw == 16)      hipLaunchKernelGGL((render_inline_kernel<true, kCached, 16>), tgrid, block, lds, stream, a);
         else if (tw == 4)  hipLaunchKernelGGL((render_inline_kernel<true, kCached, 4>), tgrid, block, lds, stream, a);
         else               hipLaunchKernelGGL((render_inline_kernel<true, kCached, 32>), tgrid, block, lds, stream, a);
         return hipGetLastError();

@@ -43,10 +43,11 @@ def test_render_inline_matches_oracle(ctx, pkg, ora, w, h, limit, spp, scene_nam
     assert stats["nominal_bounces"] == w * h * spp * limit
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 def test_every_kernel_variant_matches_oracle(pkg, ora, variant):
     """All loop shapes (persistent hand-out, lock step, regenerate, cached/static, LDS or scalar-load scene,
-    second shade round pooled over 2 / 4 / 8 waves, 8x8 / 16x4 / 4x16 / 32x2 pixel tiles per wave)
+    second shade round pooled over 2 / 4 / 8 waves, 8x8 / 16x4 / 4x16 / 32x2 pixel tiles per wave,
+    round 1's [shade][shade][trace] loop without the frozen-shade shortcut)
     compute the same seven planes -- they differ only in how lanes are kept busy."""
     scene = pkg.world.scene16()
     cam = pkg.world.initial_camera()
@@ -113,3 +114,25 @@ def test_cost_ordered_dispatch_changes_nothing_but_the_order(pkg, ora):
                 else:
                     want, _ = ora.render_streams(sp2, pl2, cam1, w, h, 1 << 16, 2, want)
                 assert_planes_equal(c.download_state(), want, "after the scene change, launch %d" % k)
+
+
+@pytest.mark.parametrize("w,h,spp,chunks", [(96, 64, 7, 3), (333, 131, 12, 5), (200, 77, 64, 64), (64, 16, 5, 2), (1920, 1080, 9, 4)])
+def test_sample_chunks_change_no_bit(pkg, ora, w, h, spp, chunks):
+    """PTMI_OPT_INLINE_SPP_CHUNKS: the tile grid is launched `chunks` times over, copy c rendering a slice of the samples
+    after copy c-1 of the same tile has published its planes.  On a small image all copies are resident at once, so
+    every later copy really waits for its predecessor -- the result must equal the oracle (and the unchunked launch)."""
+    B = pkg.binding
+    scene = pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    start = initial_planes(ora, w, h)
+    with pkg.Context(0) as c:
+        c.set_option(B.OPT_INLINE_SPP_CHUNKS, chunks)
+        assert c.get_option(B.OPT_INLINE_SPP_CHUNKS) == chunks
+        got, stats = run_gpu(c, pkg, scene, cam, w, h, 8, spp, start)
+        c.set_option(B.OPT_INLINE_SPP_CHUNKS, 1)
+        plain, _ = run_gpu(c, pkg, scene, cam, w, h, 8, spp, start)
+    assert_planes_equal(got, plain, "chunked vs one launch")
+    if w * h <= 100000:
+        want, live = ora.render_inline(scene[0], scene[1], cam, w, h, 8, spp, start)
+        assert_planes_equal(got, want, "%d sample chunks" % chunks)
+        assert stats["live_bounces"] == live

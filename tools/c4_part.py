@@ -21,7 +21,11 @@ import __graft_entry__ as graft  # noqa: E402
 
 
 def timed(ctx, cam, limit, spp, chunks, pkg):
-    """One pass of `spp` samples as `chunks` equal launches; host clock around stream-ordered launches."""
+    """One pass of `spp` samples as `chunks` equal launches; host clock around stream-ordered launches.
+    chunks == 0: ONE launch with the in-kernel sample chunks (PTMI_OPT_INLINE_SPP_CHUNKS automatic); every other
+    figure is taken with them switched off."""
+    ctx.set_option(pkg.binding.OPT_INLINE_SPP_CHUNKS, 0 if chunks == 0 else 1)
+    chunks = max(chunks, 1)
     ctx.synchronize()
     t0 = time.perf_counter()
     for _ in range(chunks):
@@ -37,7 +41,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--parts", type=int, default=8)
     ap.add_argument("--stripes", default="8,10,6")
-    ap.add_argument("--chunks", default="1,8")
+    ap.add_argument("--chunks", default="0,1,8", help="0 = one launch with in-kernel sample chunks, k = k chained launches without")
     ap.add_argument("--repeats", type=int, default=3)
     args = ap.parse_args()
     pkg = graft.load_package()

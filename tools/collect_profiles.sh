@@ -1,0 +1,28 @@
+#!/bin/bash
+# collect_profiles.sh TAG -- after tools/profile_round.sh ran on the GPU box: summarise and copy into profiles/ (tracked).
+set -e
+TAG=${1:-r02}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+SRC=$ROOT/gpurun_out/prof_$TAG
+cp "$SRC/bench.json" "$ROOT/profiles/${TAG}_bench.json"
+cp "$SRC/bench_c4_one_gpu.json" "$ROOT/profiles/${TAG}_bench_c4_one_gpu.json"
+for w in c2 streams glass_tree glass_stream s16_stream; do
+    python3 "$ROOT/tools/pmc_summary.py" "$ROOT/gpurun_out/pmc_$w" > "$ROOT/profiles/${TAG}_pmc_$w.json"
+    cp "$ROOT"/gpurun_out/pmc_$w/stats/*/*_kernel_stats.csv "$ROOT/profiles/${TAG}_kernel_stats_$w.csv"
+done
+cp "$SRC/valu_rates.json" "$ROOT/profiles/${TAG}_valu_rates.json"
+python3 "$ROOT/tools/valu_roofline.py" "$ROOT/profiles/${TAG}_pmc_c2.json" "$ROOT/profiles/${TAG}_valu_rates.json" "$TAG" > /dev/null
+python3 - "$ROOT" "$TAG" <<'PY'
+import json, sys
+root, tag = sys.argv[1], sys.argv[2]
+d = json.load(open("%s/profiles/%s_pmc_c2.json" % (root, tag)))
+k = next(v for n, v in d.items() if "render_inline_kernel" in n)
+rd, wr = k["hbm_read_MB_per_call"] * 1e6, k["hbm_write_MB_per_call"] * 1e6
+json.dump({"hbm_bytes_per_launch": round(rd + wr), "fetch_bytes_corrected": round(rd), "write_bytes": round(wr),
+           "known_bytes_each_way": 7 * 1920 * 1080 * 4, "source": "profiles/%s_pmc_c2.json (FETCH_SIZE x 2 KiB, WRITE_SIZE KiB, separate passes)" % tag,
+           "workload": "C2"}, open("%s/profiles/traffic.json" % root, "w"), indent=1)
+PY
+cp "$SRC/c4_part.json" "$ROOT/profiles/${TAG}_c4_part.json"
+cp "$SRC/extra.json" "$ROOT/profiles/${TAG}_extra_measurements.json"
+cp "$SRC/phase_stats.json" "$ROOT/profiles/${TAG}_phase_stats.json"
+echo "profiles/${TAG}_* written"

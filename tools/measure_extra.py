@@ -39,7 +39,7 @@ def main():
         t_ramp = time.perf_counter()                      # leave the idle clock state first (as bench.py does)
         while time.perf_counter() - t_ramp < 0.5:
             ctx.render(cam, 8, 64); ctx.synchronize()
-        for v in (0, 1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, 15, 16, 17):
+        for v in (0, 1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, 15, 16, 17, 18):
             ctx.set_variant(v)
             ctx.init_output(0x5EED1234)
             for _ in range(3):
@@ -51,15 +51,42 @@ def main():
             ctx.synchronize()
             res[v] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
         out["c2_ms_by_variant"] = res
-        # --- Streams on C2
+        # --- Streams on C2: per-pixel form, stream form (ordered, and 16 samples per stream), both seed rules
+        B = pkg.binding
         ctx.set_variant(0)
-        ctx.init_output(0x5EED1234)
-        ctx.render(cam, 8, 64, pkg.STREAMS); ctx.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            ctx.render(cam, 8, 64, pkg.STREAMS)
-        ctx.synchronize()
-        out["c2_streams_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+
+        def streams_ms(n=5):
+            ctx.init_output(0x5EED1234)
+            for _ in range(2):
+                ctx.render(cam, 8, 64, pkg.STREAMS)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                ctx.render(cam, 8, 64, pkg.STREAMS)
+            ctx.synchronize()
+            return round((time.perf_counter() - t0) / n * 1e3, 3)
+
+        out["c2_streams_ms"] = streams_ms()
+        ctx.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_FROM_RESULT)
+        out["c2_streams_seed_from_result_ms"] = streams_ms()
+        ctx.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_KEEP_ACCUMULATOR)
+        ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+        out["c2_streams_stream_form_ms"] = streams_ms(3)
+        ctx.set_option(B.OPT_STREAM_BATCH, 16)
+        out["c2_streams_stream_form_batch16_ms"] = streams_ms(3)
+        ctx.set_option(B.OPT_STREAM_BATCH, 0)
+        ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_AUTO)
+        # --- the glass scene (GLASS extension), 1080p / 64 spp: tree walk (default) and stream form
+        ctx.set_scene(*pkg.world.glass_scene())
+        ctx.reset_stats()
+        out["glass_1080p_64spp_tree_ms"] = streams_ms()
+        st = ctx.stats()
+        out["glass_tree_live_rays_per_sample"] = round(st["live_bounces"] / st["samples"], 3)
+        out["glass_tree_dropped"] = st["stream_rays_dropped"]
+        ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+        out["glass_1080p_64spp_stream_form_ms"] = streams_ms(3)
+        ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_AUTO)
+        ctx.set_scene(sp, pl)
         # --- C3: 3840x2160, 256 spp, 8 bounces
         w, h = 3840, 2160
         ctx.resize(w, h)
@@ -75,6 +102,23 @@ def main():
         out["c3_Msamples_s"] = round(w * h * 256 * 8 / dt / 1e6, 1)
         out["c3_algorithmic_GBs"] = round(w * h * 256 * 56 / dt / 1e9, 1)
         out["c3_live_fraction"] = round(st["live_bounces"] / st["nominal_bounces"], 4)
+    # --- C5 per part: the glass scene at 3840x2160 / 512 spp on one of 8 row-stripe parts (tree walk)
+    with pkg.Context(0) as ctx:
+        ctx.set_scene(*pkg.world.glass_scene())
+        ctx.set_partition(10, 8, 3)
+        ctx.resize(3840, 2160)
+        ctx.init_output(0x5EED1234)
+        ctx.render(cam, 8, 32, pkg.STREAMS); ctx.synchronize()
+        ctx.init_output(0x5EED1234)
+        ctx.reset_stats()
+        t0 = time.perf_counter()
+        ctx.render(cam, 8, 512, pkg.STREAMS)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        st = ctx.stats()
+        out["c5_part_of_8_4k_512spp_ms"] = round(dt * 1e3, 2)
+        out["c5_part_live_Grays_s"] = round(st["live_bounces"] / dt / 1e9, 2)
+        out["c5_part_dropped"] = st["stream_rays_dropped"]
     print(json.dumps(out))
 
 

@@ -59,7 +59,9 @@ def main():
         "lane_iterations_needed": lane_iter, "lane_iterations_paid_by_waves": paid,
         "wave_tail_factor": paid / lane_iter,
         "round_A_occupancy": a / lane_iter, "round_B_occupancy": b / lane_iter, "round_C_occupancy": cc / lane_iter,
-        "iterations_per_sample": lane_iter / (w * h * spp)}))
+        "iterations_per_sample": lane_iter / (w * h * spp),
+        "frozen_shades_finished_cheaply_per_sample": c[6] / (w * h * spp),
+        "note": "round A counts lanes entering the shade round (frozen finishes included); round B exists only in variant 18 (round 1's loop)"}))
 
 
 if __name__ == "__main__":

@@ -1,36 +1,32 @@
 #!/bin/bash
 # profile_round.sh -- the measurement pass behind profiles/<tag>_* (run ON the GPU box, from the repo root):
-#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/profile_round.sh r01'
-# then, back in the container:  python tools/summarize_pmc.py gpurun_out/prof_r01 r01  and copy the rest (see below).
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/profile_round.sh r02'
+# then, back in the container:  bash tools/collect_profiles.sh r02   (copies the summaries into profiles/).
 # Counters are collected in their own passes (rocprofv3 --pmc with --kernel-trace only), the program itself after `--`.
-set -e -o pipefail
-TAG=${1:-r01}
+set -o pipefail
+TAG=${1:-r02}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp; cd "$ROOT"
 
-# 1. the bench line as the driver runs it (N = 1, defaults), cpu_baseline included
-python3 bench.py > "$OUT/bench.json"
-echo "bench done"
+# 1. the bench line as the driver runs it (N = 1, defaults), cpu_baseline included; C4 on one GPU (the N > 1 workload)
+python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.log"; echo "bench rc=$?"
+python3 bench.py --scaling strong --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c4_one_gpu.json" 2>> "$OUT/bench.log"; echo "bench C4 rc=$?"
 
-# 2. kernel trace of the same command (average duration of the dominant kernel must agree with roofline.kernel_ms)
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" --output-format csv -- python3 bench.py --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
-echo "kernel trace done"
+# 2. kernel trace + PMC passes, per workload: the headline kernel and the Streams kernels
+#    (tools/pmc_kernels.sh writes gpurun_out/pmc_<name>/; the same bench command under every pass)
+bash tools/pmc_kernels.sh c2 > "$OUT/pmc_c2.log" 2>&1; echo "pmc c2 rc=$?"
+bash tools/pmc_kernels.sh streams --algorithm streams > "$OUT/pmc_streams.log" 2>&1; echo "pmc streams rc=$?"
+bash tools/pmc_kernels.sh glass_tree --scene glass --algorithm streams > "$OUT/pmc_glass_tree.log" 2>&1; echo "pmc glass tree rc=$?"
+bash tools/pmc_kernels.sh glass_stream --scene glass --algorithm streams --streams-form stream > "$OUT/pmc_glass_stream.log" 2>&1; echo "pmc glass stream rc=$?"
+bash tools/pmc_kernels.sh s16_stream --algorithm streams --streams-form stream > "$OUT/pmc_s16_stream.log" 2>&1; echo "pmc s16 stream rc=$?"
 
-# 3. PMC passes
-i=0
-# (FETCH_SIZE and WRITE_SIZE do not fit one pass: "Request exceeds the capabilities of the hardware to collect")
-for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" \
-            "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \
-            "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" \
-            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
-    i=$((i + 1))
-    timeout -k 10 150 rocprofv3 --pmc $pass --kernel-trace -d "$OUT/pmc_$i" --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_$i.json" 2> "$OUT/pmc_$i.log"
-    echo "pmc pass $i done"
-done
+# 3. per-opcode VALU issue costs (shader-clock domain) -- with 2. the inputs of tools/valu_roofline.py
+if [ -x build/valu_rates ]; then timeout -k 10 600 build/valu_rates 1 2 6 8 > "$OUT/valu_rates.json" 2> "$OUT/valu_rates.err"; echo "valu_rates rc=$?"; fi
 
-# 4. side measurements quoted in DESIGN.md
-python3 tools/measure_extra.py > "$OUT/extra.json"
-python3 tools/measure_host_copies.py > "$OUT/host_copies.log"
+# 4. strong scaling bound on one GPU (C4 parts), side measurements, round occupancies
+timeout -k 10 400 python3 tools/c4_part.py > "$OUT/c4_part.json" 2> "$OUT/c4_part.log"; echo "c4_part rc=$?"
+timeout -k 10 400 python3 tools/measure_extra.py > "$OUT/extra.json" 2> "$OUT/extra.log"; echo "extra rc=$?"
+timeout -k 10 300 python3 tools/phase_stats.py > "$OUT/phase_stats.json" 2> "$OUT/phase_stats.log"; echo "phase rc=$?"
 echo "all done: $OUT"
