@@ -13,7 +13,7 @@ import numpy as np
 from . import _build
 from .world import CAMERA_DTYPE, PLANE_DTYPE, SPHERE_DTYPE, INLINE, STREAMS
 
-OPT_STREAMS_SEED_RULE, OPT_STREAM_STEP_CAP, OPT_STREAM_CAPACITY, OPT_STREAMS_FORM, OPT_STREAM_BATCH, OPT_INLINE_SPP_CHUNKS = 1, 2, 3, 4, 5, 6
+OPT_STREAMS_SEED_RULE, OPT_STREAM_STEP_CAP, OPT_STREAM_CAPACITY, OPT_STREAMS_FORM, OPT_STREAM_BATCH, OPT_SPP_CHUNKS = 1, 2, 3, 4, 5, 6
 SEED_KEEP_ACCUMULATOR, SEED_FROM_RESULT = 0, 1
 FORM_AUTO, FORM_STREAM = 0, 1
 PTMI_OK, PTMI_EINVAL, PTMI_ENODEVICE, PTMI_EHIP, PTMI_ENOMEM, PTMI_ESTATE, PTMI_ELIMIT = 0, -1, -2, -3, -4, -5, -6

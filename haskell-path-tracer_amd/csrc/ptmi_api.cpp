@@ -379,8 +379,8 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
         if (launches > 0) a.quad_order = c->d_quad_order;
         if (launches < (1 << 20)) { a.quad_cost = c->d_quad_cost; next_order_state = launches + 1; }   // the sums stay far from 2^32
     }
-    if (algorithm == PTMI_INLINE) {
-        // one word per tile workgroup for the sample chunks of the tiled kernel (ptmi_kernels.hip)
+    if (per_pixel_kernel) {
+        // one word per tile workgroup for the sample chunks of the tiled per-pixel kernels (ptmi_kernels.hip)
         const unsigned int need = ((unsigned int)(((width + 7) / 8) * ((rows_local + 7) / 8)) + 31u) & ~31u;
         if (need > c->chunk_capacity) {
             if (c->d_chunk_done) { PTMI_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_chunk_done); c->d_chunk_done = nullptr; c->chunk_capacity = 0; }
@@ -664,7 +664,7 @@ int ptmi_set_option(ptmi_ctx *c, int option, int64_t value)
     case PTMI_OPT_STREAM_BATCH:
         if (value < 0 || value > 64) return fail(c, PTMI_EINVAL, "stream batch must be in [0, 64] samples");
         c->opt_batch = (int)value; return PTMI_OK;
-    case PTMI_OPT_INLINE_SPP_CHUNKS:
+    case PTMI_OPT_SPP_CHUNKS:
         if (value < 0 || value > 64) return fail(c, PTMI_EINVAL, "sample chunks must be in [0, 64]");
         c->opt_spp_chunks = (int)value; return PTMI_OK;
     default: return fail(c, PTMI_EINVAL, "unknown option");
@@ -682,7 +682,7 @@ int ptmi_get_option(ptmi_ctx *c, int option, int64_t *value)
     case PTMI_OPT_STREAM_CAPACITY:   *value = c->opt_capacity; return PTMI_OK;
     case PTMI_OPT_STREAMS_FORM:      *value = c->opt_form; return PTMI_OK;
     case PTMI_OPT_STREAM_BATCH:      *value = c->opt_batch; return PTMI_OK;
-    case PTMI_OPT_INLINE_SPP_CHUNKS: *value = c->opt_spp_chunks; return PTMI_OK;
+    case PTMI_OPT_SPP_CHUNKS: *value = c->opt_spp_chunks; return PTMI_OK;
     default: return fail(c, PTMI_EINVAL, "unknown option");
     }
 }

@@ -355,6 +355,35 @@ __host__ inline unsigned int tile_grid(const RenderArgs &a, int tw)
     return (tiles + 31u) & ~31u;                             // see lane_pixel
 }
 
+// Sample chunks (see the comment in render_inline_kernel): which copy of the tile grid this workgroup is, which slice of
+// the samples it renders, and the wait for the previous copy of the same tile.
+template <int TILE_W>
+__device__ __forceinline__ void enter_sample_chunk(const RenderArgs &a, unsigned int &wg, int &chunk, int &n_spp_chunk)
+{
+    wg = blockIdx.x; chunk = 0; n_spp_chunk = a.n_spp;
+    if (TILE_W > 0 && a.spp_chunks > 1) {
+        const unsigned int per_copy = gridDim.x / (unsigned int)a.spp_chunks;
+        chunk = (int)(wg / per_copy);
+        wg -= (unsigned int)chunk * per_copy;
+        const int per = (a.n_spp + a.spp_chunks - 1) / a.spp_chunks;
+        n_spp_chunk = a.n_spp - chunk * per;
+        n_spp_chunk = n_spp_chunk < 0 ? 0 : (n_spp_chunk > per ? per : n_spp_chunk);
+        if (chunk > 0) {
+            while (__hip_atomic_load(a.chunk_done + wg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)chunk)
+                __builtin_amdgcn_s_sleep(16);
+        }
+    }
+}
+
+template <int TILE_W>
+__device__ __forceinline__ void leave_sample_chunk(const RenderArgs &a, unsigned int wg, int chunk)
+{
+    if (TILE_W > 0 && a.spp_chunks > 1 && chunk + 1 < a.spp_chunks) {     // publish: the next copy of this tile may start
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if ((threadIdx.x & 63) == 0) __hip_atomic_store(a.chunk_done + wg, (unsigned int)(chunk + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // render Inline.  LDS_SCENE: primitives staged in LDS (default) or read straight from
 // global memory through scalar loads (ablation).  MODE selects the loop shape:
@@ -388,20 +417,8 @@ __global__ void __launch_bounds__(kRenderBlock, (MODE == kCached || MODE == kCac
     // consumer waits (in practice it finished a whole round earlier: the wait falls through).  The planes travel through
     // memory between copies: release / acquire at agent scope (L2 write-back, L1 invalidate); copies of one tile run on
     // the same XCD (the grid of a copy is a multiple of 32).  Results do not depend on the chunking (sample-split invariance).
-    unsigned int wg = blockIdx.x;
-    int chunk = 0, n_spp_chunk = a.n_spp;
-    if (TILE_W > 0 && a.spp_chunks > 1) {
-        const unsigned int per_copy = gridDim.x / (unsigned int)a.spp_chunks;
-        chunk = (int)(wg / per_copy);
-        wg -= (unsigned int)chunk * per_copy;
-        const int per = (a.n_spp + a.spp_chunks - 1) / a.spp_chunks;
-        n_spp_chunk = a.n_spp - chunk * per;
-        n_spp_chunk = n_spp_chunk < 0 ? 0 : (n_spp_chunk > per ? per : n_spp_chunk);
-        if (chunk > 0) {
-            while (__hip_atomic_load(a.chunk_done + wg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)chunk)
-                __builtin_amdgcn_s_sleep(16);
-        }
-    }
+    unsigned int wg; int chunk, n_spp_chunk;
+    enter_sample_chunk<TILE_W>(a, wg, chunk, n_spp_chunk);
     long long pixel;
     unsigned int quad, trips = 0;
     const bool valid = lane_pixel<TILE_W>(a, pixel, quad, wg);
@@ -625,10 +642,7 @@ __global__ void __launch_bounds__(kRenderBlock, (MODE == kCached || MODE == kCac
         a.planes.sa[pixel] = seed.a; a.planes.sb[pixel] = seed.b;
         a.planes.sc[pixel] = seed.c; a.planes.sctr[pixel] = seed.counter;
     }
-    if (TILE_W > 0 && a.spp_chunks > 1 && chunk + 1 < a.spp_chunks) {     // publish: the next copy of this tile may start
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if ((threadIdx.x & 63) == 0) __hip_atomic_store(a.chunk_done + wg, (unsigned int)(chunk + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    leave_sample_chunk<TILE_W>(a, wg, chunk);
 
     if (TILE_W > 0) record_cost(a, quad, trips);
     if (a.live_counter) {
@@ -1022,9 +1036,11 @@ __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const R
     const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
     const float4 *M = S + a.scene.geom_f4();
 
+    unsigned int wg; int chunk, n_spp_chunk;
+    enter_sample_chunk<TILE_W>(a, wg, chunk, n_spp_chunk);            // sample chunks, as in render_inline_kernel
     long long pixel;
     unsigned int quad, trips = 0;
-    const bool valid = lane_pixel<TILE_W>(a, pixel, quad);
+    const bool valid = lane_pixel<TILE_W>(a, pixel, quad, wg);
     unsigned int live = 0, longest = 0, cut = 0;
     const unsigned int step_cap = (unsigned int)a.stream_step_cap;
     if (valid) {
@@ -1037,7 +1053,7 @@ __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const R
         Sfc32 pixel_seed;
         pixel_seed.a = a.planes.sa[pixel]; pixel_seed.b = a.planes.sb[pixel];
         pixel_seed.c = a.planes.sc[pixel]; pixel_seed.counter = a.planes.sctr[pixel];
-        const int n_spp = a.n_spp;
+        const int n_spp = n_spp_chunk;
 
         const HitSel h0 = check_hit(S, ns, np, origin, primary);   // same primary ray for every sample
         if (!h0.just) {
@@ -1116,6 +1132,7 @@ __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const R
         a.planes.sa[pixel] = pixel_seed.a; a.planes.sb[pixel] = pixel_seed.b;
         a.planes.sc[pixel] = pixel_seed.c; a.planes.sctr[pixel] = pixel_seed.counter;
     }
+    leave_sample_chunk<TILE_W>(a, wg, chunk);
     if (TILE_W > 0) record_cost(a, quad, trips);
     if (a.live_counter) {
         const unsigned long long total = wave_sum(live);
@@ -1210,9 +1227,11 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
     const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
     const float4 *M = S + a.scene.geom_f4();
 
+    unsigned int wg; int chunk, n_spp_chunk;
+    enter_sample_chunk<TILE_W>(a, wg, chunk, n_spp_chunk);            // sample chunks, as in render_inline_kernel
     long long pixel;
     unsigned int quad, trips = 0;
-    const bool valid = lane_pixel<TILE_W>(a, pixel, quad);
+    const bool valid = lane_pixel<TILE_W>(a, pixel, quad, wg);
     unsigned int live = 0, longest = 0, cut = 0, dropped = 0;
     const unsigned int step_cap = (unsigned int)a.stream_step_cap;
     if (valid) {
@@ -1225,7 +1244,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
         Sfc32 pixel_seed;
         pixel_seed.a = a.planes.sa[pixel]; pixel_seed.b = a.planes.sb[pixel];
         pixel_seed.c = a.planes.sc[pixel]; pixel_seed.counter = a.planes.sctr[pixel];
-        const int n_spp = a.n_spp;
+        const int n_spp = n_spp_chunk;
 
         const HitSel h0 = check_hit(S, ns, np, origin, primary);   // same primary ray for every sample
         if (!h0.just) {
@@ -1335,6 +1354,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
         a.planes.sa[pixel] = pixel_seed.a; a.planes.sb[pixel] = pixel_seed.b;
         a.planes.sc[pixel] = pixel_seed.c; a.planes.sctr[pixel] = pixel_seed.counter;
     }
+    leave_sample_chunk<TILE_W>(a, wg, chunk);
     if (TILE_W > 0) record_cost(a, quad, trips);
     if (a.live_counter) {
         const unsigned long long total = wave_sum(live);
@@ -1787,6 +1807,31 @@ hipError_t launch_quad_order(const unsigned int *cost, unsigned int *order, unsi
     return hipGetLastError();
 }
 
+// Sample chunks (render_inline_kernel): only when the launch has few rounds of waves and every copy keeps >= 64 samples
+// (every copy re-evaluates the primary hit and moves the planes once more).  Sets b.spp_chunks (>= 1) and clears the flags.
+static hipError_t choose_sample_chunks(RenderArgs &b, unsigned int per_copy, int waves_per_simd, hipStream_t stream)
+{
+    const int wanted = b.spp_chunks;                           // 0 = automatic, 1 = off, k = forced
+    b.spp_chunks = 1;
+    if (!b.chunk_done || b.chunk_capacity < per_copy || wanted == 1 || b.screen_x) return hipSuccess;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        if (cus <= 0) cus = 256;
+    }
+    const unsigned long long slots = (unsigned long long)cus * 4ull * (unsigned long long)waves_per_simd;
+    int k = wanted > 1 ? wanted : (int)((16ull * slots + per_copy - 1) / per_copy);    // aim at >= 16 rounds of waves
+    if (wanted <= 0 && k > b.n_spp / 64) k = b.n_spp / 64;
+    if (k > b.n_spp) k = b.n_spp;
+    if (k > 64) k = 64;
+    if (k < 2) return hipSuccess;
+    b.spp_chunks = k;
+    return hipMemsetAsync(b.chunk_done, 0, (size_t)per_copy * sizeof(unsigned int), stream);
+}
+
 hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t stream)
 {
     const long long n_local = (long long)a.rows_local * a.width;
@@ -1832,29 +1877,9 @@ hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t st
         return hipGetLastError();
     }
     if (variant == 17 || variant == 13) {
-        // sample chunks (see the kernel): only when the launch has few rounds of waves and every copy keeps >= 64 samples
         RenderArgs b = a;
         const unsigned int per_copy = tile_grid(a, 8);
-        b.spp_chunks = 1;
-        if (a.chunk_done && a.chunk_capacity >= per_copy && a.spp_chunks != 1) {
-            static int slots = 0;
-            if (!slots) {
-                int dev = 0, cus = 0;
-                hipError_t e = hipGetDevice(&dev);
-                if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-                if (e != hipSuccess) return e;
-                slots = (cus > 0 ? cus : 256) * 4 * 6;
-            }
-            int k = a.spp_chunks > 1 ? a.spp_chunks : (int)((16ull * (unsigned long long)slots + per_copy - 1) / per_copy);   // aim at >= 16 rounds
-            if (a.spp_chunks <= 0 && k > a.n_spp / 64) k = a.n_spp / 64;
-            if (k > a.n_spp) k = a.n_spp;
-            if (k > 64) k = 64;
-            if (k >= 2) {
-                b.spp_chunks = k;
-                hipError_t e = hipMemsetAsync(a.chunk_done, 0, (size_t)per_copy * sizeof(unsigned int), stream);
-                if (e != hipSuccess) return e;
-            }
-        }
+        if (hipError_t e = choose_sample_chunks(b, per_copy, 6, stream)) return e;
         const dim3 cgrid(per_copy * (unsigned int)b.spp_chunks);
         if (variant == 17) hipLaunchKernelGGL((render_inline_kernel<false, kCached, 8>), cgrid, block, 0, stream, b);
         else               hipLaunchKernelGGL((render_inline_kernel<true, kCached, 8>), cgrid, block, lds, stream, b);
@@ -1908,9 +1933,12 @@ hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t s
     const bool scalar_scene = variant == 5 || variant == 6 || variant == 17 || lds > kMaxSceneLds;
     const bool tiles = variant == 4 || variant == 5 ? false : tiles_pay(a);      // 4 / 5 keep the row mapping (ablation)
     if (tiles) {
-        const dim3 tgrid(tile_grid(a, 8));
-        if (scalar_scene) hipLaunchKernelGGL((render_streams_kernel<false, 8>), tgrid, block, 0, stream, a);
-        else              hipLaunchKernelGGL((render_streams_kernel<true, 8>), tgrid, block, lds, stream, a);
+        RenderArgs b = a;
+        const unsigned int per_copy = tile_grid(a, 8);
+        if (hipError_t ce = choose_sample_chunks(b, per_copy, 6, stream)) return ce;
+        const dim3 tgrid(per_copy * (unsigned int)b.spp_chunks);
+        if (scalar_scene) hipLaunchKernelGGL((render_streams_kernel<false, 8>), tgrid, block, 0, stream, b);
+        else              hipLaunchKernelGGL((render_streams_kernel<true, 8>), tgrid, block, lds, stream, b);
     } else {
         if (scalar_scene) hipLaunchKernelGGL((render_streams_kernel<false>), grid, block, 0, stream, a);
         else              hipLaunchKernelGGL((render_streams_kernel<true>), grid, block, lds, stream, a);
@@ -1929,9 +1957,12 @@ hipError_t launch_render_streams_tree(const RenderArgs &a, int variant, hipStrea
     const bool scalar_scene = variant == 5 || variant == 17 || lds > kMaxSceneLds;
     const bool tiles = variant == 4 || variant == 5 ? false : tiles_pay(a);
     if (tiles) {
-        const dim3 tgrid(tile_grid(a, 8));
-        if (scalar_scene) hipLaunchKernelGGL((render_streams_tree_kernel<false, 8>), tgrid, block, 0, stream, a);
-        else              hipLaunchKernelGGL((render_streams_tree_kernel<true, 8>), tgrid, block, lds, stream, a);
+        RenderArgs b = a;
+        const unsigned int per_copy = tile_grid(a, 8);
+        if (hipError_t ce = choose_sample_chunks(b, per_copy, PTMI_TREE_WAVES, stream)) return ce;
+        const dim3 tgrid(per_copy * (unsigned int)b.spp_chunks);
+        if (scalar_scene) hipLaunchKernelGGL((render_streams_tree_kernel<false, 8>), tgrid, block, 0, stream, b);
+        else              hipLaunchKernelGGL((render_streams_tree_kernel<true, 8>), tgrid, block, lds, stream, b);
     } else {
         if (scalar_scene) hipLaunchKernelGGL((render_streams_tree_kernel<false>), grid, block, 0, stream, a);
         else              hipLaunchKernelGGL((render_streams_tree_kernel<true>), grid, block, lds, stream, a);

@@ -141,7 +141,7 @@ int ptmi_set_timing(ptmi_ctx *ctx, int enabled);
 int ptmi_set_variant(ptmi_ctx *ctx, int variant);
 
 /* Options.  1-5 concern `render Streams` (src/Scene/Trace.hs:141-191) and never change `render Inline`; 6 is a
- * scheduling knob of `render Inline` that changes no result. */
+ * scheduling knob of the per-pixel kernels that changes no result. */
 enum {
     /* Which seed a pixel carries out of `combine` (Trace.hs:179-184): the combination function keeps the seed of its
      * FIRST argument and Accelerate's `permute` does not define which of (accumulator element, new value) that is.
@@ -166,10 +166,11 @@ enum {
      * GLASS trades that order for fewer, longer launches: colours then agree to rounding only (Accelerate's `permute`
      * does not define the order either); the RNG planes stay exact. */
     PTMI_OPT_STREAM_BATCH = 5,
-    /* render Inline, a scheduling knob that changes no result: a launch of few pixels and many samples (one part of a
-     * multi-GPU image) is cut into this many chained copies of the tile grid, each rendering a slice of the samples, so
-     * that the end of the launch does not run on a partly empty chip.  0 (default) = automatic, 1 = off, k = k copies. */
-    PTMI_OPT_INLINE_SPP_CHUNKS = 6
+    /* The per-pixel kernels of both algorithms, a scheduling knob that changes no result: a launch of few pixels and
+     * many samples (one part of a multi-GPU image) is cut into this many chained copies of the tile grid, each rendering
+     * a slice of the samples, so that the end of the launch does not run on a partly empty chip.
+     * 0 (default) = automatic, 1 = off, k = k copies. */
+    PTMI_OPT_SPP_CHUNKS = 6
 };
 enum { PTMI_SEED_KEEP_ACCUMULATOR = 0, PTMI_SEED_FROM_RESULT = 1 };
 enum { PTMI_FORM_AUTO = 0, PTMI_FORM_STREAM = 1 };

@@ -118,7 +118,7 @@ def test_cost_ordered_dispatch_changes_nothing_but_the_order(pkg, ora):
 
 @pytest.mark.parametrize("w,h,spp,chunks", [(96, 64, 7, 3), (333, 131, 12, 5), (200, 77, 64, 64), (64, 16, 5, 2), (1920, 1080, 9, 4)])
 def test_sample_chunks_change_no_bit(pkg, ora, w, h, spp, chunks):
-    """PTMI_OPT_INLINE_SPP_CHUNKS: the tile grid is launched `chunks` times over, copy c rendering a slice of the samples
+    """PTMI_OPT_SPP_CHUNKS: the tile grid is launched `chunks` times over, copy c rendering a slice of the samples
     after copy c-1 of the same tile has published its planes.  On a small image all copies are resident at once, so
     every later copy really waits for its predecessor -- the result must equal the oracle (and the unchunked launch)."""
     B = pkg.binding
@@ -126,10 +126,10 @@ def test_sample_chunks_change_no_bit(pkg, ora, w, h, spp, chunks):
     cam = pkg.world.initial_camera()
     start = initial_planes(ora, w, h)
     with pkg.Context(0) as c:
-        c.set_option(B.OPT_INLINE_SPP_CHUNKS, chunks)
-        assert c.get_option(B.OPT_INLINE_SPP_CHUNKS) == chunks
+        c.set_option(B.OPT_SPP_CHUNKS, chunks)
+        assert c.get_option(B.OPT_SPP_CHUNKS) == chunks
         got, stats = run_gpu(c, pkg, scene, cam, w, h, 8, spp, start)
-        c.set_option(B.OPT_INLINE_SPP_CHUNKS, 1)
+        c.set_option(B.OPT_SPP_CHUNKS, 1)
         plain, _ = run_gpu(c, pkg, scene, cam, w, h, 8, spp, start)
     assert_planes_equal(got, plain, "chunked vs one launch")
     if w * h <= 100000:

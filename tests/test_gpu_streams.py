@@ -154,3 +154,28 @@ def test_long_lineages_and_the_step_cap(ctx, pkg, ora, stream_form):
     finally:
         ctx.set_option(B.OPT_STREAM_STEP_CAP, 1 << 16)
         ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_AUTO)
+
+
+@pytest.mark.parametrize("scene_name", ["s16", "glass"])
+def test_sample_chunks_of_the_streams_kernels(pkg, ora, scene_name):
+    """PTMI_OPT_SPP_CHUNKS on the per-pixel Streams kernels (chain and tree walk): chained copies of the tile grid, each
+    a slice of the samples -- bit-identical to the oracle."""
+    B = pkg.binding
+    scene = pkg.world.scene16() if scene_name == "s16" else pkg.world.glass_scene()
+    cam = pkg.world.initial_camera()
+    w, h, spp = 136, 70, 11
+    start = initial_planes(ora, w, h)
+    with pkg.Context(0) as c:
+        c.set_option(B.OPT_SPP_CHUNKS, 4)
+        c.set_scene(*scene)
+        c.resize(w, h)
+        c.upload_state(*start)
+        c.render(cam, 15, spp, pkg.STREAMS)
+        got = c.download_state()
+        live = c.stats()["live_bounces"]
+    if scene_name == "s16":
+        want, live_ref = ora.render_streams(scene[0], scene[1], cam, w, h, CAP, spp, start)
+    else:
+        want, live_ref = ora.render_streams_tree(scene[0], scene[1], cam, w, h, CAP, spp, start)[:2]
+    assert_planes_equal(got, want, "streams in 4 sample chunks (%s)" % scene_name)
+    assert live == live_ref

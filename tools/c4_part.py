@@ -22,9 +22,9 @@ import __graft_entry__ as graft  # noqa: E402
 
 def timed(ctx, cam, limit, spp, chunks, pkg):
     """One pass of `spp` samples as `chunks` equal launches; host clock around stream-ordered launches.
-    chunks == 0: ONE launch with the in-kernel sample chunks (PTMI_OPT_INLINE_SPP_CHUNKS automatic); every other
+    chunks == 0: ONE launch with the in-kernel sample chunks (PTMI_OPT_SPP_CHUNKS automatic); every other
     figure is taken with them switched off."""
-    ctx.set_option(pkg.binding.OPT_INLINE_SPP_CHUNKS, 0 if chunks == 0 else 1)
+    ctx.set_option(pkg.binding.OPT_SPP_CHUNKS, 0 if chunks == 0 else 1)
     chunks = max(chunks, 1)
     ctx.synchronize()
     t0 = time.perf_counter()
