@@ -69,10 +69,19 @@ constexpr int kStreamStepCapDefault = 1 << 16;   // traceSteps per ray lineage; 
 //   [kLvLive, +8) children emitted, sharded by workgroup | kLvCut rays cut by the step cap | kLvDropped children that found
 //   the output stream full | kLvDeepest deepest step + 1 | kLvCursor + 2 l: the reservation cursor of the stream level l WRITES
 //   (= the item count, holes included, of the stream level l + 1 reads) | kLvCursor + 2 l + 1: the children level l stored
-constexpr int kLvLive = 0, kLvCut = 8, kLvDropped = 9, kLvDeepest = 10, kLvCursor = 11, kLvMaxLevels = 64;
+constexpr int kLvLive = 0, kLvCut = 8, kLvDropped = 9, kLvDeepest = 10, kLvHits = 11, kLvCursor = 12, kLvMaxLevels = 64;   // kLvHits: pixels whose primary ray hits
 constexpr int kLvWords = (kLvCursor + 2 * kLvMaxLevels) * kCounterStride;
+// The primary hits of the pixels held by a context, compacted (pixels whose primary ray misses take no part in a
+// sample beyond updateSeed): one record per hit pixel, struct-of-arrays, written once per render call.
+struct HitList {
+    float *f[9];            // hit position, normal, primary direction
+    uint32_t *idx;          // primitive hit
+    uint32_t *pixel;        // local pixel index
+};
+constexpr int kHitListWords = 11;
 struct LevelArgs {
-    RayQueue in, out;               // `in` is unused by level 0 (its rays are generated on the fly)
+    RayQueue in, out;               // `in` is unused by level 0 (it starts from the cached primary hits)
+    HitList hits;                   // level 0
     const unsigned int *in_count;   // device: the producer level's cursor (NULL for level 0)
     unsigned int *out_count;        // device: this level's reservation cursor, preset to grid * (first block size)
     unsigned int *emitted;          // device: children this level stored in `out`
@@ -82,6 +91,7 @@ struct LevelArgs {
 };
 
 hipError_t launch_streams_level(const RenderArgs &a, const LevelArgs &lv, bool first, unsigned int grid, hipStream_t stream);
+hipError_t launch_streams_primary(const RenderArgs &a, HitList hits, unsigned int *hit_count, hipStream_t stream);
 unsigned int streams_first_block();   // output slots every wave of a level owns from the start
 hipError_t launch_streams_update_seed(Planes p, long long n, int draws, hipStream_t stream);
 

@@ -1374,16 +1374,20 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
 }
 
 // ---------------------------------------------------------------------------------------
-// render Streams as a stream, the kernel.  One launch per LEVEL of the ray tree; a level's input is a compacted stream
-// of ray states in HBM (level 0: the primary rays of `batch` samples of every pixel, generated on the fly -- no init
-// pass writes them out), its output the stream of the children that could not stay in a lane.
+// render Streams as a stream, the kernels.  One launch per LEVEL of the ray tree; a level's input is a compacted stream
+// in HBM -- level 0: the cached primary HITS of the pixels (streams_primary_kernel: every sample of a pixel shoots the
+// same primary ray, Trace.hs:244-262, so its checkHit + hit are evaluated once per render call, and pixels whose primary
+// ray misses never enter a stream), later levels: the ray states of the children that could not stay in a lane.
 //   * persistent waves: wave w takes the 64-item chunks w, w + G, w + 2G, ... of the input (static striding: every
 //     wave sees the whole image, no hand-out atomics);
 //   * a lane follows its ray's LINEAGE: a Matte / Glossy hit spawns one child, which simply is the lane's next ray; at
 //     a GLASS hit (two children) the reflection stays in the lane and only the refraction goes to the output stream;
-//   * REFILL: when a lineage ends (miss, nearZero throughput) the lane takes the next unprocessed item of the wave's
-//     current chunk -- ballot of the idle lanes + popcount prefix for the rank -- so the trace / shade rounds run dense
-//     although lineages differ in length (the old step kernel idled until the slowest of 64 lineages had ended);
+//   * loop shape [refill][shade][trace].  A hit found by the trace round whose ray arrived with near-zero throughput
+//     (numNewRays = 0, Trace.hs:329-331) adds its emittance right there and ends the lineage, so every lane that enters
+//     the shade round is alive, and a lineage that ends that way costs one shade and one trace per trip;
+//   * REFILL: when a lineage ends the lane takes the next unprocessed item of the wave's current chunk -- ballot of the
+//     idle lanes + popcount prefix for the rank -- so the rounds run dense although lineages differ in length (round 1's
+//     step kernel idled until the slowest of 64 lineages had ended);
 //   * `expand` (Trace.hs:284-289) = wave-level compaction into the output stream: ballot of the lanes that emit a
 //     child, popcount prefix for the slot, space reserved a BLOCK at a time (the first block of every wave is static,
 //     later ones cost one atomic per 256 children: a single counter word serves only ~90 requests/us).  What is left
@@ -1404,6 +1408,46 @@ constexpr unsigned int kFirstBlock = 64, kNextBlock = 256;   // output slots a w
 #endif
 constexpr unsigned int kRefillBatch = PTMI_REFILL_BATCH;     // idle lanes a wave waits for before it runs the refill block
 
+// Level 0's input: the primary hit of every pixel whose primary ray hits something, compacted (ballot + prefix per wave,
+// one atomic per workgroup).  The order of the list does not matter: a pixel has one lineage per stream unless rays split.
+__global__ void __launch_bounds__(kBlock) streams_primary_kernel(const RenderArgs a, const HitList out, unsigned int *hit_count)
+{
+    __shared__ unsigned int wave_hits[kBlock / 64];
+    __shared__ unsigned int block_base;
+    const int ns = a.scene.n_spheres, np = a.scene.n_planes;
+    const float4 *S = a.scene.packed;                        // one evaluation per pixel and call: scalar loads will do
+    const long long n_local = (long long)a.rows_local * a.width;
+    const long long pixel = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool hit = false;
+    V3 pos = mk(0, 0, 0), normal = pos, primary = pos;
+    int idx = 0;
+    if (pixel < n_local) {
+        const int local_row = (int)(pixel / a.width);
+        const int col = (int)(pixel - (long long)local_row * a.width);
+        primary = primary_direction(a.cam, col, global_row(local_row, a.stripe_rows, a.n_parts, a.part));
+        const HitSel h = check_hit(S, ns, np, a.cam.pos, primary);
+        if (h.just) { hit = true; idx = h.idx; hit_record(S, ns, h.idx, a.cam.pos, primary, h.t, pos, normal); }
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (lane == 0) wave_hits[wave] = (unsigned int)__builtin_popcountll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int total = 0;
+        for (int w = 0; w < kBlock / 64; ++w) total += wave_hits[w];
+        block_base = total ? atomicAdd(hit_count, total) : 0u;
+    }
+    __syncthreads();
+    if (hit) {
+        unsigned int slot = block_base + (unsigned int)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) slot += wave_hits[w];
+        out.f[0][slot] = pos.x; out.f[1][slot] = pos.y; out.f[2][slot] = pos.z;
+        out.f[3][slot] = normal.x; out.f[4][slot] = normal.y; out.f[5][slot] = normal.z;
+        out.f[6][slot] = primary.x; out.f[7][slot] = primary.y; out.f[8][slot] = primary.z;
+        out.idx[slot] = (uint32_t)idx; out.pixel[slot] = (uint32_t)pixel;
+    }
+}
+
 template <bool LDS_SCENE, bool FIRST>
 __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_kernel(const RenderArgs a, const LevelArgs lv)
 {
@@ -1421,38 +1465,28 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
     const unsigned int G = gridDim.x, w = blockIdx.x;
     const unsigned int step_cap = (unsigned int)a.stream_step_cap;
 
-    // input: level 0 = chunks_per_sample * batch chunks of <= 64 pixels; later levels = ceil(n_in / 64) chunks of the stream
-    const unsigned int n_px = lv.n_px, cps = (n_px + 63u) / 64u;
-    unsigned int n_in = 0, n_chunks;
-    if (FIRST) n_chunks = cps * (unsigned int)lv.batch;
-    else {
-        n_in = *lv.in_count;                                  // the producer's cursor: real items and holes
-        n_in = n_in < lv.in.capacity ? n_in : lv.in.capacity;
-        n_chunks = (n_in + 63u) / 64u;
-    }
+    // input: level 0 = chunks_per_sample * batch chunks of <= 64 cached primary hits; later levels = ceil(n_in / 64) chunks
+    unsigned int n_in = *lv.in_count;                         // level 0: hit pixels; else the producer's cursor (real items and holes)
+    if (!FIRST) n_in = n_in < lv.in.capacity ? n_in : lv.in.capacity;
+    const unsigned int cps = (n_in + 63u) / 64u;
+    const unsigned int n_chunks = FIRST ? cps * (unsigned int)lv.batch : cps;
     unsigned int chunk = w, taken = 0;                       // wave-uniform cursor: chunk index, items of it already handed out
     unsigned int blk = w * kFirstBlock, blk_end = blk + kFirstBlock;   // wave-uniform: the output block being filled
-    // wave-uniform description of the current chunk, recomputed only when the cursor moves to another chunk, so that
-    // the refill below needs no per-lane integer division
-    unsigned int chunk_len = 0, chunk_j = 0, chunk_px0 = 0, chunk_row0 = 0, chunk_col0 = 0;
+    // wave-uniform description of the current chunk, recomputed only when the cursor moves to another chunk
+    unsigned int chunk_len = 0, chunk_j = 0, chunk_first = 0;
     auto open_chunk = [&]() {
         if (chunk >= n_chunks) { chunk_len = 0; return; }
-        if (FIRST) {
-            chunk_j = chunk / cps;
-            chunk_px0 = (chunk - chunk_j * cps) * 64u;
-            chunk_len = n_px - chunk_px0 < 64u ? n_px - chunk_px0 : 64u;
-            chunk_row0 = chunk_px0 / (unsigned int)a.width;
-            chunk_col0 = chunk_px0 - chunk_row0 * (unsigned int)a.width;
-        } else {
-            chunk_len = n_in - chunk * 64u < 64u ? n_in - chunk * 64u : 64u;
-        }
+        chunk_j = FIRST ? chunk / cps : 0u;
+        chunk_first = (chunk - chunk_j * cps) * 64u;          // first item of the chunk within the sample / the stream
+        chunk_len = n_in - chunk_first < 64u ? n_in - chunk_first : 64u;
     };
     open_chunk();
 
-    bool has_ray = false;
-    V3 o = mk(0, 0, 0), d = o, throughput = o;
+    bool has_ray = false, pending = false;                    // a ray to trace / a hit to shade
+    V3 o = mk(0, 0, 0), d = o, throughput = o, normal = o;    // o: the ray's origin, or the position of the pending hit
     Sfc32 seed; seed.a = seed.b = seed.c = seed.counter = 0;
-    uint32_t pixel = 0, depth = 0, hits = 0;
+    uint32_t pixel = 0, depth = 0, hits = 0;                  // depth: step index of the lane's current ray
+    int idx = 0;
     unsigned int live = 0, cut = 0, dropped = 0, deepest = 0, stored = 0;
 
     // combine new old (PTMI_SEED_FROM_RESULT; never with GLASS): the seed the lineage's last hit carried = the pixel's
@@ -1463,34 +1497,39 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
             for (unsigned int k = 3u; k < 3u * hits; ++k) (void)sfc32_next(sd);
             a.planes.sa[pixel] = sd.a; a.planes.sb[pixel] = sd.b; a.planes.sc[pixel] = sd.c; a.planes.sctr[pixel] = sd.counter;
         }
-        has_ray = false;
+        has_ray = false; pending = false;
+    };
+    // computeResult + permute (+) (Trace.hs:179-184, :318-323); adding an exact zero changes nothing
+    auto add_colour = [&](V3 c) {
+        if (c.x != 0.0f) atomicAdd(a.planes.r + pixel, c.x);
+        if (c.y != 0.0f) atomicAdd(a.planes.g + pixel, c.y);
+        if (c.z != 0.0f) atomicAdd(a.planes.b + pixel, c.z);
     };
 
     for (;;) {
         // ---- refill: idle lanes take the next items of the wave's current chunk.  The block runs for the whole wave
         // whenever it runs, so it waits until kRefillBatch lanes are idle -- or nothing else is in flight.
-        const unsigned long long idle = __ballot(!has_ray);
+        const unsigned long long idle = __ballot(!has_ray && !pending);
         if (chunk < n_chunks && ((unsigned int)__builtin_popcountll(idle) >= kRefillBatch || (idle && !~idle))) {   // wave-uniform
             const unsigned int want = (unsigned int)__builtin_popcountll(idle), avail = chunk_len - taken;
             const unsigned int take = want < avail ? want : avail;
             const unsigned int rank = (unsigned int)__builtin_popcountll(idle & below);
-            if (!has_ray && rank < take) {
-                const unsigned int k = taken + rank;
+            if (!has_ray && !pending && rank < take) {
+                const unsigned int i = chunk_first + taken + rank;
                 if (FIRST) {
-                    // initialState (Trace.hs:158-162); sample j of the batch starts from the pixel's seed advanced by j
-                    // draws, which is what j applications of updateSeed leave behind (Trace.hs:190-191)
-                    pixel = chunk_px0 + k;
-                    unsigned int col = chunk_col0 + k, row = chunk_row0;
-                    while (col >= (unsigned int)a.width) { col -= (unsigned int)a.width; ++row; }
-                    const int image_row = a.n_parts == 1 ? (int)row : global_row((int)row, a.stripe_rows, a.n_parts, a.part);
-                    o = a.cam.pos;
-                    d = primary_direction(a.cam, (int64_t)col, (int64_t)image_row);
+                    // initialState (Trace.hs:158-162) one step on: the pixel's cached primary hit; sample j of the batch
+                    // starts from the pixel's seed advanced by j draws, which is what j updateSeeds leave (Trace.hs:190-191)
+                    pixel = lv.hits.pixel[i];
+                    o = mk(lv.hits.f[0][i], lv.hits.f[1][i], lv.hits.f[2][i]);
+                    normal = mk(lv.hits.f[3][i], lv.hits.f[4][i], lv.hits.f[5][i]);
+                    d = mk(lv.hits.f[6][i], lv.hits.f[7][i], lv.hits.f[8][i]);
+                    idx = (int)lv.hits.idx[i];
                     throughput = mk(1.0f, 1.0f, 1.0f);
                     seed.a = a.planes.sa[pixel]; seed.b = a.planes.sb[pixel]; seed.c = a.planes.sc[pixel]; seed.counter = a.planes.sctr[pixel];
                     for (unsigned int q = 0; q < chunk_j; ++q) (void)random_float(seed);
-                    depth = 0; hits = 0; has_ray = true;
+                    depth = 0; hits = 0; pending = true;
+                    deepest = deepest > 1u ? deepest : 1u;    // the primary ray's traceStep
                 } else {
-                    const unsigned int i = chunk * 64u + k;
                     pixel = lv.in.pixel[i];
                     if (pixel != kHole) {
                         o = mk(lv.in.f[0][i], lv.in.f[1][i], lv.in.f[2][i]);
@@ -1504,50 +1543,32 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
             taken += take;
             if (taken >= chunk_len) { chunk += G; taken = 0; open_chunk(); }
         }
-        if (!__any(has_ray)) {
+        if (!__any(has_ray || pending)) {
             if (chunk >= n_chunks) break;
             continue;                                         // a chunk of holes: look at the next one
         }
 
-        // ---- one traceStep (Trace.hs:272-294) for every lane that holds a ray
+        // ---- shade round: every pending hit belongs to a ray that is alive (dead ones were finished after their trace)
         bool emits = false;
         V3 ko = o, kd = o, kt = o; Sfc32 ks = seed;
-        if (has_ray) {
-            if (depth >= step_cap) {                          // the safety cap (the reference has none): the ray is in the stream, never traced
-                ++cut; lineage_ended();
+        if (pending) {
+            const float4 ma = M[2 * idx], mb = M[2 * idx + 1];
+            V3 contribution;
+            ++hits;
+            if (f2u(mb.x) == 2u) {                            // GLASS (extension): reflection stays, refraction is emitted
+                contribution = scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput;
+                V3 co[2], cd[2], ct[2]; Sfc32 cs[2];
+                glass_children(mk(ma.x, ma.y, ma.z), mb.y, o, normal, d, throughput, seed, co, cd, ct, cs);
+                o = co[0]; d = cd[0]; throughput = ct[0]; seed = cs[0];
+                ko = co[1]; kd = cd[1]; kt = ct[1]; ks = cs[1];
+                emits = true; live += 2u;
             } else {
-                deepest = depth + 1u > deepest ? depth + 1u : deepest;
-                const HitSel h = check_hit(S, ns, np, o, d);
-                if (!h.just) {
-                    lineage_ended();
-                } else {
-                    V3 hit_pos, normal;
-                    hit_record(S, ns, h.idx, o, d, h.t, hit_pos, normal);
-                    const float4 ma = M[2 * h.idx], mb = M[2 * h.idx + 1];
-                    const bool alive = !near_zero(throughput);                  // numNewRays (Trace.hs:329-331)
-                    V3 contribution;
-                    ++hits;
-                    if (f2u(mb.x) == 2u) {                                        // GLASS (extension): reflection stays, refraction is emitted
-                        contribution = scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput;
-                        if (alive) {
-                            V3 co[2], cd[2], ct[2]; Sfc32 cs[2];
-                            glass_children(mk(ma.x, ma.y, ma.z), mb.y, hit_pos, normal, d, throughput, seed, co, cd, ct, cs);
-                            o = co[0]; d = cd[0]; throughput = ct[0]; seed = cs[0];
-                            ko = co[1]; kd = cd[1]; kt = ct[1]; ks = cs[1];
-                            emits = true; live += 2u;
-                        }
-                    } else {
-                        contribution = mk(0.0f, 0.0f, 0.0f);
-                        shade(M, h.idx, hit_pos, normal, o, d, throughput, contribution, seed);   // contribution = 0 + emittance * throughput
-                        if (alive) ++live;
-                    }
-                    // computeResult + permute (+) (Trace.hs:179-184, :318-323); adding an exact zero changes nothing
-                    if (contribution.x != 0.0f) atomicAdd(a.planes.r + pixel, contribution.x);
-                    if (contribution.y != 0.0f) atomicAdd(a.planes.g + pixel, contribution.y);
-                    if (contribution.z != 0.0f) atomicAdd(a.planes.b + pixel, contribution.z);
-                    if (alive) ++depth; else lineage_ended();
-                }
+                contribution = mk(0.0f, 0.0f, 0.0f);
+                shade(M, idx, o, normal, o, d, throughput, contribution, seed);   // contribution = 0 + emittance * throughput
+                ++live;
             }
+            add_colour(contribution);
+            ++depth; pending = false; has_ray = true;          // the child: next traceStep, same lane
         }
         // ---- expand: compaction of the emitted children into the output stream
         const unsigned long long kids = __ballot(emits);
@@ -1565,8 +1586,31 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
                 blk += cnt;
             }
             if (emits) {
-                if (slot < lv.out.capacity) { queue_store(lv.out, slot, ko, kd, kt, pixel, ks, depth); ++stored; }   // depth: already the child's step index
+                if (slot < lv.out.capacity) { queue_store(lv.out, slot, ko, kd, kt, pixel, ks, depth); ++stored; }   // depth: the child's step index
                 else ++dropped;
+            }
+        }
+        // ---- trace round: one traceStep (Trace.hs:272-294) for every lane that holds a ray
+        if (has_ray) {
+            if (depth >= step_cap) {                          // the safety cap (the reference has none): the ray is in the stream, never traced
+                ++cut; lineage_ended();
+            } else {
+                deepest = depth + 1u > deepest ? depth + 1u : deepest;
+                const HitSel h = check_hit(S, ns, np, o, d);
+                if (!h.just) {
+                    lineage_ended();
+                } else {
+                    hit_record(S, ns, h.idx, o, d, h.t, o, normal);
+                    idx = h.idx;
+                    if (near_zero(throughput)) {              // numNewRays = 0: the hit adds its emittance, nothing else of it survives
+                        const float4 ma = M[2 * idx];
+                        ++hits;
+                        add_colour(scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);
+                        lineage_ended();
+                    } else {
+                        has_ray = false; pending = true;
+                    }
+                }
             }
         }
     }
@@ -1987,6 +2031,14 @@ hipError_t launch_streams_level(const RenderArgs &a, const LevelArgs &lv, bool f
 }
 
 unsigned int streams_first_block() { return kFirstBlock; }
+
+hipError_t launch_streams_primary(const RenderArgs &a, HitList hits, unsigned int *hit_count, hipStream_t stream)
+{
+    const long long n = (long long)a.rows_local * a.width;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(streams_primary_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, a, hits, hit_count);
+    return hipGetLastError();
+}
 
 hipError_t launch_streams_update_seed(Planes p, long long n, int draws, hipStream_t stream)
 {
