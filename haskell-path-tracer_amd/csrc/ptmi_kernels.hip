@@ -177,6 +177,20 @@ __device__ __forceinline__ void hit_record(ScenePtr S, int ns, int idx, V3 o, V3
     }
 }
 
+// normal (Intersection.hs:50 / :64) of primitive idx at a hit position computed earlier: the second half of hit_record
+template <typename ScenePtr>
+__device__ __forceinline__ V3 normal_at(ScenePtr S, int ns, int idx, V3 hit_pos)
+{
+    if (idx < ns) {
+        const float4 g = S[idx];
+        const V3 v = hit_pos - mk(g.x, g.y, g.z);
+        const float len2 = dot(v, v);
+        return (near_zero(len2) || near_zero(1.0f - len2)) ? v : div_r(v, sqrt_rn(len2));
+    }
+    const float4 gn = S[ns + 2 * (idx - ns) + 1];
+    return mk(gn.x, gn.y, gn.z);
+}
+
 // genVec (Util.hs:114-118) for the device: component = (random * 2.0) - 1.0 with
 // random = (float(int32 w) * 2^-32 + 0.5) + 2^-33.  Doubling is exact and commutes with rounding
 // here (no value leaves the normal range), so the doubled form below is the same binary32 value
@@ -1199,15 +1213,23 @@ __device__ __forceinline__ void glass_children(V3 color, float ior, V3 p, V3 n, 
 // ---------------------------------------------------------------------------------------
 // render Streams for scenes whose rays SPLIT (the build-defined GLASS extension), per-pixel form: the tree walk.
 // A lane owns a pixel and walks each sample's ray TREE depth first: at a GLASS hit the reflection child continues in
-// the lane and the refraction child waits on a small lane-private stack (scratch memory: pushed and popped by the same
-// lane, L2-resident); when a lineage ends the lane pops the most recent waiting child, and only when the stack is
-// empty does it start the pixel's next sample.  Compared with the stream form below: no ray ever travels through HBM
-// queues, a colour word has ONE adder (no atomics, and the order of a pixel's additions is defined: depth first,
-// reflection before refraction -- oracle: ora_render_streams_tree, bit-exact), the primary hit is cached per pixel and
-// the waves are dispatched by recorded cost, exactly as in render_streams_kernel.  What it gives up is the stream's
-// density: a lane whose pixel's trees are small idles at the end of the wave.  The set of rays traced is the stream
-// algorithm's (same children, same seeds, same step indices); a child that finds the stack full (kTreeStackDepth
-// pending children in one lane) is dropped and counted, like a child that finds the next stream full.
+// the lane and the refraction child waits on a lane-private stack (scratch memory); when a lineage ends the lane pops
+// the most recent waiting child, and only when the stack is empty does it go on with the sample's next start hit or
+// the pixel's next sample.  Compared with the stream form below: no ray ever travels through HBM queues, a colour word
+// has ONE adder (no atomics, and the order of a pixel's additions is defined: depth first, reflection before
+// refraction -- oracle: ora_render_streams_tree, bit-exact), and the waves are dispatched by recorded cost, exactly as in
+// render_streams_kernel.  The set of rays traced is the stream algorithm's (same children, same seeds, same step
+// indices); a child that finds kTreeStackDepth children waiting in its lane is dropped and counted.
+//
+// THE START RECORD.  Every sample of a pixel shoots the same primary ray (Trace.hs:244-262), and a GLASS hit involves no
+// random draw that changes a direction (glass_children only ADVANCES the seed): if the primary hit is glass, its two
+// children are the same two rays in every sample too.  So what is evaluated once per pixel and kept in a lane-private
+// LDS column is not only the primary hit but, for a glass primary hit, the first hit of EACH child -- the hits a sample
+// starts from (0, 1 or 2 of them; a child that misses contributes nothing).  A sample then adds the glass hit's
+// emittance (the same value every time), counts its two children, and works through its start hits in tree order, each
+// with the seed its ray would carry: the sample's seed advanced by 3 (reflection) or 4 (refraction) raw draws.  Two
+// traces and one glass evaluation per sample disappear for such pixels; everything downstream -- including start hits
+// that are glass themselves -- takes the general path.  (With a step cap below 3 the children could be cut: no caching.)
 // ---------------------------------------------------------------------------------------
 #ifndef PTMI_TREE_WAVES
 #define PTMI_TREE_WAVES 5
@@ -1215,8 +1237,9 @@ __device__ __forceinline__ void glass_children(V3 color, float ior, V3 p, V3 n, 
 template <bool LDS_SCENE, int TILE_W = 0>
 __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_tree_kernel(const RenderArgs a)
 {
-    __shared__ float pixel_const[9][kRenderBlock];          // per-lane restart record: primary hit position, normal, primary direction
-    __shared__ uint32_t stack_bottom[14][kRenderBlock];      // a lane's FIRST waiting child (the common depth); deeper ones go to scratch
+    // two start hits per lane: position (3), incoming direction (3), throughput (3), primitive, steps | draws << 8
+    __shared__ uint32_t start_rec[22][kRenderBlock];
+
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -1250,55 +1273,99 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
         if (!h0.just) {
             for (int s = 0; s < n_spp; ++s) (void)random_float(pixel_seed);     // updateSeed only
         } else {
-            float *mine = &pixel_const[0][threadIdx.x];
-            auto put = [&](int k, float v) { mine[k * kRenderBlock] = v; };
-            auto get = [&](int k) { return mine[k * kRenderBlock]; };
+            uint32_t *rec = &start_rec[0][threadIdx.x];
+            auto put_entry = [&](int e, V3 p, V3 dir, V3 t, int prim, unsigned int steps_done, unsigned int draws) {
+                uint32_t *q = rec + (size_t)e * 11 * kRenderBlock;
+                q[0] = f2u(p.x); q[kRenderBlock] = f2u(p.y); q[2 * kRenderBlock] = f2u(p.z);
+                q[3 * kRenderBlock] = f2u(dir.x); q[4 * kRenderBlock] = f2u(dir.y); q[5 * kRenderBlock] = f2u(dir.z);
+                q[6 * kRenderBlock] = f2u(t.x); q[7 * kRenderBlock] = f2u(t.y); q[8 * kRenderBlock] = f2u(t.z);
+                q[9 * kRenderBlock] = (uint32_t)prim; q[10 * kRenderBlock] = steps_done | (draws << 8);
+            };
             V3 pos, normal;                                       // pos: the hit to shade, then the next ray's origin
             hit_record(S, ns, h0.idx, origin, primary, h0.t, pos, normal);
-            put(0, pos.x); put(1, pos.y); put(2, pos.z);
-            put(3, normal.x); put(4, normal.y); put(5, normal.z);
-            put(6, primary.x); put(7, primary.y); put(8, primary.z);
-            const int idx0 = h0.idx;
-            // children waiting for this lane: origin, direction, throughput, seed, step index (RayState, Trace.hs:45).
-            // Entry 0 lives in a lane-private LDS column, entries 1.. in scratch memory: the reflection that is followed
-            // first rarely meets glass again, so nearly all pushes and pops are LDS traffic (with the whole stack in
-            // scratch the kernel wrote 23 GB per C2-sized launch: every push is 14 partial-line writes).
-            uint32_t stack_w[kTreeStackDepth - 1][14];
-            uint32_t *bottom = &stack_bottom[0][threadIdx.x];
-            int sp = 0;
-            int s = 0, idx = idx0;
-            unsigned int steps = 0, deepest = 1;                 // deepest: traceSteps of the sample's longest lineage (the primary trace is step 1)
+            int n_entries = 0;
+            V3 emit0 = mk(0.0f, 0.0f, 0.0f);
+            const float4 ma0 = M[2 * h0.idx], mb0 = M[2 * h0.idx + 1];
+            const bool prefix = f2u(mb0.x) == 2u && step_cap >= 3u;   // a glass primary hit whose children cannot be cut
+            if (prefix) {
+                emit0 = scale_r(mk(ma0.x, ma0.y, ma0.z), ma0.w) * mk(1.0f, 1.0f, 1.0f);     // computeResult of the primary hit
+                V3 ko[2], kd[2], kt[2]; Sfc32 ks[2];
+                glass_children(mk(ma0.x, ma0.y, ma0.z), mb0.y, pos, normal, primary, mk(1.0f, 1.0f, 1.0f), pixel_seed, ko, kd, kt, ks);
+                for (int k = 0; k < 2; ++k) {
+                    const V3 ro = k == 0 ? ko[0] : ko[1], rd = k == 0 ? kd[0] : kd[1], rt = k == 0 ? kt[0] : kt[1];
+                    const HitSel h = check_hit(S, ns, np, ro, rd);
+                    if (h.just) {
+                        V3 hp, hn;
+                        hit_record(S, ns, h.idx, ro, rd, h.t, hp, hn);
+                        put_entry(n_entries++, hp, rd, rt, h.idx, 1u, 3u + (unsigned int)k);
+                    }
+                }
+            } else {
+                put_entry(0, pos, primary, mk(1.0f, 1.0f, 1.0f), h0.idx, 0u, 0u);
+                n_entries = 1;
+            }
+            // children waiting for this lane: origin, direction, throughput, seed, step index (RayState, Trace.hs:45); scratch
+            // memory.  (Before the start record existed, every sample of a glass pixel pushed a child and the first entry
+            // lived in LDS: 23 GB -> 1.4 GB of scratch writes per launch.  With the primary split cached, pushes are rare,
+            // and an LDS entry beside the start record would cost a wave of occupancy: 10.2 ms instead of 9.1.)
+            uint32_t stack_w[kTreeStackDepth][14];
+            int sp = 0, entry_i = 0;
+            int s = 0, idx = h0.idx;
+            unsigned int steps = 0, deepest = 0;                 // deepest: traceSteps of the sample's longest lineage
             V3 d = primary;
             V3 throughput = mk(1.0f, 1.0f, 1.0f);
             Sfc32 seed = pixel_seed;
-            bool pending = n_spp > 0, has_ray = false;
+            bool pending = false, has_ray = false;
+            auto begin_sample = [&]() {                           // what every sample of this pixel has already behind it
+                if (prefix) { acc = acc + emit0; live += 2u; }
+                entry_i = 0; deepest = prefix ? 2u : 1u;
+            };
+            // the next hit this sample starts from -- or, when it has none left, the end of the sample and the next one
+            auto next_start = [&]() {
+                for (;;) {
+                    if (entry_i < n_entries) {
+                        const uint32_t *q = rec + (size_t)entry_i * 11 * kRenderBlock;
+                        pos = mk(u2f(q[0]), u2f(q[kRenderBlock]), u2f(q[2 * kRenderBlock]));
+                        d = mk(u2f(q[3 * kRenderBlock]), u2f(q[4 * kRenderBlock]), u2f(q[5 * kRenderBlock]));
+                        throughput = mk(u2f(q[6 * kRenderBlock]), u2f(q[7 * kRenderBlock]), u2f(q[8 * kRenderBlock]));
+                        idx = (int)q[9 * kRenderBlock];
+                        const uint32_t meta = q[10 * kRenderBlock];
+                        steps = meta & 0xffu;
+                        normal = normal_at(S, ns, idx, pos);
+                        seed = pixel_seed;
+                        for (uint32_t k = 0; k < (meta >> 8); ++k) (void)sfc32_next(seed);     // the draws its ray's ancestors made
+                        ++entry_i;
+                        pending = true; has_ray = false;
+                        return;
+                    }
+                    (void)random_float(pixel_seed);               // updateSeed: the sample's tree is done
+                    ++s; longest = deepest > longest ? deepest : longest;
+                    if (s >= n_spp) { pending = false; has_ray = false; return; }
+                    begin_sample();
+                }
+            };
             auto lineage_ended = [&]() {
                 if (sp > 0) {                                     // the most recent waiting child
                     --sp;
                     uint32_t e[14];
-                    if (sp == 0) { for (int q = 0; q < 14; ++q) e[q] = bottom[q * kRenderBlock]; }
-                    else         { for (int q = 0; q < 14; ++q) e[q] = stack_w[sp - 1][q]; }
+                    for (int q = 0; q < 14; ++q) e[q] = stack_w[sp][q];
                     pos = mk(u2f(e[0]), u2f(e[1]), u2f(e[2]));
                     d = mk(u2f(e[3]), u2f(e[4]), u2f(e[5]));
                     throughput = mk(u2f(e[6]), u2f(e[7]), u2f(e[8]));
                     seed.a = e[9]; seed.b = e[10]; seed.c = e[11]; seed.counter = e[12];
                     steps = e[13];
                     pending = false; has_ray = true;
-                } else {                                          // the sample's tree is done
-                    (void)random_float(pixel_seed);               // updateSeed
-                    seed = pixel_seed;
-                    ++s; longest = deepest > longest ? deepest : longest; steps = 0; deepest = 1;
-                    throughput = mk(1.0f, 1.0f, 1.0f);
-                    pos = mk(get(0), get(1), get(2)); normal = mk(get(3), get(4), get(5));
-                    d = mk(get(6), get(7), get(8)); idx = idx0;
-                    pending = s < n_spp; has_ray = false;
+                } else {
+                    next_start();
                 }
             };
+            if (n_spp > 0) { begin_sample(); next_start(); }
             while (pending || has_ray) {
                 ++trips;
                 // shade round.  A ray whose throughput is already near zero dies at this hit (numNewRays): the hit adds its
-                // emittance and nothing else of it survives, so such lanes skip the expensive half, resume their most recent
-                // waiting child or start the pixel's next sample, and -- in the latter case -- take part in this round's full shade.
+                // emittance and nothing else of it survives, so such lanes skip the expensive half and go on with their most
+                // recent waiting child, their sample's next start hit or the pixel's next sample -- in the latter cases they
+                // take part in this round's full shade.
                 if (pending && !has_ray && near_zero(throughput)) {
                     const float4 ma = M[2 * idx];
                     acc = acc + (scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);   // computeResult (Trace.hs:318-323)
@@ -1319,8 +1386,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                             if (sp < kTreeStackDepth) {
                                 const uint32_t e[14] = {f2u(ko[1].x), f2u(ko[1].y), f2u(ko[1].z), f2u(kd[1].x), f2u(kd[1].y), f2u(kd[1].z),
                                                         f2u(kt[1].x), f2u(kt[1].y), f2u(kt[1].z), ks[1].a, ks[1].b, ks[1].c, ks[1].counter, steps};
-                                if (sp == 0) { for (int q = 0; q < 14; ++q) bottom[q * kRenderBlock] = e[q]; }
-                                else         { for (int q = 0; q < 14; ++q) stack_w[sp - 1][q] = e[q]; }
+                                for (int q = 0; q < 14; ++q) stack_w[sp][q] = e[q];
                                 ++sp;
                             } else {
                                 ++dropped;
