@@ -1286,7 +1286,11 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
             int n_entries = 0;
             V3 emit0 = mk(0.0f, 0.0f, 0.0f);
             const float4 ma0 = M[2 * h0.idx], mb0 = M[2 * h0.idx + 1];
+#ifdef PTMI_TREE_NO_PREFIX
+            const bool prefix = false;
+#else
             const bool prefix = f2u(mb0.x) == 2u && step_cap >= 3u;   // a glass primary hit whose children cannot be cut
+#endif
             if (prefix) {
                 emit0 = scale_r(mk(ma0.x, ma0.y, ma0.z), ma0.w) * mk(1.0f, 1.0f, 1.0f);     // computeResult of the primary hit
                 V3 ko[2], kd[2], kt[2]; Sfc32 ks[2];
@@ -1310,6 +1314,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
             // and an LDS entry beside the start record would cost a wave of occupancy: 10.2 ms instead of 9.1.)
             uint32_t stack_w[kTreeStackDepth][14];
             int sp = 0, entry_i = 0;
+            int stack_limit = kTreeStackDepth;                    // while the reflection's subtree is walked, the cached refraction "waits": one slot less
             int s = 0, idx = h0.idx;
             unsigned int steps = 0, deepest = 0;                 // deepest: traceSteps of the sample's longest lineage
             V3 d = primary;
@@ -1331,6 +1336,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                         idx = (int)q[9 * kRenderBlock];
                         const uint32_t meta = q[10 * kRenderBlock];
                         steps = meta & 0xffu;
+                        stack_limit = kTreeStackDepth - ((meta >> 8) == 3u ? 1 : 0);
                         normal = normal_at(S, ns, idx, pos);
                         seed = pixel_seed;
                         for (uint32_t k = 0; k < (meta >> 8); ++k) (void)sfc32_next(seed);     // the draws its ray's ancestors made
@@ -1366,7 +1372,8 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                 // emittance and nothing else of it survives, so such lanes skip the expensive half and go on with their most
                 // recent waiting child, their sample's next start hit or the pixel's next sample -- in the latter cases they
                 // take part in this round's full shade.
-                if (pending && !has_ray && near_zero(throughput)) {
+                // (A loop: the start hit that comes next may itself belong to a dead ray -- a reflection of weight ~0.)
+                while (pending && !has_ray && near_zero(throughput)) {
                     const float4 ma = M[2 * idx];
                     acc = acc + (scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);   // computeResult (Trace.hs:318-323)
                     ++steps;
@@ -1383,7 +1390,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                         live += 2u;
                         if (capped) { cut += 2u; lineage_ended(); }
                         else {
-                            if (sp < kTreeStackDepth) {
+                            if (sp < stack_limit) {
                                 const uint32_t e[14] = {f2u(ko[1].x), f2u(ko[1].y), f2u(ko[1].z), f2u(kd[1].x), f2u(kd[1].y), f2u(kd[1].z),
                                                         f2u(kt[1].x), f2u(kt[1].y), f2u(kt[1].z), ks[1].a, ks[1].b, ks[1].c, ks[1].counter, steps};
                                 for (int q = 0; q < 14; ++q) stack_w[sp][q] = e[q];

@@ -156,3 +156,78 @@ def test_random_scenes_with_non_finite_and_denormal_numbers(ctx, pkg, ora):
             assert_planes_equal_up_to_nan_payload(got, want, what + " streams")
         if case % 500 == 499:
             print("extreme fuzz: %d cases" % (case + 1), flush=True)
+
+
+N_GLASS = int(os.environ.get("PTMI_FUZZ_GLASS_CASES", "150"))
+
+
+def test_random_glass_scenes_tree_walk_and_stream_form(ctx, pkg, ora):
+    """Random scenes with GLASS primitives (the build-defined extension; spec = the oracle): the per-pixel tree walk --
+    start record, lane stack, sample chunks -- must equal the oracle's tree order BIT FOR BIT; every fourth case also runs
+    the stream form, which must agree with the oracle's stream order to rounding with exact RNG planes.  A step cap keeps
+    facing glass surfaces from bouncing a ray 65 536 times; the rays it cuts must be counted alike."""
+    B = pkg.binding
+    r = np.random.default_rng(SEED + 2)
+    for case in range(N_GLASS):
+        spheres, planes, cam, w, h, limit, spp = random_case(pkg, r)
+        n_glass = 0
+        for arr in (spheres, planes):
+            for i in range(len(arr)):
+                if r.random() < 0.45:
+                    arr["brdf_tag"][i] = pkg.GLASS
+                    arr["brdf_param"][i] = float(r.choice([1.0, 1.33, 1.5, 2.4, 0.7]))
+                    arr["color"][i] = r.uniform(0.2, 1.0, 3)
+                    arr["illuminance"][i] = float(r.choice([0.0, 0.0, 0.0, 3.0]))
+                    n_glass += 1
+        if case % 4 == 0:
+            # The cases that also go through the stream form.  Its float atomics add a pixel's contributions in yet
+            # another order, and contributions of opposite sign cancel (case 44 of this generator: terms of +-3e5 leaving
+            # -8.25), which no relative tolerance survives.  Keep every contribution non-negative here: Glossy instead of
+            # Matte (Matte's brdf is not clamped, Trace.hs:411), non-negative colours, unit plane normals (Schlick's
+            # weight leaves [0, 1] otherwise).
+            for arr in (spheres, planes):
+                arr["brdf_tag"][arr["brdf_tag"] == pkg.MATTE] = pkg.GLOSSY
+                arr["color"][:] = np.abs(arr["color"])
+            for j in range(len(planes)):
+                n = planes["direction"][j].astype(np.float64)
+                planes["direction"][j] = (n / np.linalg.norm(n)).astype(np.float32)
+        cap = int(r.choice([1, 2, 3, 4, 6, 9]))
+        chunks = int(r.choice([0, 0, 1, 2, 3]))
+        start = initial_planes(ora, w, h, seed0=int(r.integers(0, 2 ** 63)))
+        if case % 7 == 3:                                          # a deep tree now and then: the lane stack overflows and must say so
+            cap, w, h, spp = 24, min(w, 24), min(h, 12), 1
+            start = [p[:h, :w].copy() for p in start]
+        ctx.set_scene(spheres, planes)
+        ctx.set_option(B.OPT_STREAM_STEP_CAP, cap)
+        ctx.set_option(B.OPT_SPP_CHUNKS, chunks)
+        try:
+            ctx.resize(w, h)
+            ctx.upload_state(*start)
+            ctx.reset_stats()
+            ctx.render(cam, limit, spp, pkg.STREAMS)
+            got, st = ctx.download_state(), ctx.stats()
+            with np.errstate(all="ignore"):
+                want, live, dropped, longest, cut = ora.render_streams_tree(spheres, planes, cam, w, h, cap, spp, start)
+            what = "glass case %d (%dx%d, %d+%d prims, %d glass, cap %d, spp %d, chunks %d)" % (case, w, h, len(spheres), len(planes), n_glass, cap, spp, chunks)
+            if n_glass:
+                assert_planes_equal(got, want, what + " tree walk")
+                assert st["live_bounces"] == live and st["stream_rays_truncated"] == cut and st["stream_rays_dropped"] == dropped, what
+            if case % 4 == 0 and n_glass:
+                ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+                ctx.set_option(B.OPT_STREAM_CAPACITY, 64)
+                ctx.upload_state(*start)
+                ctx.reset_stats()
+                ctx.render(cam, limit, spp, pkg.STREAMS)
+                got_s, st_s = ctx.download_state(), ctx.stats()
+                for a, b in zip(got_s[3:], want[3:]):
+                    assert np.array_equal(a, b), what
+                assert st_s["live_bounces"] == live and st_s["stream_rays_truncated"] == cut and st_s["stream_rays_dropped"] == 0, what
+                for a, b in zip(got_s[:3], want[:3]):                            # another order of the same non-negative terms
+                    ratio = np.abs(a - b) / np.maximum(np.abs(b), 1e-3 + 1e-4 * np.max(np.abs(b)))
+                    assert np.max(ratio) <= 1e-4, "%s: stream form vs tree order, worst %.3g at %d: %r vs %r" % (
+                        what, float(np.max(ratio)), int(np.argmax(ratio)), a.reshape(-1)[np.argmax(ratio)], b.reshape(-1)[np.argmax(ratio)])
+        finally:
+            ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_AUTO)
+            ctx.set_option(B.OPT_STREAM_CAPACITY, 4)
+            ctx.set_option(B.OPT_STREAM_STEP_CAP, 1 << 16)
+            ctx.set_option(B.OPT_SPP_CHUNKS, 0)
