@@ -1030,16 +1030,15 @@ __global__ void __launch_bounds__(kRenderBlock) render_inline_persistent_kernel(
 //     guarantees that the kernel terminates (rays it cuts are counted, stream_counters[kScTruncated]);
 //   * which seed the pixel carries out of `combine` (Trace.hs:179-184) is Accelerate-backend behaviour
 //     (assumption A5).  Default: the pixel keeps its OLD seed while the sample runs;
-//     a.seed_from_result: the seed of the ray that made the sample's LAST hit replaces it -- that ray carried the
-//     sample's start seed advanced by three draws per earlier hit, so the survivor is re-derived from the number
-//     of hits instead of being kept in registers.  Either way updateSeed then advances the pixel's seed by one
+//     a.seed_from_result: the seed of the ray that made the sample's LAST hit replaces it (kept in the lane's LDS
+//     column, not in registers).  Either way updateSeed then advances the pixel's seed by one
 //     draw (Trace.hs:151, :190-191).
 // ---------------------------------------------------------------------------------------
 
 template <bool LDS_SCENE, int TILE_W = 0>
 __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const RenderArgs a)
 {
-    __shared__ float pixel_const[16][kRenderBlock];         // per-lane restart record, as in render_inline_kernel
+    __shared__ float pixel_const[13][kRenderBlock];         // per-lane restart record (rows 0..8) and the last hit's seed (9..12)
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -1082,14 +1081,11 @@ __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const R
             put(3, normal.x); put(4, normal.y); put(5, normal.z);
             put(6, primary.x); put(7, primary.y); put(8, primary.z);
             const int idx0 = h0.idx;
-            {   // what every first shade of this pixel uses (shade_first)
-                const float4 ma0 = M[2 * idx0], mb0 = M[2 * idx0 + 1];
-                V3 axis; float hk;
-                bounce_axis(mb0, normal, primary, axis, hk);
-                const V3 first_term = scale_r(mk(ma0.x, ma0.y, ma0.z), ma0.w) * mk(1.0f, 1.0f, 1.0f);
-                put(9, axis.x); put(10, axis.y); put(11, axis.z); put(12, hk);
-                put(13, first_term.x); put(14, first_term.y); put(15, first_term.z);
-            }
+            // PTMI_SEED_FROM_RESULT (combine new old): every hit leaves the seed its ray carried in rows 9..12 of the lane's
+            // LDS column (four ds_writes per hit instead of four more registers); the sample's last one survives.
+            auto note_hit_seed = [&](const Sfc32 &sd) {
+                if (a.seed_from_result) { put(9, u2f(sd.a)); put(10, u2f(sd.b)); put(11, u2f(sd.c)); put(12, u2f(sd.counter)); }
+            };
             int s = 0, idx = idx0;
             unsigned int steps = 0;
             V3 d = primary;
@@ -1097,8 +1093,9 @@ __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const R
             Sfc32 seed = pixel_seed;
             bool pending = n_spp > 0, has_ray = false;
             auto end_sample = [&]() {
-                // combine new old: the seed the last hit's ray carried = start seed + 3 draws per earlier hit
-                if (a.seed_from_result) for (unsigned int k = 3u; k < 3u * steps; ++k) (void)sfc32_next(pixel_seed);
+                if (a.seed_from_result && steps > 0u) {           // combine new old: the seed the sample's last hit carried
+                    pixel_seed.a = f2u(get(9)); pixel_seed.b = f2u(get(10)); pixel_seed.c = f2u(get(11)); pixel_seed.counter = f2u(get(12));
+                }
                 (void)random_float(pixel_seed);                   // updateSeed
                 seed = pixel_seed;
                 ++s; longest = steps > longest ? steps : longest; steps = 0;
@@ -1117,11 +1114,13 @@ __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const R
                     if (near_zero(throughput)) {
                         const float4 ma = M[2 * idx];
                         acc = acc + (scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);
+                        note_hit_seed(seed);
                         ++steps;
                         end_sample();
                     }
                     if (pending) {                                 // alive: a fresh sample starts with throughput 1
                         const bool capped = steps + 1u >= step_cap;
+                        note_hit_seed(seed);
                         // results: colour += emittance * throughput for EVERY hit; then the new ray
                         shade(M, idx, pos, normal, pos, d, throughput, acc, seed);
                         ++steps; ++live;                           // the child exists even if the cap then cuts it

@@ -1,6 +1,5 @@
 """The multi-device entry of the C ABI (ptmi_group_*): partition arithmetic on the CPU; on the GPU a group's stitched
 read-out -- host planes and RCCL gather to a root device -- equals the ungrouped image bit for bit."""
-import os
 
 import numpy as np
 import pytest

@@ -8,7 +8,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft  # noqa: E402
-import numpy as np  # noqa: E402
+
 
 
 def main():
