@@ -304,9 +304,12 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
             lv.in_count = level == 0 ? d_hit_count : c->d_qcount + cursor_of(level - 1);
             lv.out_count = c->d_qcount + cursor_of(level);
             lv.emitted = lv.out_count + kCounterStride;
+            lv.may_emit = c->has_glass ? 1 : 0;
             const unsigned int grid = grid_for(expected_items);
-            PTMI_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(lv.out_count), (int)(grid * first_block), 1, c->stream));
-            PTMI_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(lv.emitted), 0, 1, c->stream));
+            if (lv.may_emit) {                                 // without a ray-splitting material nothing is appended: no cursor to preset
+                PTMI_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(lv.out_count), (int)(grid * first_block), 1, c->stream));
+                PTMI_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(lv.emitted), 0, 1, c->stream));
+            }
             PTMI_HIP(c, launch_streams_level(a, lv, level == 0, grid, c->stream));
             return PTMI_OK;
         };

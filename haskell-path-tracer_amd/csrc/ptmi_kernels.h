@@ -88,6 +88,7 @@ struct LevelArgs {
     unsigned int *stats;            // device: base of the counter block
     unsigned int n_px;              // pixels held by the context
     int batch;                      // level 0: samples of every pixel in this stream
+    int may_emit;                   // 0: the scene has no ray-splitting material -- nothing is ever written to `out`
 };
 
 hipError_t launch_streams_level(const RenderArgs &a, const LevelArgs &lv, bool first, unsigned int grid, hipStream_t stream);

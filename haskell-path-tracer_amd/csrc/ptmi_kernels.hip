@@ -1643,7 +1643,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
             ++depth; pending = false; has_ray = true;          // the child: next traceStep, same lane
         }
         // ---- expand: compaction of the emitted children into the output stream
-        const unsigned long long kids = __ballot(emits);
+        const unsigned long long kids = lv.may_emit ? __ballot(emits) : 0ull;
         if (kids) {                                           // wave-uniform
             const unsigned int cnt = (unsigned int)__builtin_popcountll(kids), rank = (unsigned int)__builtin_popcountll(kids & below);
             const unsigned int room = blk_end - blk;
@@ -1687,7 +1687,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
         }
     }
     // what is left of this wave's last block: holes
-    {
+    if (lv.may_emit) {
         const unsigned int end = blk_end < lv.out.capacity ? blk_end : lv.out.capacity;
         for (unsigned int i = blk + (unsigned int)lane; i < end; i += 64u) lv.out.pixel[i] = kHole;
     }
