@@ -251,6 +251,9 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
         if (batch_max > n_spp) batch_max = n_spp;
     }
     if (a.seed_from_result) batch_max = 1;               // a sample starts from the seed the previous sample's last hit left
+    // Without ray splitting (and with the default seed rule) a lane renders up to 64 successive samples of its pixel before it
+    // refills: one adder per pixel, in sample order, and launches long enough to pay for their start and drain.
+    const int in_lane_max = (!c->has_glass && !a.seed_from_result && c->opt_batch == 0) ? 64 : 1;
     if (n * cap_factor > 0xfffffff0ull) return fail(c, PTMI_ELIMIT, "image too large for the stream form of Streams");
     static int max_grid = 0;                                 // persistent waves: 6 per SIMD
     if (!max_grid) {
@@ -293,7 +296,9 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
     PTMI_HIP(c, launch_streams_primary(a, hits, d_hit_count, c->stream));
     uint64_t cut_in_streams = 0;
     for (int s = 0; s < n_spp;) {
-        const int batch = n_spp - s < batch_max ? n_spp - s : batch_max;
+        const int span = in_lane_max > 1 ? in_lane_max : batch_max;       // samples this pass covers
+        const int covered = n_spp - s < span ? n_spp - s : span;
+        const int batch = in_lane_max > 1 ? 1 : covered;                  // samples that share the stream
         auto cursor_of = [&](int level) { return (size_t)(kLvCursor + 2 * (level % kLvMaxLevels)) * kCounterStride; };
         auto launch_level = [&](int level, size_t expected_items) -> int {
             LevelArgs lv{};
@@ -305,6 +310,10 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
             lv.out_count = c->d_qcount + cursor_of(level);
             lv.emitted = lv.out_count + kCounterStride;
             lv.may_emit = c->has_glass ? 1 : 0;
+            lv.samples_in_lane = in_lane_max > 1 ? covered : 1;
+            lv.chunk_cursor = lv.out_count;                    // the output cursor is idle without ray splitting: it hands out chunks
+            if (lv.samples_in_lane > 1)
+                PTMI_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(lv.chunk_cursor), (int)grid_for(expected_items), 1, c->stream));
             const unsigned int grid = grid_for(expected_items);
             if (lv.may_emit) {                                 // without a ray-splitting material nothing is appended: no cursor to preset
                 PTMI_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(lv.out_count), (int)(grid * first_block), 1, c->stream));
@@ -343,8 +352,8 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
             // children of the deepest allowed level sit in a stream no level will read: the cap cut them
             cut_in_streams += raw[cursor_of(level) + kCounterStride];
         }
-        PTMI_HIP(c, launch_streams_update_seed(a.planes, (long long)n, batch, c->stream));
-        s += batch;
+        PTMI_HIP(c, launch_streams_update_seed(a.planes, (long long)n, covered, c->stream));
+        s += covered;
     }
     PTMI_HIP(c, hipMemcpyAsync(raw.data(), c->d_qcount, (size_t)kLvCursor * kCounterStride * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));

@@ -89,6 +89,9 @@ struct LevelArgs {
     unsigned int n_px;              // pixels held by the context
     int batch;                      // level 0: samples of every pixel in this stream
     int may_emit;                   // 0: the scene has no ray-splitting material -- nothing is ever written to `out`
+    unsigned int *chunk_cursor;     // device: next chunk to hand out when samples_in_lane > 1 (preset to the grid size)
+    int samples_in_lane;            // level 0 without ray splitting: a lane renders this many successive samples of its pixel
+                                    // before it refills (the stream then holds every hit pixel once; batch is 1)
 };
 
 hipError_t launch_streams_level(const RenderArgs &a, const LevelArgs &lv, bool first, unsigned int grid, hipStream_t stream);

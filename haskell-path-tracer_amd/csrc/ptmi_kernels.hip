@@ -1283,6 +1283,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
             V3 pos, normal;                                       // pos: the hit to shade, then the next ray's origin
             hit_record(S, ns, h0.idx, origin, primary, h0.t, pos, normal);
             int n_entries = 0;
+            bool first_is_reflection = false;
             V3 emit0 = mk(0.0f, 0.0f, 0.0f);
             const float4 ma0 = M[2 * h0.idx], mb0 = M[2 * h0.idx + 1];
 #ifdef PTMI_TREE_NO_PREFIX
@@ -1300,6 +1301,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                     if (h.just) {
                         V3 hp, hn;
                         hit_record(S, ns, h.idx, ro, rd, h.t, hp, hn);
+                        if (n_entries == 0) first_is_reflection = k == 0;
                         put_entry(n_entries++, hp, rd, rt, h.idx, 1u, 3u + (unsigned int)k);
                     }
                 }
@@ -1313,7 +1315,6 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
             // and an LDS entry beside the start record would cost a wave of occupancy: 10.2 ms instead of 9.1.)
             uint32_t stack_w[kTreeStackDepth][14];
             int sp = 0, entry_i = 0;
-            int stack_limit = kTreeStackDepth;                    // while the reflection's subtree is walked, the cached refraction "waits": one slot less
             int s = 0, idx = h0.idx;
             unsigned int steps = 0, deepest = 0;                 // deepest: traceSteps of the sample's longest lineage
             V3 d = primary;
@@ -1334,12 +1335,11 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                         throughput = mk(u2f(q[6 * kRenderBlock]), u2f(q[7 * kRenderBlock]), u2f(q[8 * kRenderBlock]));
                         idx = (int)q[9 * kRenderBlock];
                         const uint32_t meta = q[10 * kRenderBlock];
+                        ++entry_i;
                         steps = meta & 0xffu;
-                        stack_limit = kTreeStackDepth - ((meta >> 8) == 3u ? 1 : 0);
                         normal = normal_at(S, ns, idx, pos);
                         seed = pixel_seed;
                         for (uint32_t k = 0; k < (meta >> 8); ++k) (void)sfc32_next(seed);     // the draws its ray's ancestors made
-                        ++entry_i;
                         pending = true; has_ray = false;
                         return;
                     }
@@ -1370,15 +1370,19 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                 // shade round.  A ray whose throughput is already near zero dies at this hit (numNewRays): the hit adds its
                 // emittance and nothing else of it survives, so such lanes skip the expensive half and go on with their most
                 // recent waiting child, their sample's next start hit or the pixel's next sample -- in the latter cases they
-                // take part in this round's full shade.
-                // (A loop: the start hit that comes next may itself belong to a dead ray -- a reflection of weight ~0.)
-                while (pending && !has_ray && near_zero(throughput)) {
+                // take part in this round's full shade.  (lineage_ended is a large block -- next start hit, its normal, its
+                // seed: it is expanded at two places only, here and at the end of the trip.)
+                if (pending && !has_ray && near_zero(throughput)) {
                     const float4 ma = M[2 * idx];
                     acc = acc + (scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);   // computeResult (Trace.hs:318-323)
                     ++steps;
                     lineage_ended();
                 }
-                if (pending && !has_ray) {                         // alive
+                bool ended = false;
+                // (The start hit that the block above may just have loaded can itself belong to a dead ray -- a reflection of
+                // weight ~0: it must not be shaded; it waits for the next trip's dead-ray block.  A test inside next_start
+                // instead cost 12 %.)
+                if (pending && !has_ray && !near_zero(throughput)) {   // alive
                     const float4 ma = M[2 * idx], mb = M[2 * idx + 1];
                     const bool capped = steps + 1u >= step_cap;
                     if (f2u(mb.x) == 2u) {                        // GLASS: two children (extension; spec = the oracle's glass_children)
@@ -1387,9 +1391,10 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                         V3 ko[2], kd[2], kt[2]; Sfc32 ks[2];
                         glass_children(mk(ma.x, ma.y, ma.z), mb.y, pos, normal, d, throughput, seed, ko, kd, kt, ks);
                         live += 2u;
-                        if (capped) { cut += 2u; lineage_ended(); }
+                        if (capped) { cut += 2u; pending = false; ended = true; }
                         else {
-                            if (sp < stack_limit) {
+                            // while the cached reflection's subtree is walked, the cached refraction "waits": one slot less
+                            if (sp < kTreeStackDepth - ((prefix && entry_i == 1 && first_is_reflection) ? 1 : 0)) {
                                 const uint32_t e[14] = {f2u(ko[1].x), f2u(ko[1].y), f2u(ko[1].z), f2u(kd[1].x), f2u(kd[1].y), f2u(kd[1].z),
                                                         f2u(kt[1].x), f2u(kt[1].y), f2u(kt[1].z), ks[1].a, ks[1].b, ks[1].c, ks[1].counter, steps};
                                 for (int q = 0; q < 14; ++q) stack_w[sp][q] = e[q];
@@ -1404,8 +1409,9 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                         // results: colour += emittance * throughput for EVERY hit; then the new ray
                         shade(M, idx, pos, normal, pos, d, throughput, acc, seed);
                         ++steps; ++live;
-                        if (capped) { ++cut; lineage_ended(); }
-                        else { pending = false; has_ray = true; }
+                        pending = false;
+                        if (capped) { ++cut; ended = true; }
+                        else has_ray = true;
                     }
                 }
                 if (has_ray) {
@@ -1417,9 +1423,10 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                         idx = h.idx;
                         pending = true;
                     } else {
-                        lineage_ended();
+                        ended = true;
                     }
                 }
+                if (ended) lineage_ended();
             }
         }
         a.planes.r[pixel] = acc.x; a.planes.g[pixel] = acc.y; a.planes.b[pixel] = acc.z;
@@ -1520,9 +1527,23 @@ __global__ void __launch_bounds__(kBlock) streams_primary_kernel(const RenderArg
     }
 }
 
-template <bool LDS_SCENE, bool FIRST>
+// level 0: a hit pixel (re)starts a sample from its cached primary hit
+__device__ __forceinline__ void load_cached_hit(const HitList &h, unsigned int i, V3 &pos, V3 &normal, V3 &dir, int &idx)
+{
+    pos = mk(h.f[0][i], h.f[1][i], h.f[2][i]);
+    normal = mk(h.f[3][i], h.f[4][i], h.f[5][i]);
+    dir = mk(h.f[6][i], h.f[7][i], h.f[8][i]);
+    idx = (int)h.idx[i];
+}
+
+// IN_LANE (level 0, scenes without ray splitting): a lane renders lv.samples_in_lane successive samples of its pixel before
+// it refills, and the waves take their chunks from a global counter (a chunk is then ~100 loop trips: one atomic each is cheap,
+// and a static share of 3 or 4 such chunks per wave would leave a quarter of the chip idle at the end).
+template <bool LDS_SCENE, bool FIRST, bool IN_LANE = false>
 __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_kernel(const RenderArgs a, const LevelArgs lv)
 {
+    __shared__ uint32_t sample_seed[IN_LANE ? 4 : 1][kRenderBlock];   // IN_LANE: the seed the lane's current sample started from
+    __shared__ float lane_hit[IN_LANE ? 10 : 1][kRenderBlock];        // IN_LANE: the lane's cached primary hit (position, normal, direction, primitive)
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -1542,11 +1563,17 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
     if (!FIRST) n_in = n_in < lv.in.capacity ? n_in : lv.in.capacity;
     const unsigned int cps = (n_in + 63u) / 64u;
     const unsigned int n_chunks = FIRST ? cps * (unsigned int)lv.batch : cps;
+    auto next_chunk = [&](unsigned int current) __attribute__((always_inline)) -> unsigned int {
+        if (!IN_LANE) return current + G;                      // static stride
+        unsigned int c = 0;
+        if (lane == 0) c = atomicAdd(lv.chunk_cursor, 1u);     // dynamic hand-out: the cursor starts at G
+        return (unsigned int)__builtin_amdgcn_readfirstlane((int)c);
+    };
     unsigned int chunk = w, taken = 0;                       // wave-uniform cursor: chunk index, items of it already handed out
     unsigned int blk = w * kFirstBlock, blk_end = blk + kFirstBlock;   // wave-uniform: the output block being filled
     // wave-uniform description of the current chunk, recomputed only when the cursor moves to another chunk
     unsigned int chunk_len = 0, chunk_j = 0, chunk_first = 0;
-    auto open_chunk = [&]() {
+    auto open_chunk = [&]() __attribute__((always_inline)) {
         if (chunk >= n_chunks) { chunk_len = 0; return; }
         chunk_j = FIRST ? chunk / cps : 0u;
         chunk_first = (chunk - chunk_j * cps) * 64u;          // first item of the chunk within the sample / the stream
@@ -1559,11 +1586,29 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
     Sfc32 seed; seed.a = seed.b = seed.c = seed.counter = 0;
     uint32_t pixel = 0, depth = 0, hits = 0;                  // depth: step index of the lane's current ray
     int idx = 0;
+    unsigned int sample_j = 0;                                // IN_LANE: which of its pixel's samples the lane is rendering
     unsigned int live = 0, cut = 0, dropped = 0, deepest = 0, stored = 0;
 
     // combine new old (PTMI_SEED_FROM_RESULT; never with GLASS): the seed the lineage's last hit carried = the pixel's
     // seed + 3 draws per earlier hit, written back so that updateSeed advances the survivor
-    auto lineage_ended = [&]() {
+    auto lineage_ended = [&]() __attribute__((always_inline)) {
+        if (IN_LANE && sample_j + 1u < (unsigned int)lv.samples_in_lane) {
+            // Without ray splitting a pixel has one lineage per sample: the lane goes on with the pixel's next sample, so that
+            // one lane adds to the pixel in sample order (bit-identical to the per-pixel kernel) and a launch is long enough
+            // to pay for its start and drain.  updateSeed (Trace.hs:190-191): the next sample starts one draw further.
+            ++sample_j;
+            Sfc32 ss; ss.a = sample_seed[0][threadIdx.x]; ss.b = sample_seed[1][threadIdx.x]; ss.c = sample_seed[2][threadIdx.x]; ss.counter = sample_seed[3][threadIdx.x];
+            (void)random_float(ss);
+            sample_seed[0][threadIdx.x] = ss.a; sample_seed[1][threadIdx.x] = ss.b; sample_seed[2][threadIdx.x] = ss.c; sample_seed[3][threadIdx.x] = ss.counter;
+            seed = ss;
+            o = mk(lane_hit[0][threadIdx.x], lane_hit[1][threadIdx.x], lane_hit[2][threadIdx.x]);
+            normal = mk(lane_hit[3][threadIdx.x], lane_hit[4][threadIdx.x], lane_hit[5][threadIdx.x]);
+            d = mk(lane_hit[6][threadIdx.x], lane_hit[7][threadIdx.x], lane_hit[8][threadIdx.x]);
+            idx = (int)f2u(lane_hit[9][threadIdx.x]);
+            throughput = mk(1.0f, 1.0f, 1.0f);
+            depth = 0; hits = 0; pending = true; has_ray = false;
+            return;
+        }
         if (a.seed_from_result && hits > 0u) {
             Sfc32 sd; sd.a = a.planes.sa[pixel]; sd.b = a.planes.sb[pixel]; sd.c = a.planes.sc[pixel]; sd.counter = a.planes.sctr[pixel];
             for (unsigned int k = 3u; k < 3u * hits; ++k) (void)sfc32_next(sd);
@@ -1572,7 +1617,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
         has_ray = false; pending = false;
     };
     // computeResult + permute (+) (Trace.hs:179-184, :318-323); adding an exact zero changes nothing
-    auto add_colour = [&](V3 c) {
+    auto add_colour = [&](V3 c) __attribute__((always_inline)) {
         if (c.x != 0.0f) atomicAdd(a.planes.r + pixel, c.x);
         if (c.y != 0.0f) atomicAdd(a.planes.g + pixel, c.y);
         if (c.z != 0.0f) atomicAdd(a.planes.b + pixel, c.z);
@@ -1592,13 +1637,20 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
                     // initialState (Trace.hs:158-162) one step on: the pixel's cached primary hit; sample j of the batch
                     // starts from the pixel's seed advanced by j draws, which is what j updateSeeds leave (Trace.hs:190-191)
                     pixel = lv.hits.pixel[i];
-                    o = mk(lv.hits.f[0][i], lv.hits.f[1][i], lv.hits.f[2][i]);
-                    normal = mk(lv.hits.f[3][i], lv.hits.f[4][i], lv.hits.f[5][i]);
-                    d = mk(lv.hits.f[6][i], lv.hits.f[7][i], lv.hits.f[8][i]);
-                    idx = (int)lv.hits.idx[i];
-                    throughput = mk(1.0f, 1.0f, 1.0f);
                     seed.a = a.planes.sa[pixel]; seed.b = a.planes.sb[pixel]; seed.c = a.planes.sc[pixel]; seed.counter = a.planes.sctr[pixel];
                     for (unsigned int q = 0; q < chunk_j; ++q) (void)random_float(seed);
+                    if (IN_LANE) {
+                        sample_j = 0;
+                        sample_seed[0][threadIdx.x] = seed.a; sample_seed[1][threadIdx.x] = seed.b; sample_seed[2][threadIdx.x] = seed.c; sample_seed[3][threadIdx.x] = seed.counter;
+                    }
+                    load_cached_hit(lv.hits, i, o, normal, d, idx);
+                    if (IN_LANE) {
+                        lane_hit[0][threadIdx.x] = o.x; lane_hit[1][threadIdx.x] = o.y; lane_hit[2][threadIdx.x] = o.z;
+                        lane_hit[3][threadIdx.x] = normal.x; lane_hit[4][threadIdx.x] = normal.y; lane_hit[5][threadIdx.x] = normal.z;
+                        lane_hit[6][threadIdx.x] = d.x; lane_hit[7][threadIdx.x] = d.y; lane_hit[8][threadIdx.x] = d.z;
+                        lane_hit[9][threadIdx.x] = u2f((uint32_t)idx);
+                    }
+                    throughput = mk(1.0f, 1.0f, 1.0f);
                     depth = 0; hits = 0; pending = true;
                     deepest = deepest > 1u ? deepest : 1u;    // the primary ray's traceStep
                 } else {
@@ -1613,7 +1665,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
                 }
             }
             taken += take;
-            if (taken >= chunk_len) { chunk += G; taken = 0; open_chunk(); }
+            if (taken >= chunk_len) { chunk = next_chunk(chunk); taken = 0; open_chunk(); }
         }
         if (!__any(has_ray || pending)) {
             if (chunk >= n_chunks) break;
@@ -2092,7 +2144,10 @@ hipError_t launch_streams_level(const RenderArgs &a, const LevelArgs &lv, bool f
     const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
     const bool scalar_scene = lds > kMaxSceneLds;              // a scene too big for LDS at this occupancy: scalar loads
     const dim3 g(grid), b(kRenderBlock);
-    if (first) {
+    if (first && lv.samples_in_lane > 1) {
+        if (scalar_scene) hipLaunchKernelGGL((streams_level_kernel<false, true, true>), g, b, 0, stream, a, lv);
+        else              hipLaunchKernelGGL((streams_level_kernel<true, true, true>), g, b, lds, stream, a, lv);
+    } else if (first) {
         if (scalar_scene) hipLaunchKernelGGL((streams_level_kernel<false, true>), g, b, 0, stream, a, lv);
         else              hipLaunchKernelGGL((streams_level_kernel<true, true>), g, b, lds, stream, a, lv);
     } else {
