@@ -161,6 +161,9 @@ def main():
     ap.add_argument("--scene", choices=["s16", "main", "glass"], default="s16")
     ap.add_argument("--algorithm", choices=["inline", "streams"], default="inline")
     ap.add_argument("--weak", choices=["rows", "spp"], default="rows", help="weak scaling: what grows with the GPU count")
+    ap.add_argument("--part-of", type=int, default=0,
+                    help="one GPU only: render part 0 of this many row-stripe parts of the image (what one rank of an N-GPU job does), "
+                         "e.g. C5 per part: --scene glass --algorithm streams --width 3840 --height 2160 --spp 512 --part-of 8")
     ap.add_argument("--streams-form", choices=["auto", "stream"], default="auto",
                     help="render Streams: per-pixel kernels (auto) or the stream ('wavefront') form")
     args = ap.parse_args()
@@ -217,9 +220,12 @@ def main():
         args.stripe_rows = pick_stripe(height, world)
     ctx = pkg.Context(local_rank)
     ctx.set_scene(spheres, planes)
-    part = StripePartition(height, world, rank, args.stripe_rows)
-    if world > 1:
-        ctx.set_partition(args.stripe_rows, world, rank)
+    n_parts, my_part = (args.part_of, 0) if (world == 1 and args.part_of > 1) else (world, rank)
+    if n_parts != world and args.stripe_rows == pick_stripe(height, world):
+        args.stripe_rows = pick_stripe(height, n_parts)
+    part = StripePartition(height, n_parts, my_part, args.stripe_rows)
+    if n_parts > 1:
+        ctx.set_partition(args.stripe_rows, n_parts, my_part)
     ctx.resize(width, height)
     assert ctx.local_rows == part.local_rows
     color = torch.zeros((3, ctx.local_rows, width), dtype=torch.float32, device="cuda")
@@ -314,7 +320,8 @@ def main():
         dist.barrier()
 
     if rank == 0:
-        nominal_per_step = width * height * spp * BOUNCE_LIMIT          # whole job, all ranks
+        rows_total = ctx.local_rows if n_parts != world else height      # --part-of: the job is this part only
+        nominal_per_step = width * rows_total * spp * BOUNCE_LIMIT       # whole job, all ranks
         value = nominal_per_step * args.steps / elapsed / 1e6
         # dominant kernel, per launch on one GPU: pixels held x spp x 56 B / launch duration
         alg_bytes = ctx.local_rows * width * spp * BYTES_PER_PIXEL_SAMPLE
@@ -353,7 +360,8 @@ def main():
                        "primitives": int(len(spheres) + len(planes)),
                        "parallelism": "row stripes of %d rows over %d GPU(s)%s"
                                       % (args.stripe_rows, world, " + RCCL gather of colour planes" if world > 1 else ""),
-                       "rows_per_gpu": ctx.local_rows, "variant": args.variant},
+                       "rows_per_gpu": ctx.local_rows, "variant": args.variant,
+                       "part_of": args.part_of if n_parts != world else None},
             "live_bounce_fraction": round(live_total / (nominal_per_step * args.steps), 4) if args.algorithm == "inline" else None,
             "live_Mbounces_per_s": round(live_total / elapsed / 1e6, 1),
             "roofline": roofline,
