@@ -270,17 +270,21 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
         c->queue_capacity = capacity;
     }
     if (!c->d_qcount) PTMI_HIP(c, hipMalloc(&c->d_qcount, (size_t)kLvWords * sizeof(unsigned int)));
-    if (n != c->hit_capacity) {
+    const size_t hit_slots = 2 * n;                          // a glass primary hit contributes up to two start hits
+    if (hit_slots > 0xfffffff0ull) return fail(c, PTMI_ELIMIT, "image too large for the stream form of Streams");
+    if (hit_slots != c->hit_capacity) {
         if (c->hit_block) { PTMI_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->hit_block); c->hit_block = nullptr; c->hit_capacity = 0; }
-        PTMI_HIP(c, hipMalloc(&c->hit_block, (size_t)kHitListWords * n * 4));
-        c->hit_capacity = n;
+        PTMI_HIP(c, hipMalloc(&c->hit_block, (size_t)kHitListWords * hit_slots * 4));
+        c->hit_capacity = hit_slots;
     }
     HitList hits;
     {
         char *hb = static_cast<char *>(c->hit_block);
-        for (int k = 0; k < 9; ++k) hits.f[k] = reinterpret_cast<float *>(hb + (size_t)k * n * 4);
-        hits.idx = reinterpret_cast<uint32_t *>(hb + (size_t)9 * n * 4);
-        hits.pixel = reinterpret_cast<uint32_t *>(hb + (size_t)10 * n * 4);
+        for (int k = 0; k < 9; ++k) hits.f[k] = reinterpret_cast<float *>(hb + (size_t)k * hit_slots * 4);
+        for (int k = 0; k < 3; ++k) hits.t[k] = reinterpret_cast<float *>(hb + (size_t)(9 + k) * hit_slots * 4);
+        hits.idx = reinterpret_cast<uint32_t *>(hb + (size_t)12 * hit_slots * 4);
+        hits.pixel = reinterpret_cast<uint32_t *>(hb + (size_t)13 * hit_slots * 4);
+        hits.meta = reinterpret_cast<uint32_t *>(hb + (size_t)14 * hit_slots * 4);
     }
     const RayQueue q[2] = {carve_queue(c->queue_block, capacity, 0), carve_queue(c->queue_block, capacity, 1)};
     auto grid_for = [&](size_t items) {                      // (more chunks per wave, i.e. fewer waves, measured no faster: 1, 2, 4 equal, 8 slower)
@@ -293,7 +297,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
     PTMI_HIP(c, hipMemsetAsync(c->d_qcount, 0, (size_t)kLvCursor * kCounterStride * sizeof(unsigned int), c->stream));
     // every sample of a pixel shoots the same primary ray: its hit is evaluated once per call, pixels that miss stay out
     unsigned int *d_hit_count = c->d_qcount + (size_t)kLvHits * kCounterStride;
-    PTMI_HIP(c, launch_streams_primary(a, hits, d_hit_count, c->stream));
+    PTMI_HIP(c, launch_streams_primary(a, hits, c->d_qcount, c->stream));
     uint64_t cut_in_streams = 0;
     for (int s = 0; s < n_spp;) {
         const int span = in_lane_max > 1 ? in_lane_max : batch_max;       // samples this pass covers
@@ -323,7 +327,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
             return PTMI_OK;
         };
         int level = 0;
-        if (int rc = launch_level(0, n * (size_t)batch)) return rc;
+        if (int rc = launch_level(0, (c->has_glass ? 2 * n : n) * (size_t)batch)) return rc;
         // the levels the previous batch needed, each with a grid that covers the stream it is EXPECTED to read (the length
         // seen there last time plus a margin; the grid only sets the parallelism, any grid processes any length)
         for (size_t k = 0; k < seen.size(); ++k) {
@@ -358,6 +362,8 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
     PTMI_HIP(c, hipMemcpyAsync(raw.data(), c->d_qcount, (size_t)kLvCursor * kCounterStride * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
     for (int k = 0; k < 8; ++k) c->live_host += raw[(size_t)(kLvLive + k) * kCounterStride];
+    // the two children of every glass primary hit whose split is cached in the start list: counted here, per sample
+    c->live_host += 2ull * raw[(size_t)kLvSplitPixels * kCounterStride] * (uint64_t)n_spp;
     c->rays_dropped += raw[(size_t)kLvDropped * kCounterStride];
     c->rays_truncated += raw[(size_t)kLvCut * kCounterStride] + cut_in_streams;
     unsigned int longest = raw[(size_t)kLvDeepest * kCounterStride];            // stream_iterations: the deepest step of this call

@@ -69,16 +69,22 @@ constexpr int kStreamStepCapDefault = 1 << 16;   // traceSteps per ray lineage; 
 //   [kLvLive, +8) children emitted, sharded by workgroup | kLvCut rays cut by the step cap | kLvDropped children that found
 //   the output stream full | kLvDeepest deepest step + 1 | kLvCursor + 2 l: the reservation cursor of the stream level l WRITES
 //   (= the item count, holes included, of the stream level l + 1 reads) | kLvCursor + 2 l + 1: the children level l stored
-constexpr int kLvLive = 0, kLvCut = 8, kLvDropped = 9, kLvDeepest = 10, kLvHits = 11, kLvCursor = 12, kLvMaxLevels = 64;   // kLvHits: pixels whose primary ray hits
+constexpr int kLvLive = 0, kLvCut = 8, kLvDropped = 9, kLvDeepest = 10, kLvHits = 11, kLvSplitPixels = 12, kLvCursor = 13, kLvMaxLevels = 64;
+// kLvHits: start hits in the list; kLvSplitPixels: pixels whose (glass) primary hit was replaced by its children's hits
 constexpr int kLvWords = (kLvCursor + 2 * kLvMaxLevels) * kCounterStride;
-// The primary hits of the pixels held by a context, compacted (pixels whose primary ray misses take no part in a
-// sample beyond updateSeed): one record per hit pixel, struct-of-arrays, written once per render call.
+// The hits the samples of the held pixels START from, compacted, struct-of-arrays, written once per render call
+// (streams_primary_kernel).  Usually the pixel's primary hit (pixels whose primary ray misses take no part in a sample
+// beyond updateSeed).  For a GLASS primary hit -- whose two children are the same two rays in every sample, a glass hit
+// draws nothing that changes a direction -- the first hit of each child instead (0, 1 or 2 records), with the
+// throughput, the step index and the number of raw draws its ray's seed is ahead of the sample's.
 struct HitList {
-    float *f[9];            // hit position, normal, primary direction
+    float *f[9];            // hit position, normal, incoming direction
+    float *t[3];            // throughput of the incoming ray
     uint32_t *idx;          // primitive hit
     uint32_t *pixel;        // local pixel index
+    uint32_t *meta;         // step index of the incoming ray | raw draws << 8
 };
-constexpr int kHitListWords = 11;
+constexpr int kHitListWords = 15;
 struct LevelArgs {
     RayQueue in, out;               // `in` is unused by level 0 (it starts from the cached primary hits)
     HitList hits;                   // level 0
@@ -95,7 +101,7 @@ struct LevelArgs {
 };
 
 hipError_t launch_streams_level(const RenderArgs &a, const LevelArgs &lv, bool first, unsigned int grid, hipStream_t stream);
-hipError_t launch_streams_primary(const RenderArgs &a, HitList hits, unsigned int *hit_count, hipStream_t stream);
+hipError_t launch_streams_primary(const RenderArgs &a, HitList hits, unsigned int *counters, hipStream_t stream);
 unsigned int streams_first_block();   // output slots every wave of a level owns from the start
 hipError_t launch_streams_update_seed(Planes p, long long n, int draws, hipStream_t stream);
 

@@ -1487,43 +1487,85 @@ constexpr unsigned int kFirstBlock = 64, kNextBlock = 256;   // output slots a w
 #endif
 constexpr unsigned int kRefillBatch = PTMI_REFILL_BATCH;     // idle lanes a wave waits for before it runs the refill block
 
-// Level 0's input: the primary hit of every pixel whose primary ray hits something, compacted (ballot + prefix per wave,
-// one atomic per workgroup).  The order of the list does not matter: a pixel has one lineage per stream unless rays split.
-__global__ void __launch_bounds__(kBlock) streams_primary_kernel(const RenderArgs a, const HitList out, unsigned int *hit_count)
+// Level 0's input: the hits the samples start from (HitList), compacted -- ballot + prefix per wave, one atomic per
+// workgroup.  The order of the list does not matter: a pixel's additions are ordered (one lineage) unless rays split.
+// A glass primary hit is replaced by the first hits of its two children when that changes nothing observable: the
+// step cap cannot cut the children (>= 3) and the glass hit itself emits nothing (its emittance would have to be added
+// once per sample).  `counters`: the stream form's counter block (kLvHits, kLvSplitPixels, kLvDeepest).
+__global__ void __launch_bounds__(kBlock) streams_primary_kernel(const RenderArgs a, const HitList out, unsigned int *counters)
 {
     __shared__ unsigned int wave_hits[kBlock / 64];
     __shared__ unsigned int block_base;
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     const float4 *S = a.scene.packed;                        // one evaluation per pixel and call: scalar loads will do
+    const float4 *M = S + a.scene.geom_f4();
     const long long n_local = (long long)a.rows_local * a.width;
     const long long pixel = (long long)blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    bool hit = false;
-    V3 pos = mk(0, 0, 0), normal = pos, primary = pos;
-    int idx = 0;
+    int n_rec = 0;                                            // records this pixel contributes: 0, 1 or 2
+    V3 pos[2], nor[2], dir[2], thr[2];
+    int prim[2] = {0, 0};
+    uint32_t meta[2] = {0u, 0u};
+    bool split = false;
     if (pixel < n_local) {
         const int local_row = (int)(pixel / a.width);
         const int col = (int)(pixel - (long long)local_row * a.width);
-        primary = primary_direction(a.cam, col, global_row(local_row, a.stripe_rows, a.n_parts, a.part));
+        const V3 primary = primary_direction(a.cam, col, global_row(local_row, a.stripe_rows, a.n_parts, a.part));
         const HitSel h = check_hit(S, ns, np, a.cam.pos, primary);
-        if (h.just) { hit = true; idx = h.idx; hit_record(S, ns, h.idx, a.cam.pos, primary, h.t, pos, normal); }
+        if (h.just) {
+            V3 p0, n0;
+            hit_record(S, ns, h.idx, a.cam.pos, primary, h.t, p0, n0);
+            const float4 ma = M[2 * h.idx], mb = M[2 * h.idx + 1];
+            const V3 emit = scale_r(mk(ma.x, ma.y, ma.z), ma.w) * mk(1.0f, 1.0f, 1.0f);
+            split = f2u(mb.x) == 2u && a.stream_step_cap >= 3 && emit.x == 0.0f && emit.y == 0.0f && emit.z == 0.0f;
+            if (split) {
+                V3 ko[2], kd[2], kt[2]; Sfc32 ks[2]; Sfc32 dummy; dummy.a = dummy.b = dummy.c = dummy.counter = 0;
+                glass_children(mk(ma.x, ma.y, ma.z), mb.y, p0, n0, primary, mk(1.0f, 1.0f, 1.0f), dummy, ko, kd, kt, ks);
+                for (int k = 0; k < 2; ++k) {
+                    const V3 ro = k == 0 ? ko[0] : ko[1], rd = k == 0 ? kd[0] : kd[1], rt = k == 0 ? kt[0] : kt[1];
+                    const HitSel hc = check_hit(S, ns, np, ro, rd);
+                    if (hc.just) {
+                        V3 hp, hn;
+                        hit_record(S, ns, hc.idx, ro, rd, hc.t, hp, hn);
+                        const int e = n_rec++;
+                        if (e == 0) { pos[0] = hp; nor[0] = hn; dir[0] = rd; thr[0] = rt; prim[0] = hc.idx; meta[0] = 1u | ((3u + (unsigned int)k) << 8); }
+                        else        { pos[1] = hp; nor[1] = hn; dir[1] = rd; thr[1] = rt; prim[1] = hc.idx; meta[1] = 1u | ((3u + (unsigned int)k) << 8); }
+                    }
+                }
+            } else {
+                pos[0] = p0; nor[0] = n0; dir[0] = primary; thr[0] = mk(1.0f, 1.0f, 1.0f); prim[0] = h.idx; meta[0] = 0u;
+                n_rec = 1;
+            }
+        }
     }
-    const unsigned long long mask = __ballot(hit);
-    if (lane == 0) wave_hits[wave] = (unsigned int)__builtin_popcountll(mask);
+    const unsigned long long m0 = __ballot(n_rec > 0), m1 = __ballot(n_rec > 1), ms = __ballot(split);
+    if (lane == 0) wave_hits[wave] = (unsigned int)(__builtin_popcountll(m0) + __builtin_popcountll(m1));
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int total = 0;
         for (int w = 0; w < kBlock / 64; ++w) total += wave_hits[w];
-        block_base = total ? atomicAdd(hit_count, total) : 0u;
+        block_base = total ? atomicAdd(counters + kLvHits * kCounterStride, total) : 0u;
+    }
+    if (lane == 0 && ms) {
+        atomicAdd(counters + kLvSplitPixels * kCounterStride, (unsigned int)__builtin_popcountll(ms));
+        atomicMax(counters + kLvDeepest * kCounterStride, 2u);       // the children's traceStep
     }
     __syncthreads();
-    if (hit) {
-        unsigned int slot = block_base + (unsigned int)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wave; ++w) slot += wave_hits[w];
-        out.f[0][slot] = pos.x; out.f[1][slot] = pos.y; out.f[2][slot] = pos.z;
-        out.f[3][slot] = normal.x; out.f[4][slot] = normal.y; out.f[5][slot] = normal.z;
-        out.f[6][slot] = primary.x; out.f[7][slot] = primary.y; out.f[8][slot] = primary.z;
-        out.idx[slot] = (uint32_t)idx; out.pixel[slot] = (uint32_t)pixel;
+    unsigned int slot = block_base;
+    for (int w = 0; w < wave; ++w) slot += wave_hits[w];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int e = 0; e < 2; ++e) {
+        if (n_rec > e) {
+            const unsigned int i = slot + (e == 0 ? (unsigned int)__builtin_popcountll(m0 & below)
+                                                  : (unsigned int)(__builtin_popcountll(m0) + __builtin_popcountll(m1 & below)));
+            const V3 p = e == 0 ? pos[0] : pos[1], n = e == 0 ? nor[0] : nor[1], dd = e == 0 ? dir[0] : dir[1], tt = e == 0 ? thr[0] : thr[1];
+            out.f[0][i] = p.x; out.f[1][i] = p.y; out.f[2][i] = p.z;
+            out.f[3][i] = n.x; out.f[4][i] = n.y; out.f[5][i] = n.z;
+            out.f[6][i] = dd.x; out.f[7][i] = dd.y; out.f[8][i] = dd.z;
+            out.t[0][i] = tt.x; out.t[1][i] = tt.y; out.t[2][i] = tt.z;
+            out.idx[i] = (uint32_t)(e == 0 ? prim[0] : prim[1]); out.pixel[i] = (uint32_t)pixel;
+            out.meta[i] = e == 0 ? meta[0] : meta[1];
+        }
     }
 }
 
@@ -1644,15 +1686,23 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
                         sample_seed[0][threadIdx.x] = seed.a; sample_seed[1][threadIdx.x] = seed.b; sample_seed[2][threadIdx.x] = seed.c; sample_seed[3][threadIdx.x] = seed.counter;
                     }
                     load_cached_hit(lv.hits, i, o, normal, d, idx);
+                    const uint32_t meta = IN_LANE ? 0u : lv.hits.meta[i];   // (no ray splitting: every start hit is a primary hit)
+                    for (uint32_t q = 0; q < (meta >> 8); ++q) (void)sfc32_next(seed);      // the draws its ray's ancestors made
                     if (IN_LANE) {
                         lane_hit[0][threadIdx.x] = o.x; lane_hit[1][threadIdx.x] = o.y; lane_hit[2][threadIdx.x] = o.z;
                         lane_hit[3][threadIdx.x] = normal.x; lane_hit[4][threadIdx.x] = normal.y; lane_hit[5][threadIdx.x] = normal.z;
                         lane_hit[6][threadIdx.x] = d.x; lane_hit[7][threadIdx.x] = d.y; lane_hit[8][threadIdx.x] = d.z;
                         lane_hit[9][threadIdx.x] = u2f((uint32_t)idx);
                     }
-                    throughput = mk(1.0f, 1.0f, 1.0f);
-                    depth = 0; hits = 0; pending = true;
+                    throughput = IN_LANE ? mk(1.0f, 1.0f, 1.0f) : mk(lv.hits.t[0][i], lv.hits.t[1][i], lv.hits.t[2][i]);
+                    depth = meta & 0xffu; hits = 0; pending = true;
                     deepest = deepest > 1u ? deepest : 1u;    // the primary ray's traceStep
+                    if (!IN_LANE && near_zero(throughput)) {   // a start hit of a dead ray (a reflection of weight ~0): its emittance, nothing else
+                        const float4 ma = M[2 * idx];
+                        ++hits;
+                        add_colour(scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);
+                        lineage_ended();
+                    }
                 } else {
                     pixel = lv.in.pixel[i];
                     if (pixel != kHole) {
@@ -2159,11 +2209,11 @@ hipError_t launch_streams_level(const RenderArgs &a, const LevelArgs &lv, bool f
 
 unsigned int streams_first_block() { return kFirstBlock; }
 
-hipError_t launch_streams_primary(const RenderArgs &a, HitList hits, unsigned int *hit_count, hipStream_t stream)
+hipError_t launch_streams_primary(const RenderArgs &a, HitList hits, unsigned int *counters, hipStream_t stream)
 {
     const long long n = (long long)a.rows_local * a.width;
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(streams_primary_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, a, hits, hit_count);
+    hipLaunchKernelGGL(streams_primary_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, a, hits, counters);
     return hipGetLastError();
 }
 
