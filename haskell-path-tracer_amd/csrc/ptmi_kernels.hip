@@ -10,14 +10,19 @@
 //     draws and of floating-point additions is exactly that of n_spp successive `render` calls;
 //   * the primitive list is staged into LDS once per workgroup and read as wave-wide
 //     broadcasts (every lane walks the same primitive at the same time);
+//   * a shade whose outcome the next prepareRay is certain to freeze only adds its emittance and draws (surely_frozen_after);
 //   * no MFMA: the work is scalar-per-lane f32/f64 VALU with divergent control flow.
+// Kernels in this file: render_inline_kernel (+ pooled / persistent ablations), render_streams_kernel (Streams, one chain per
+// pixel), render_streams_tree_kernel (Streams with ray splitting, one tree per pixel), streams_primary_kernel +
+// streams_level_kernel (Streams as compacted streams, one launch per level), seed / create_with / present / stitch /
+// quad_order / point-query kernels.
 #include "ptmi_kernels.h"
 
 namespace ptmi {
 
 namespace {
 
-constexpr int kBlock = 256;      // small kernels and the wavefront step (its workgroup-level append wants many waves per atomic)
+constexpr int kBlock = 256;      // small streaming kernels
 constexpr size_t kMaxSceneLds = 3 * 1024;  // bytes of staged scene per one-wave workgroup before LDS would cap occupancy (~60 primitives)
 constexpr int kRenderBlock = 64; // render kernels: one wave per workgroup, so a finished wave's slot is refilled at once (+1 % on C2)
 #ifndef PTMI_FETCH_BATCH

@@ -86,7 +86,7 @@ typedef struct ptmi_camera {       /* data Camera   Objects.hs:67-74 */
 } ptmi_camera;
 
 typedef struct ptmi_stats {
-    uint64_t live_bounces;         /* iterations that took computeRay (Trace.hs:374) since the last reset */
+    uint64_t live_bounces;         /* Inline: iterations that took computeRay (Trace.hs:374); Streams: child rays emitted -- since the last reset */
     uint64_t nominal_bounces;      /* pixels x samples x bounce_limit since the last reset                  */
     uint64_t samples;              /* pixels x samples                                                       */
     float    last_render_ms;       /* device time of the last ptmi_render launch(es); 0 unless timing is on */
