@@ -212,17 +212,13 @@ void pack_scene(const ptmi_sphere *sph, int ns, const ptmi_plane *pl, int np, st
     for (int j = 0; j < np; ++j) mat(pl[j].color, pl[j].illuminance, pl[j].brdf_tag, pl[j].brdf_param);
 }
 
-constexpr size_t kStreamQueueBudget = 8ull << 30;   // bytes the two ray streams may take together (of 288 GB)
+constexpr size_t kStreamQueueBudget = 32ull << 30;  // bytes the two ray streams may take together (of 288 GB)
 constexpr int kStreamBatchMax = 16;                 // samples of every pixel that share one stream when rays can split
 
 RayQueue carve_queue(void *block, size_t capacity, int which)
 {
     RayQueue q;
-    char *b = static_cast<char *>(block) + (size_t)which * kRayQueueWords * capacity * 4;
-    for (int k = 0; k < 9; ++k) q.f[k] = reinterpret_cast<float *>(b + (size_t)k * capacity * 4);
-    q.pixel = reinterpret_cast<uint32_t *>(b + (size_t)9 * capacity * 4);
-    for (int k = 0; k < 4; ++k) q.seed[k] = reinterpret_cast<uint32_t *>(b + (size_t)(10 + k) * capacity * 4);
-    q.depth = reinterpret_cast<uint32_t *>(b + (size_t)14 * capacity * 4);
+    q.base = static_cast<uint32_t *>(block) + (size_t)which * kRayQueueWords * capacity;
     q.capacity = (unsigned int)capacity;
     return q;
 }
@@ -252,8 +248,10 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
     }
     if (a.seed_from_result) batch_max = 1;               // a sample starts from the seed the previous sample's last hit left
     // Without ray splitting (and with the default seed rule) a lane renders up to 64 successive samples of its pixel before it
-    // refills: one adder per pixel, in sample order, and launches long enough to pay for their start and drain.
-    const int in_lane_max = (!c->has_glass && !a.seed_from_result && c->opt_batch == 0) ? 64 : 1;
+    // refills: one adder per pixel, in sample order, and launches long enough to pay for their start and drain.  With GLASS a
+    // lane of level 0 renders the samples of the batch from its start hit one after the other (their refractions share the
+    // output stream): the start hits are read once per batch and a lane whose lineage ends goes on at once.
+    const int in_lane_max = c->has_glass ? batch_max : ((!a.seed_from_result && c->opt_batch == 0) ? 64 : 1);
     if (n * cap_factor > 0xfffffff0ull) return fail(c, PTMI_ELIMIT, "image too large for the stream form of Streams");
     static int max_grid = 0;                                 // persistent waves: 6 per SIMD
     if (!max_grid) {
@@ -278,14 +276,8 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
         c->hit_capacity = hit_slots;
     }
     HitList hits;
-    {
-        char *hb = static_cast<char *>(c->hit_block);
-        for (int k = 0; k < 9; ++k) hits.f[k] = reinterpret_cast<float *>(hb + (size_t)k * hit_slots * 4);
-        for (int k = 0; k < 3; ++k) hits.t[k] = reinterpret_cast<float *>(hb + (size_t)(9 + k) * hit_slots * 4);
-        hits.idx = reinterpret_cast<uint32_t *>(hb + (size_t)12 * hit_slots * 4);
-        hits.pixel = reinterpret_cast<uint32_t *>(hb + (size_t)13 * hit_slots * 4);
-        hits.meta = reinterpret_cast<uint32_t *>(hb + (size_t)14 * hit_slots * 4);
-    }
+    hits.base = static_cast<uint32_t *>(c->hit_block);
+    hits.slots = (unsigned int)hit_slots;
     const RayQueue q[2] = {carve_queue(c->queue_block, capacity, 0), carve_queue(c->queue_block, capacity, 1)};
     auto grid_for = [&](size_t items) {                      // (more chunks per wave, i.e. fewer waves, measured no faster: 1, 2, 4 equal, 8 slower)
         const size_t chunks = (items + 63) / 64;
@@ -293,8 +285,9 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
     };
     std::vector<unsigned int> raw((size_t)kLvWords);
     std::vector<unsigned int> seen;                          // stream lengths of the previous batch, per level (level 1 first)
-    // the statistics accumulate on the device over the whole call; the per-level cursors are preset at every launch
+    // the statistics accumulate on the device over the whole call; the per-level cursors are cleared once per batch
     PTMI_HIP(c, hipMemsetAsync(c->d_qcount, 0, (size_t)kLvCursor * kCounterStride * sizeof(unsigned int), c->stream));
+    std::vector<unsigned int> base((size_t)kLvMaxLevels, 0u);   // per level (mod kLvMaxLevels): where its reserved blocks start
     // every sample of a pixel shoots the same primary ray: its hit is evaluated once per call, pixels that miss stay out
     unsigned int *d_hit_count = c->d_qcount + (size_t)kLvHits * kCounterStride;
     PTMI_HIP(c, launch_streams_primary(a, hits, c->d_qcount, c->stream));
@@ -303,7 +296,9 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
         const int span = in_lane_max > 1 ? in_lane_max : batch_max;       // samples this pass covers
         const int covered = n_spp - s < span ? n_spp - s : span;
         const int batch = in_lane_max > 1 ? 1 : covered;                  // samples that share the stream
-        auto cursor_of = [&](int level) { return (size_t)(kLvCursor + 2 * (level % kLvMaxLevels)) * kCounterStride; };
+        auto cursor_of = [&](int level) { return (size_t)(kLvCursor + 3 * (level % kLvMaxLevels)) * kCounterStride; };
+        PTMI_HIP(c, hipMemsetAsync(c->d_qcount + (size_t)kLvCursor * kCounterStride, 0,
+                                   (size_t)3 * kLvMaxLevels * kCounterStride * sizeof(unsigned int), c->stream));
         auto launch_level = [&](int level, size_t expected_items) -> int {
             LevelArgs lv{};
             lv.in = q[(level + 1) & 1]; lv.out = q[level & 1];
@@ -311,18 +306,17 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
             lv.n_px = (unsigned int)n; lv.batch = batch;
             lv.stats = c->d_qcount;
             lv.in_count = level == 0 ? d_hit_count : c->d_qcount + cursor_of(level - 1);
+            lv.in_base = level == 0 ? 0u : base[(size_t)((level - 1) % kLvMaxLevels)];
             lv.out_count = c->d_qcount + cursor_of(level);
             lv.emitted = lv.out_count + kCounterStride;
+            lv.chunk_cursor = lv.out_count + 2 * kCounterStride;
             lv.may_emit = c->has_glass ? 1 : 0;
             lv.samples_in_lane = in_lane_max > 1 ? covered : 1;
-            lv.chunk_cursor = lv.out_count;                    // the output cursor is idle without ray splitting: it hands out chunks
-            if (lv.samples_in_lane > 1)
-                PTMI_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(lv.chunk_cursor), (int)grid_for(expected_items), 1, c->stream));
             const unsigned int grid = grid_for(expected_items);
-            if (lv.may_emit) {                                 // without a ray-splitting material nothing is appended: no cursor to preset
-                PTMI_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(lv.out_count), (int)(grid * first_block), 1, c->stream));
-                PTMI_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(lv.emitted), 0, 1, c->stream));
-            }
+            lv.out_base = grid * first_block;
+            base[(size_t)(level % kLvMaxLevels)] = lv.out_base;
+            if (level >= kLvMaxLevels)                         // the counter words come round again: this level's are long idle
+                PTMI_HIP(c, hipMemsetAsync(lv.out_count, 0, (size_t)3 * kCounterStride * sizeof(unsigned int), c->stream));
             PTMI_HIP(c, launch_streams_level(a, lv, level == 0, grid, c->stream));
             return PTMI_OK;
         };
@@ -341,7 +335,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
             // `null state` (Trace.hs:166-170): the loop goes on while the last level emitted a child that a further step may trace
             const bool more = raw[cursor_of(level) + kCounterStride] > 0u && level + 1 < a.stream_step_cap;
             if (!more) break;
-            const unsigned int cursor = raw[cursor_of(level)];
+            const size_t cursor = (size_t)raw[cursor_of(level)] + base[(size_t)(level % kLvMaxLevels)];
             ++level;
             if (int rc = launch_level(level, cursor < capacity ? cursor : capacity)) return rc;
         }
@@ -349,8 +343,8 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
             now.clear();
             for (int l = 0; l < level; ++l) {                // stream lengths (holes included) the levels 1.. read, while they held rays
                 if (raw[cursor_of(l) + kCounterStride] == 0u) break;
-                const unsigned int cursor = raw[cursor_of(l)];
-                now.push_back(cursor < capacity ? cursor : (unsigned int)capacity);
+                const size_t cursor = (size_t)raw[cursor_of(l)] + base[(size_t)(l % kLvMaxLevels)];
+                now.push_back((unsigned int)(cursor < capacity ? cursor : capacity));
             }
             seen.swap(now);
             // children of the deepest allowed level sit in a stream no level will read: the cap cut them

@@ -103,6 +103,20 @@ __host__ __device__ __noinline__ inline Reduced sincos_reduce_large(uint32_t xi)
 // two on the device for ALL 2^32 binary32 arguments and found them bit-identical after the final
 // rounding to binary32 (profiles/r01_verify_sincos.txt) -- glibc's own FMA build (`__sinf_fma`,
 // the variant x86-64 hosts with FMA dispatch to) is the same kind of contraction.
+// An FMA with two constant operands needs one of them in a vector register pair.  Kept live across the render loops those
+// pairs were the registers that spilled; formed where it is used -- two moves of literals, the same issue cycles as the copy
+// of a pair that the accumulating FMA needs anyway -- it occupies nothing.  (The empty asm keeps the halves from being hoisted.)
+PTMI_HD double local_constant(double k)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t lo = (uint32_t)__builtin_bit_cast(uint64_t, k), hi = (uint32_t)(__builtin_bit_cast(uint64_t, k) >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+#else
+    return k;
+#endif
+}
+
 template <bool FUSED>
 PTMI_HD void sincos_t(float y, float &sn, float &cs)
 {
@@ -129,12 +143,12 @@ PTMI_HD void sincos_t(float y, float &sn, float &cs)
     float S, Cp;
     if (FUSED) {
         const double x3 = xs * x2;
-        const double s1 = __builtin_fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+        const double s1 = __builtin_fma(x2, -0x1.994eb3774cf24p-13, local_constant(0x1.1107605230bc4p-7));
         const double x7 = x3 * x2;
         const double s = __builtin_fma(x3, -0x1.555545995a603p-3, xs);
         S = (float)__builtin_fma(x7, s1, s);
         const double x4 = x2 * x2;
-        const double c2 = __builtin_fma(x2, 0x1.99343027bf8c3p-16, -0x1.6c087e89a359dp-10);
+        const double c2 = __builtin_fma(x2, 0x1.99343027bf8c3p-16, local_constant(-0x1.6c087e89a359dp-10));
         const double c1 = __builtin_fma(x2, -0x1.ffffffd0c621cp-2, 0x1p0);
         const double x6 = x4 * x2;
         const double c = __builtin_fma(x4, 0x1.55553e1068f19p-5, c1);

@@ -219,7 +219,21 @@ int ptmi_group_render(ptmi_group *g, const ptmi_camera *camera, int algorithm, i
 {
     if (!g) return PTMI_EINVAL;
     std::lock_guard<std::mutex> lock(g->mu);
-    for (size_t i = 0; i < g->members.size(); ++i)             /* asynchronous: every device is busy before the first returns */
+    const size_t n = g->members.size();
+    // The per-pixel kernels are launched asynchronously: every device is busy before the first call returns.  The stream
+    // form of Streams reads stream lengths back while it runs (the host plays `awhile`), so its members get a thread each.
+    int64_t form = PTMI_FORM_AUTO;
+    if (algorithm == PTMI_STREAMS && n > 1) (void)ptmi_get_option(g->members[0], PTMI_OPT_STREAMS_FORM, &form);
+    if (form == PTMI_FORM_STREAM) {
+        std::vector<int> rcs(n, PTMI_OK);
+        std::vector<std::thread> threads;
+        for (size_t i = 0; i < n; ++i)
+            threads.emplace_back([&, i]() { rcs[i] = ptmi_render(g->members[i], camera, algorithm, bounce_limit, n_spp); });
+        for (std::thread &t : threads) t.join();
+        for (size_t i = 0; i < n; ++i) if (rcs[i] != PTMI_OK) return member_fail(g, (int)i, rcs[i]);
+        return PTMI_OK;
+    }
+    for (size_t i = 0; i < n; ++i)
         if (int rc = ptmi_render(g->members[i], camera, algorithm, bounce_limit, n_spp)) return member_fail(g, (int)i, rc);
     return PTMI_OK;
 }

@@ -55,49 +55,59 @@ enum { kScTruncated = 0, kScDropped = 1, kScWords = 4 };
 constexpr int kTreeStackDepth = 16;        // per-pixel tree walk: pending children a lane can hold (render_streams_tree_kernel)
 
 // Ray stream of the wavefront Streams path: struct-of-arrays, `capacity` rays (type RayState, Trace.hs:46)
+// One base pointer + the capacity (15 word planes of `capacity` slots each): fifteen pointers per stream as kernel arguments
+// filled the scalar register file of the level kernel and pushed constants and flags into scratch memory.
 struct RayQueue {
-    float *f[9];            // origin xyz, direction xyz, throughput xyz
-    uint32_t *pixel;        // local pixel index
-    uint32_t *seed[4];      // SFC32 a, b, c, counter
-    uint32_t *depth;        // traceSteps already taken by the ray's ancestors (= the awhile iteration it belongs to)
+    uint32_t *base;
     unsigned int capacity;  // slots
+    PTMI_HD uint32_t *plane(int k) const { return base + (size_t)k * capacity; }
+    PTMI_HD float *f(int k) const { return reinterpret_cast<float *>(plane(k)); }   // 0..8: origin xyz, direction xyz, throughput xyz
+    PTMI_HD uint32_t *pixel() const { return plane(9); }                             // local pixel index
+    PTMI_HD uint32_t *seed(int k) const { return plane(10 + k); }                    // SFC32 a, b, c, counter
+    PTMI_HD uint32_t *depth() const { return plane(14); }    // traceSteps already taken by the ray's ancestors (= the awhile iteration it belongs to)
 };
 constexpr int kRayQueueWords = 15;
 constexpr int kCounterStride = 32;          // device counters sit 128 B apart (one per cache line)
 constexpr int kStreamStepCapDefault = 1 << 16;   // traceSteps per ray lineage; the reference has no bound (Trace.hs:166-170) -- this only guarantees termination
 // Counters of the stream form, each kCounterStride words apart:
 //   [kLvLive, +8) children emitted, sharded by workgroup | kLvCut rays cut by the step cap | kLvDropped children that found
-//   the output stream full | kLvDeepest deepest step + 1 | kLvCursor + 2 l: the reservation cursor of the stream level l WRITES
-//   (= the item count, holes included, of the stream level l + 1 reads) | kLvCursor + 2 l + 1: the children level l stored
+//   the output stream full | kLvDeepest deepest step + 1 | kLvCursor + 3 l: the reservation cursor of the stream level l WRITES,
+//   counted from the end of its waves' static blocks (grid * first block: LevelArgs.out_base / in_base; that sum = the item
+//   count, holes included, of the stream level l + 1 reads) | + 1: the children level l stored | + 2: level l's chunk hand-out
 constexpr int kLvLive = 0, kLvCut = 8, kLvDropped = 9, kLvDeepest = 10, kLvHits = 11, kLvSplitPixels = 12, kLvCursor = 13, kLvMaxLevels = 64;
 // kLvHits: start hits in the list; kLvSplitPixels: pixels whose (glass) primary hit was replaced by its children's hits
-constexpr int kLvWords = (kLvCursor + 2 * kLvMaxLevels) * kCounterStride;
+constexpr int kLvWords = (kLvCursor + 3 * kLvMaxLevels) * kCounterStride;
 // The hits the samples of the held pixels START from, compacted, struct-of-arrays, written once per render call
 // (streams_primary_kernel).  Usually the pixel's primary hit (pixels whose primary ray misses take no part in a sample
 // beyond updateSeed).  For a GLASS primary hit -- whose two children are the same two rays in every sample, a glass hit
 // draws nothing that changes a direction -- the first hit of each child instead (0, 1 or 2 records), with the
 // throughput, the step index and the number of raw draws its ray's seed is ahead of the sample's.
 struct HitList {
-    float *f[9];            // hit position, normal, incoming direction
-    float *t[3];            // throughput of the incoming ray
-    uint32_t *idx;          // primitive hit
-    uint32_t *pixel;        // local pixel index
-    uint32_t *meta;         // step index of the incoming ray | raw draws << 8
+    uint32_t *base;
+    unsigned int slots;
+    PTMI_HD uint32_t *plane(int k) const { return base + (size_t)k * slots; }
+    PTMI_HD float *f(int k) const { return reinterpret_cast<float *>(plane(k)); }       // 0..8: hit position, normal, incoming direction
+    PTMI_HD float *t(int k) const { return reinterpret_cast<float *>(plane(9 + k)); }   // throughput of the incoming ray
+    PTMI_HD uint32_t *idx() const { return plane(12); }      // primitive hit
+    PTMI_HD uint32_t *pixel() const { return plane(13); }    // local pixel index
+    PTMI_HD uint32_t *meta() const { return plane(14); }     // step index of the incoming ray | raw draws << 8
 };
 constexpr int kHitListWords = 15;
 struct LevelArgs {
     RayQueue in, out;               // `in` is unused by level 0 (it starts from the cached primary hits)
     HitList hits;                   // level 0
-    const unsigned int *in_count;   // device: the producer level's cursor (NULL for level 0)
-    unsigned int *out_count;        // device: this level's reservation cursor, preset to grid * (first block size)
+    const unsigned int *in_count;   // device: level 0: start hits in the list; else the producer level's reservation cursor
+    unsigned int in_base;           // ... which counts from here (the producer's out_base)
+    unsigned int *out_count;        // device: this level's reservation cursor, zero at launch
+    unsigned int out_base;          // grid * (first block size): where reserved blocks start
     unsigned int *emitted;          // device: children this level stored in `out`
     unsigned int *stats;            // device: base of the counter block
     unsigned int n_px;              // pixels held by the context
     int batch;                      // level 0: samples of every pixel in this stream
     int may_emit;                   // 0: the scene has no ray-splitting material -- nothing is ever written to `out`
-    unsigned int *chunk_cursor;     // device: next chunk to hand out when samples_in_lane > 1 (preset to the grid size)
-    int samples_in_lane;            // level 0 without ray splitting: a lane renders this many successive samples of its pixel
-                                    // before it refills (the stream then holds every hit pixel once; batch is 1)
+    unsigned int *chunk_cursor;     // device: chunks handed out beyond the waves' own when samples_in_lane > 1 (zero at launch)
+    int samples_in_lane;            // level 0: a lane renders this many successive samples from its start hit before it
+                                    // refills (the stream then holds every start hit once; batch is 1)
 };
 
 hipError_t launch_streams_level(const RenderArgs &a, const LevelArgs &lv, bool first, unsigned int grid, hipStream_t stream);

@@ -1181,12 +1181,12 @@ __global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const R
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void queue_store(const RayQueue &q, unsigned int i, V3 o, V3 d, V3 t, uint32_t pixel, Sfc32 s, uint32_t depth)
 {
-    q.depth[i] = depth;
-    q.f[0][i] = o.x; q.f[1][i] = o.y; q.f[2][i] = o.z;
-    q.f[3][i] = d.x; q.f[4][i] = d.y; q.f[5][i] = d.z;
-    q.f[6][i] = t.x; q.f[7][i] = t.y; q.f[8][i] = t.z;
-    q.pixel[i] = pixel;
-    q.seed[0][i] = s.a; q.seed[1][i] = s.b; q.seed[2][i] = s.c; q.seed[3][i] = s.counter;
+    q.depth()[i] = depth;
+    q.f(0)[i] = o.x; q.f(1)[i] = o.y; q.f(2)[i] = o.z;
+    q.f(3)[i] = d.x; q.f(4)[i] = d.y; q.f(5)[i] = d.z;
+    q.f(6)[i] = t.x; q.f(7)[i] = t.y; q.f(8)[i] = t.z;
+    q.pixel()[i] = pixel;
+    q.seed(0)[i] = s.a; q.seed(1)[i] = s.b; q.seed(2)[i] = s.c; q.seed(3)[i] = s.counter;
 }
 
 // GLASS ior (extension): reflection child + refraction child; see the oracle's glass_children for the spec.
@@ -1564,12 +1564,12 @@ __global__ void __launch_bounds__(kBlock) streams_primary_kernel(const RenderArg
             const unsigned int i = slot + (e == 0 ? (unsigned int)__builtin_popcountll(m0 & below)
                                                   : (unsigned int)(__builtin_popcountll(m0) + __builtin_popcountll(m1 & below)));
             const V3 p = e == 0 ? pos[0] : pos[1], n = e == 0 ? nor[0] : nor[1], dd = e == 0 ? dir[0] : dir[1], tt = e == 0 ? thr[0] : thr[1];
-            out.f[0][i] = p.x; out.f[1][i] = p.y; out.f[2][i] = p.z;
-            out.f[3][i] = n.x; out.f[4][i] = n.y; out.f[5][i] = n.z;
-            out.f[6][i] = dd.x; out.f[7][i] = dd.y; out.f[8][i] = dd.z;
-            out.t[0][i] = tt.x; out.t[1][i] = tt.y; out.t[2][i] = tt.z;
-            out.idx[i] = (uint32_t)(e == 0 ? prim[0] : prim[1]); out.pixel[i] = (uint32_t)pixel;
-            out.meta[i] = e == 0 ? meta[0] : meta[1];
+            out.f(0)[i] = p.x; out.f(1)[i] = p.y; out.f(2)[i] = p.z;
+            out.f(3)[i] = n.x; out.f(4)[i] = n.y; out.f(5)[i] = n.z;
+            out.f(6)[i] = dd.x; out.f(7)[i] = dd.y; out.f(8)[i] = dd.z;
+            out.t(0)[i] = tt.x; out.t(1)[i] = tt.y; out.t(2)[i] = tt.z;
+            out.idx()[i] = (uint32_t)(e == 0 ? prim[0] : prim[1]); out.pixel()[i] = (uint32_t)pixel;
+            out.meta()[i] = e == 0 ? meta[0] : meta[1];
         }
     }
 }
@@ -1577,20 +1577,24 @@ __global__ void __launch_bounds__(kBlock) streams_primary_kernel(const RenderArg
 // level 0: a hit pixel (re)starts a sample from its cached primary hit
 __device__ __forceinline__ void load_cached_hit(const HitList &h, unsigned int i, V3 &pos, V3 &normal, V3 &dir, int &idx)
 {
-    pos = mk(h.f[0][i], h.f[1][i], h.f[2][i]);
-    normal = mk(h.f[3][i], h.f[4][i], h.f[5][i]);
-    dir = mk(h.f[6][i], h.f[7][i], h.f[8][i]);
-    idx = (int)h.idx[i];
+    pos = mk(h.f(0)[i], h.f(1)[i], h.f(2)[i]);
+    normal = mk(h.f(3)[i], h.f(4)[i], h.f(5)[i]);
+    dir = mk(h.f(6)[i], h.f(7)[i], h.f(8)[i]);
+    idx = (int)h.idx()[i];
 }
 
-// IN_LANE (level 0, scenes without ray splitting): a lane renders lv.samples_in_lane successive samples of its pixel before
-// it refills, and the waves take their chunks from a global counter (a chunk is then ~100 loop trips: one atomic each is cheap,
-// and a static share of 3 or 4 such chunks per wave would leave a quarter of the chip idle at the end).
+// IN_LANE (level 0): a lane renders lv.samples_in_lane successive samples from its start hit before it refills -- the hit
+// and the sample's seed live in a lane-private LDS column -- and the waves take their chunks from a global counter (a chunk is
+// then ~100 loop trips: one atomic each is cheap, and a static share of 3 or 4 such chunks per wave would leave a quarter of
+// the chip idle at the end).  Without ray splitting that covers up to 64 samples with ONE adder per pixel, in sample order
+// (bit-identical to the per-pixel kernel); with GLASS the samples of a batch, whose refractions share the output stream.
+// Cursors count from zero (the host clears all of them once per batch): the reservation cursor is relative to lv.out_base,
+// the chunk cursor to the grid size.
 template <bool LDS_SCENE, bool FIRST, bool IN_LANE = false>
 __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_kernel(const RenderArgs a, const LevelArgs lv)
 {
     __shared__ uint32_t sample_seed[IN_LANE ? 4 : 1][kRenderBlock];   // IN_LANE: the seed the lane's current sample started from
-    __shared__ float lane_hit[IN_LANE ? 10 : 1][kRenderBlock];        // IN_LANE: the lane's cached primary hit (position, normal, direction, primitive)
+    __shared__ float lane_hit[IN_LANE ? 14 : 1][kRenderBlock];        // IN_LANE: the lane's start hit (position, normal, direction, primitive, throughput, meta)
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -1606,14 +1610,14 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
     const unsigned int step_cap = (unsigned int)a.stream_step_cap;
 
     // input: level 0 = chunks_per_sample * batch chunks of <= 64 cached primary hits; later levels = ceil(n_in / 64) chunks
-    unsigned int n_in = *lv.in_count;                         // level 0: hit pixels; else the producer's cursor (real items and holes)
-    if (!FIRST) n_in = n_in < lv.in.capacity ? n_in : lv.in.capacity;
+    unsigned int n_in = *lv.in_count;                         // level 0: start hits; else the producer's cursor (real items and holes)
+    if (!FIRST) { n_in += lv.in_base; n_in = n_in < lv.in.capacity ? n_in : lv.in.capacity; }
     const unsigned int cps = (n_in + 63u) / 64u;
     const unsigned int n_chunks = FIRST ? cps * (unsigned int)lv.batch : cps;
     auto next_chunk = [&](unsigned int current) __attribute__((always_inline)) -> unsigned int {
         if (!IN_LANE) return current + G;                      // static stride
         unsigned int c = 0;
-        if (lane == 0) c = atomicAdd(lv.chunk_cursor, 1u);     // dynamic hand-out: the cursor starts at G
+        if (lane == 0) c = G + atomicAdd(lv.chunk_cursor, 1u); // dynamic hand-out: the first G chunks are the waves' own
         return (unsigned int)__builtin_amdgcn_readfirstlane((int)c);
     };
     unsigned int chunk = w, taken = 0;                       // wave-uniform cursor: chunk index, items of it already handed out
@@ -1631,14 +1635,17 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
     bool has_ray = false, pending = false;                    // a ray to trace / a hit to shade
     V3 o = mk(0, 0, 0), d = o, throughput = o, normal = o;    // o: the ray's origin, or the position of the pending hit
     Sfc32 seed; seed.a = seed.b = seed.c = seed.counter = 0;
-    uint32_t pixel = 0, depth = 0, hits = 0;                  // depth: step index of the lane's current ray
+    uint32_t pixel = 0, depth = 0, hits = 0;                  // depth: step index of the lane's current ray; hits: FROM_RESULT only (never IN_LANE)
     int idx = 0;
     unsigned int sample_j = 0;                                // IN_LANE: which of its pixel's samples the lane is rendering
-    unsigned int live = 0, cut = 0, dropped = 0, deepest = 0, stored = 0;
+    unsigned int deepest = 0;
+    unsigned int live_w = 0, cut_w = 0, dropped_w = 0, stored_w = 0;   // wave-uniform statistics (scalar registers: the lanes' are scarce)
 
     // combine new old (PTMI_SEED_FROM_RESULT; never with GLASS): the seed the lineage's last hit carried = the pixel's
     // seed + 3 draws per earlier hit, written back so that updateSeed advances the survivor
-    auto lineage_ended = [&]() __attribute__((always_inline)) {
+    // Returns whether the lane holds a hit to shade again (IN_LANE: its next sample); the callers set the flags -- a closure
+    // that captured `has_ray` / `pending` by reference kept both in scratch memory.
+    auto lineage_ended = [&]() __attribute__((always_inline)) -> bool {
         if (IN_LANE && sample_j + 1u < (unsigned int)lv.samples_in_lane) {
             // Without ray splitting a pixel has one lineage per sample: the lane goes on with the pixel's next sample, so that
             // one lane adds to the pixel in sample order (bit-identical to the per-pixel kernel) and a launch is long enough
@@ -1652,16 +1659,18 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
             normal = mk(lane_hit[3][threadIdx.x], lane_hit[4][threadIdx.x], lane_hit[5][threadIdx.x]);
             d = mk(lane_hit[6][threadIdx.x], lane_hit[7][threadIdx.x], lane_hit[8][threadIdx.x]);
             idx = (int)f2u(lane_hit[9][threadIdx.x]);
-            throughput = mk(1.0f, 1.0f, 1.0f);
-            depth = 0; hits = 0; pending = true; has_ray = false;
-            return;
+            throughput = mk(lane_hit[10][threadIdx.x], lane_hit[11][threadIdx.x], lane_hit[12][threadIdx.x]);
+            const uint32_t meta = f2u(lane_hit[13][threadIdx.x]);
+            for (uint32_t q = 0; q < (meta >> 8); ++q) (void)sfc32_next(seed);          // the draws its ray's ancestors made
+            depth = meta & 0xffu;
+            return true;
         }
-        if (a.seed_from_result && hits > 0u) {
+        if (!IN_LANE && a.seed_from_result && hits > 0u) {
             Sfc32 sd; sd.a = a.planes.sa[pixel]; sd.b = a.planes.sb[pixel]; sd.c = a.planes.sc[pixel]; sd.counter = a.planes.sctr[pixel];
             for (unsigned int k = 3u; k < 3u * hits; ++k) (void)sfc32_next(sd);
             a.planes.sa[pixel] = sd.a; a.planes.sb[pixel] = sd.b; a.planes.sc[pixel] = sd.c; a.planes.sctr[pixel] = sd.counter;
         }
-        has_ray = false; pending = false;
+        return false;
     };
     // computeResult + permute (+) (Trace.hs:179-184, :318-323); adding an exact zero changes nothing
     auto add_colour = [&](V3 c) __attribute__((always_inline)) {
@@ -1683,7 +1692,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
                 if (FIRST) {
                     // initialState (Trace.hs:158-162) one step on: the pixel's cached primary hit; sample j of the batch
                     // starts from the pixel's seed advanced by j draws, which is what j updateSeeds leave (Trace.hs:190-191)
-                    pixel = lv.hits.pixel[i];
+                    pixel = lv.hits.pixel()[i];
                     seed.a = a.planes.sa[pixel]; seed.b = a.planes.sb[pixel]; seed.c = a.planes.sc[pixel]; seed.counter = a.planes.sctr[pixel];
                     for (unsigned int q = 0; q < chunk_j; ++q) (void)random_float(seed);
                     if (IN_LANE) {
@@ -1691,31 +1700,39 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
                         sample_seed[0][threadIdx.x] = seed.a; sample_seed[1][threadIdx.x] = seed.b; sample_seed[2][threadIdx.x] = seed.c; sample_seed[3][threadIdx.x] = seed.counter;
                     }
                     load_cached_hit(lv.hits, i, o, normal, d, idx);
-                    const uint32_t meta = IN_LANE ? 0u : lv.hits.meta[i];   // (no ray splitting: every start hit is a primary hit)
+                    const uint32_t meta = lv.hits.meta()[i];
                     for (uint32_t q = 0; q < (meta >> 8); ++q) (void)sfc32_next(seed);      // the draws its ray's ancestors made
+                    throughput = mk(lv.hits.t(0)[i], lv.hits.t(1)[i], lv.hits.t(2)[i]);
                     if (IN_LANE) {
                         lane_hit[0][threadIdx.x] = o.x; lane_hit[1][threadIdx.x] = o.y; lane_hit[2][threadIdx.x] = o.z;
                         lane_hit[3][threadIdx.x] = normal.x; lane_hit[4][threadIdx.x] = normal.y; lane_hit[5][threadIdx.x] = normal.z;
                         lane_hit[6][threadIdx.x] = d.x; lane_hit[7][threadIdx.x] = d.y; lane_hit[8][threadIdx.x] = d.z;
                         lane_hit[9][threadIdx.x] = u2f((uint32_t)idx);
+                        lane_hit[10][threadIdx.x] = throughput.x; lane_hit[11][threadIdx.x] = throughput.y; lane_hit[12][threadIdx.x] = throughput.z;
+                        lane_hit[13][threadIdx.x] = u2f(meta);
                     }
-                    throughput = IN_LANE ? mk(1.0f, 1.0f, 1.0f) : mk(lv.hits.t[0][i], lv.hits.t[1][i], lv.hits.t[2][i]);
                     depth = meta & 0xffu; hits = 0; pending = true;
                     deepest = deepest > 1u ? deepest : 1u;    // the primary ray's traceStep
-                    if (!IN_LANE && near_zero(throughput)) {   // a start hit of a dead ray (a reflection of weight ~0): its emittance, nothing else
+                    if (near_zero(throughput)) {               // a start hit of a dead ray (a reflection of weight ~0): its emittance, nothing else
                         const float4 ma = M[2 * idx];
-                        ++hits;
-                        add_colour(scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);
-                        lineage_ended();
+                        const V3 term = scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput;
+                        if (IN_LANE) {                         // ... in every one of the lane's samples: the hit is the same
+                            for (int q = 0; q < lv.samples_in_lane; ++q) add_colour(term);
+                            pending = false;
+                        } else {
+                            ++hits;
+                            add_colour(term);
+                            pending = lineage_ended();
+                        }
                     }
                 } else {
-                    pixel = lv.in.pixel[i];
+                    pixel = lv.in.pixel()[i];
                     if (pixel != kHole) {
-                        o = mk(lv.in.f[0][i], lv.in.f[1][i], lv.in.f[2][i]);
-                        d = mk(lv.in.f[3][i], lv.in.f[4][i], lv.in.f[5][i]);
-                        throughput = mk(lv.in.f[6][i], lv.in.f[7][i], lv.in.f[8][i]);
-                        seed.a = lv.in.seed[0][i]; seed.b = lv.in.seed[1][i]; seed.c = lv.in.seed[2][i]; seed.counter = lv.in.seed[3][i];
-                        depth = lv.in.depth[i]; hits = 0; has_ray = true;
+                        o = mk(lv.in.f(0)[i], lv.in.f(1)[i], lv.in.f(2)[i]);
+                        d = mk(lv.in.f(3)[i], lv.in.f(4)[i], lv.in.f(5)[i]);
+                        throughput = mk(lv.in.f(6)[i], lv.in.f(7)[i], lv.in.f(8)[i]);
+                        seed.a = lv.in.seed(0)[i]; seed.b = lv.in.seed(1)[i]; seed.c = lv.in.seed(2)[i]; seed.counter = lv.in.seed(3)[i];
+                        depth = lv.in.depth()[i]; hits = 0; has_ray = true;
                     }
                 }
             }
@@ -1730,21 +1747,21 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
         // ---- shade round: every pending hit belongs to a ray that is alive (dead ones were finished after their trace)
         bool emits = false;
         V3 ko = o, kd = o, kt = o; Sfc32 ks = seed;
+        live_w += (unsigned int)__builtin_popcountll(__ballot(pending));      // one child per shaded hit ...
         if (pending) {
             const float4 ma = M[2 * idx], mb = M[2 * idx + 1];
             V3 contribution;
-            ++hits;
+            if (!IN_LANE) ++hits;
             if (f2u(mb.x) == 2u) {                            // GLASS (extension): reflection stays, refraction is emitted
                 contribution = scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput;
                 V3 co[2], cd[2], ct[2]; Sfc32 cs[2];
                 glass_children(mk(ma.x, ma.y, ma.z), mb.y, o, normal, d, throughput, seed, co, cd, ct, cs);
                 o = co[0]; d = cd[0]; throughput = ct[0]; seed = cs[0];
                 ko = co[1]; kd = cd[1]; kt = ct[1]; ks = cs[1];
-                emits = true; live += 2u;
+                emits = true;
             } else {
                 contribution = mk(0.0f, 0.0f, 0.0f);
                 shade(M, idx, o, normal, o, d, throughput, contribution, seed);   // contribution = 0 + emittance * throughput
-                ++live;
             }
             add_colour(contribution);
             ++depth; pending = false; has_ray = true;          // the child: next traceStep, same lane
@@ -1753,39 +1770,40 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
         const unsigned long long kids = lv.may_emit ? __ballot(emits) : 0ull;
         if (kids) {                                           // wave-uniform
             const unsigned int cnt = (unsigned int)__builtin_popcountll(kids), rank = (unsigned int)__builtin_popcountll(kids & below);
+            live_w += cnt;                                    // ... and a second one per GLASS hit
             const unsigned int room = blk_end - blk;
             unsigned int slot = blk + rank;
             if (cnt > room) {                                 // the block is full: one atomic reserves the next for the whole wave
                 unsigned int fresh = 0;
-                if (lane == 0) fresh = atomicAdd(lv.out_count, kNextBlock);
+                if (lane == 0) fresh = lv.out_base + atomicAdd(lv.out_count, kNextBlock);
                 fresh = (unsigned int)__builtin_amdgcn_readfirstlane((int)fresh);
                 if (rank >= room) slot = fresh + (rank - room);
                 blk = fresh + (cnt - room); blk_end = fresh + kNextBlock;
             } else {
                 blk += cnt;
             }
-            if (emits) {
-                if (slot < lv.out.capacity) { queue_store(lv.out, slot, ko, kd, kt, pixel, ks, depth); ++stored; }   // depth: the child's step index
-                else ++dropped;
-            }
+            const unsigned int lost = (unsigned int)__builtin_popcountll(__ballot(emits && slot >= lv.out.capacity));
+            stored_w += cnt - lost; dropped_w += lost;
+            if (emits && slot < lv.out.capacity) queue_store(lv.out, slot, ko, kd, kt, pixel, ks, depth);   // depth: the child's step index
         }
         // ---- trace round: one traceStep (Trace.hs:272-294) for every lane that holds a ray
+        cut_w += (unsigned int)__builtin_popcountll(__ballot(has_ray && depth >= step_cap));
         if (has_ray) {
             if (depth >= step_cap) {                          // the safety cap (the reference has none): the ray is in the stream, never traced
-                ++cut; lineage_ended();
+                has_ray = false; pending = lineage_ended();
             } else {
                 deepest = depth + 1u > deepest ? depth + 1u : deepest;
                 const HitSel h = check_hit(S, ns, np, o, d);
                 if (!h.just) {
-                    lineage_ended();
+                    has_ray = false; pending = lineage_ended();
                 } else {
                     hit_record(S, ns, h.idx, o, d, h.t, o, normal);
                     idx = h.idx;
                     if (near_zero(throughput)) {              // numNewRays = 0: the hit adds its emittance, nothing else of it survives
                         const float4 ma = M[2 * idx];
-                        ++hits;
+                        if (!IN_LANE) ++hits;
                         add_colour(scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);
-                        lineage_ended();
+                        has_ray = false; pending = lineage_ended();
                     } else {
                         has_ray = false; pending = true;
                     }
@@ -1796,21 +1814,18 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
     // what is left of this wave's last block: holes
     if (lv.may_emit) {
         const unsigned int end = blk_end < lv.out.capacity ? blk_end : lv.out.capacity;
-        for (unsigned int i = blk + (unsigned int)lane; i < end; i += 64u) lv.out.pixel[i] = kHole;
+        for (unsigned int i = blk + (unsigned int)lane; i < end; i += 64u) lv.out.pixel()[i] = kHole;
     }
     // statistics: one set of atomics per wave, on counters sharded by workgroup
-    const unsigned long long n_live = wave_sum(live), n_stored = wave_sum(stored);
     unsigned int deep = deepest;
     for (int off = 32; off > 0; off >>= 1) { const unsigned int other = __shfl_xor(deep, off, 64); deep = other > deep ? other : deep; }
-    const bool rare = __any((cut | dropped) != 0u);
-    const unsigned long long n_cut = rare ? wave_sum(cut) : 0ull, n_dropped = rare ? wave_sum(dropped) : 0ull;
     if (lane == 0) {
         unsigned int *st = lv.stats;
-        if (n_live) atomicAdd(st + (kLvLive + (w & 7u)) * kCounterStride, (unsigned int)n_live);
-        if (n_stored) atomicAdd(lv.emitted, (unsigned int)n_stored);
+        if (live_w) atomicAdd(st + (kLvLive + (w & 7u)) * kCounterStride, live_w);
+        if (stored_w) atomicAdd(lv.emitted, stored_w);
         if (deep) atomicMax(st + kLvDeepest * kCounterStride, deep);
-        if (n_cut) atomicAdd(st + kLvCut * kCounterStride, (unsigned int)n_cut);
-        if (n_dropped) atomicAdd(st + kLvDropped * kCounterStride, (unsigned int)n_dropped);
+        if (cut_w) atomicAdd(st + kLvCut * kCounterStride, cut_w);
+        if (dropped_w) atomicAdd(st + kLvDropped * kCounterStride, dropped_w);
     }
 }
 

@@ -84,3 +84,30 @@ def test_group_device_gather_one_member(pkg, monkeypatch, force_rccl):
             g.gather_color(0, r, gp, b)
             got = out.download_color()
     assert_planes_equal(got, want, "device gather (%s)" % ("RCCL" if force_rccl else "copy"))
+
+
+@pytest.mark.gpu
+def test_group_renders_the_stream_form_on_all_members(pkg):
+    """render Streams in its stream form reads stream lengths back while it runs, so ptmi_group_render gives every member a
+    host thread; the stitched colours equal the ungrouped per-pixel Streams image bit for bit (no ray-splitting material)."""
+    sp, pl = pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    w, h = 211, 97
+    with pkg.Context(0) as c:
+        c.set_scene(sp, pl)
+        c.resize(w, h)
+        c.init_output(11)
+        c.render(cam, 8, 3, pkg.STREAMS)
+        want = c.download_color()
+        live = c.stats()["live_bounces"]
+    with pkg.Group([0, 0, 0], 4) as g:
+        g.set_scene(sp, pl)
+        g.resize(w, h)
+        g.init_output(11)
+        for i in range(g.size):
+            g.member(i).set_option(pkg.binding.OPT_STREAMS_FORM, pkg.binding.FORM_STREAM)
+        g.render(cam, 8, 3, pkg.STREAMS)
+        g.synchronize()
+        got = g.download_color()
+        assert g.stats()["live_bounces"] == live
+    assert_planes_equal(got, want, "group of 3, stream form")
