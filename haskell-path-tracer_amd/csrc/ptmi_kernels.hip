@@ -50,6 +50,32 @@ __device__ __forceinline__ float sqrt_rn(float x)
     return r;
 }
 
+// v ^/ s for the three components of a sphere normal: three IEEE divisions by ONE denominator.  The compiler's division is
+// div_scale (both operands), rcp, two refinements of the reciprocal, quotient, two residual corrections, div_fmas, div_fixup;
+// when neither operand needs scaling and nothing is special -- the denominator within [2^-20, 2^40], the numerators at least
+// 2^-100 in magnitude and (being components of the vector whose length the denominator is) not above it -- div_scale is the
+// identity, div_fmas a plain fma and div_fixup passes the quotient through, so the same operations with the reciprocal and its
+// refinements formed ONCE give the same three quotients bit for bit (18 instead of 33 instructions, one v_rcp_f32 instead of
+// three).  If any lane of the wave falls outside (a zero component, a huge sphere, a NaN) the wave takes the compiler's form.
+__device__ __forceinline__ V3 div3_by_length(V3 v, float s)
+{
+#ifdef PTMI_PLAIN_DIVISION
+    return div_r(v, s);
+#else
+    const float amin = __builtin_fminf(__builtin_fminf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), __builtin_fabsf(v.z));
+    const bool plain = s >= 0x1p-20f && s <= 0x1p40f && amin >= 0x1p-100f;
+    if (__builtin_expect(!__all(plain), 0)) return div_r(v, s);
+    const float r0 = __builtin_amdgcn_rcpf(s);
+    const float r = __builtin_fmaf(__builtin_fmaf(-s, r0, 1.0f), r0, r0);
+    auto quotient = [&](float a) {
+        float q = a * r;
+        q = __builtin_fmaf(__builtin_fmaf(-s, q, a), r, q);
+        return __builtin_fmaf(__builtin_fmaf(-s, q, a), r, q);
+    };
+    return mk(quotient(v.x), quotient(v.y), quotient(v.z));
+#endif
+}
+
 // checkHit (Trace.hs:443-447): mapScene over spheres ++ planes (Util.hs:156-158), then
 // expMinWith (Util.hs:171-178): left fold keeping the accumulated element iff keyA <= keyB.
 // The reference builds every hit record and selects; selecting the index first and building
@@ -175,7 +201,7 @@ __device__ __forceinline__ void hit_record(ScenePtr S, int ns, int idx, V3 o, V3
         // normalize (linear): v unchanged if |v|^2 is within 1e-6 of 0 or 1, else v / sqrt |v|^2
         const V3 v = hit_pos - mk(g.x, g.y, g.z);
         const float len2 = dot(v, v);
-        normal = (near_zero(len2) || near_zero(1.0f - len2)) ? v : div_r(v, sqrt_rn(len2));
+        normal = (near_zero(len2) || near_zero(1.0f - len2)) ? v : div3_by_length(v, sqrt_rn(len2));
     } else {
         const float4 gn = S[ns + 2 * (idx - ns) + 1];
         normal = mk(gn.x, gn.y, gn.z);
@@ -190,7 +216,7 @@ __device__ __forceinline__ V3 normal_at(ScenePtr S, int ns, int idx, V3 hit_pos)
         const float4 g = S[idx];
         const V3 v = hit_pos - mk(g.x, g.y, g.z);
         const float len2 = dot(v, v);
-        return (near_zero(len2) || near_zero(1.0f - len2)) ? v : div_r(v, sqrt_rn(len2));
+        return (near_zero(len2) || near_zero(1.0f - len2)) ? v : div3_by_length(v, sqrt_rn(len2));
     }
     const float4 gn = S[ns + 2 * (idx - ns) + 1];
     return mk(gn.x, gn.y, gn.z);

@@ -95,6 +95,48 @@ def test_device_equals_oracle_bitwise_on_random_rays(ctx, pkg, ora):
             assert np.array_equal(nrm[i, 3:], pl[i]["direction"])
 
 
+def test_sphere_normals_equal_oracle_when_every_lane_hits(ctx, pkg, ora):
+    """hit's normalisation divides three components by one length; the device shares the reciprocal when no operand of any
+    lane needs scaling (div3_by_length) and takes the compiler's division otherwise.  Rays aimed AT their spheres, so that
+    whole waves hit: ordinary magnitudes (the shared form), then the same with axis-aligned rays (zero components), tiny
+    and huge spheres (the fallback).  Bit for bit against the oracle's IEEE divisions."""
+    r = np.random.default_rng(2024)
+
+    def batch(n, radius, aligned):
+        rad = radius(n).astype(F)
+        c = (r.uniform(-10, 10, (n, 3)) * rad[:, None]).astype(F)
+        if aligned:
+            axis = r.integers(0, 3, n)
+            off = np.zeros((n, 3), F)
+            off[np.arange(n), axis] = (rad * F(3.0)).astype(F)
+            o = (c + off).astype(F)
+            d = np.zeros((n, 3), F)
+            d[np.arange(n), axis] = F(-1.0)
+        else:
+            o = (c + (r.normal(0, 1, (n, 3)) * rad[:, None] * 4).astype(F)).astype(F)
+            target = (c + (r.uniform(-0.5, 0.5, (n, 3)) * rad[:, None]).astype(F)).astype(F)
+            v = (target - o).astype(np.float64)
+            d = (v / np.linalg.norm(v, axis=1)[:, None]).astype(F)       # (linear's normalize leaves tiny vectors unscaled)
+        sph = np.array([rp.make_sphere(pkg.world.SPHERE_DTYPE, p, q) for p, q in zip(c, rad)])
+        just, t, nrm = ctx.eval_distance_to_sphere(sph, np.concatenate([o, d], 1))
+        hits = 0
+        for i in range(n):
+            want = ora.distance_to_sphere(o[i], d[i], sph[i])
+            assert bool(just[i]) == (want is not None)
+            if want is not None:
+                hits += 1
+                pos, nor, _ = ora.hit_sphere(o[i], d[i], want, sph[i])
+                assert np.array_equal(nrm[i, :3].view(np.uint32), pos.view(np.uint32))
+                assert np.array_equal(nrm[i, 3:].view(np.uint32), nor.view(np.uint32)), (i, nrm[i, 3:], nor)
+        return hits
+
+    n = 4096
+    assert batch(n, lambda k: np.exp(r.uniform(np.log(0.05), np.log(500.0), k)), False) > 0.9 * n
+    assert batch(n, lambda k: r.uniform(0.5, 3.0, k), True) > 0.9 * n
+    assert batch(n, lambda k: np.exp(r.uniform(np.log(1e-7), np.log(1e-5), k)), False) > 0
+    assert batch(n, lambda k: np.exp(r.uniform(np.log(1e13), np.log(1e17), k)), False) > 0
+
+
 def test_device_sincos_equals_oracle_and_libm(ctx, ora):
     """The device's sin/cos (binary64 evaluation of glibc's algorithm) == oracle == host libm, bitwise."""
     r = np.random.default_rng(5)
