@@ -1396,8 +1396,14 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                 }
             };
             if (n_spp > 0) { begin_sample(); next_start(); }
+#ifdef PTMI_TREE_STATS
+            unsigned int st_dead = 0, st_shade = 0, st_trace = 0;      // this lane's participation per round (diagnostic build)
+#endif
             while (pending || has_ray) {
                 ++trips;
+#ifdef PTMI_TREE_STATS
+                if (pending && !has_ray && near_zero(throughput)) ++st_dead;
+#endif
                 // shade round.  A ray whose throughput is already near zero dies at this hit (numNewRays): the hit adds its
                 // emittance and nothing else of it survives, so such lanes skip the expensive half and go on with their most
                 // recent waiting child, their sample's next start hit or the pixel's next sample -- in the latter cases they
@@ -1414,6 +1420,9 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                 // weight ~0: it must not be shaded; it waits for the next trip's dead-ray block.  A test inside next_start
                 // instead cost 12 %.)
                 if (pending && !has_ray && !near_zero(throughput)) {   // alive
+#ifdef PTMI_TREE_STATS
+                    ++st_shade;
+#endif
                     const float4 ma = M[2 * idx], mb = M[2 * idx + 1];
                     const bool capped = steps + 1u >= step_cap;
                     if (f2u(mb.x) == 2u) {                        // GLASS: two children (extension; spec = the oracle's glass_children)
@@ -1446,6 +1455,9 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                     }
                 }
                 if (has_ray) {
+#ifdef PTMI_TREE_STATS
+                    ++st_trace;
+#endif
                     deepest = steps + 1u > deepest ? steps + 1u : deepest;
                     const HitSel h = check_hit(S, ns, np, pos, d);
                     has_ray = false;
@@ -1459,12 +1471,27 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                 }
                 if (ended) lineage_ended();
             }
+#ifdef PTMI_TREE_STATS
+            // [1] lane-trips needed, [2] dead-ray finishes, [3] shades, [4] traces (lane participations)
+            atomicAdd(a.work_counter + 1, trips); atomicAdd(a.work_counter + 2, st_dead);
+            atomicAdd(a.work_counter + 3, st_shade); atomicAdd(a.work_counter + 4, st_trace);
+#endif
         }
+#ifdef PTMI_TREE_STATS_MAP
+        acc.x = (float)trips;                                         // diagnostic build: the red plane becomes the per-pixel cost map
+#endif
         a.planes.r[pixel] = acc.x; a.planes.g[pixel] = acc.y; a.planes.b[pixel] = acc.z;
         a.planes.sa[pixel] = pixel_seed.a; a.planes.sb[pixel] = pixel_seed.b;
         a.planes.sc[pixel] = pixel_seed.c; a.planes.sctr[pixel] = pixel_seed.counter;
     }
     leave_sample_chunk<TILE_W>(a, wg, chunk);
+#ifdef PTMI_TREE_STATS
+    {   // [5] lane-trips the wave paid for: its longest lane x 64
+        unsigned int mx = trips;
+        for (int off = 32; off > 0; off >>= 1) { const unsigned int o2 = __shfl_xor(mx, off, 64); mx = o2 > mx ? o2 : mx; }
+        if ((threadIdx.x & 63) == 0) atomicAdd(a.work_counter + 5, mx * 64u);
+    }
+#endif
     if (TILE_W > 0) record_cost(a, quad, trips);
     if (a.live_counter) {
         const unsigned long long total = wave_sum(live);
@@ -1516,7 +1543,11 @@ constexpr unsigned int kFirstBlock = 64, kNextBlock = 256;   // output slots a w
 #ifndef PTMI_REFILL_BATCH
 #define PTMI_REFILL_BATCH 8
 #endif
+#ifndef PTMI_REFILL_BATCH_IN_LANE
+#define PTMI_REFILL_BATCH_IN_LANE 1
+#endif
 constexpr unsigned int kRefillBatch = PTMI_REFILL_BATCH;     // idle lanes a wave waits for before it runs the refill block
+constexpr unsigned int kRefillBatchInLane = PTMI_REFILL_BATCH_IN_LANE;
 
 // Level 0's input: the hits the samples start from (HitList), compacted -- ballot + prefix per wave, one atomic per
 // workgroup.  The order of the list does not matter: a pixel's additions are ordered (one lineage) unless rays split.
@@ -1707,9 +1738,11 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
 
     for (;;) {
         // ---- refill: idle lanes take the next items of the wave's current chunk.  The block runs for the whole wave
-        // whenever it runs, so it waits until kRefillBatch lanes are idle -- or nothing else is in flight.
+        // whenever it runs, so it waits until kRefillBatch lanes are idle -- or nothing else is in flight.  IN_LANE a lane
+        // keeps its item for many samples and refills are rare: it refills at once (S16: 6.2 -> 5.3 ms; batches of 2, 4 and 8 equal).
         const unsigned long long idle = __ballot(!has_ray && !pending);
-        if (chunk < n_chunks && ((unsigned int)__builtin_popcountll(idle) >= kRefillBatch || (idle && !~idle))) {   // wave-uniform
+        constexpr unsigned int refill_batch = IN_LANE ? kRefillBatchInLane : kRefillBatch;
+        if (chunk < n_chunks && ((unsigned int)__builtin_popcountll(idle) >= refill_batch || (idle && !~idle))) {   // wave-uniform
             const unsigned int want = (unsigned int)__builtin_popcountll(idle), avail = chunk_len - taken;
             const unsigned int take = want < avail ? want : avail;
             const unsigned int rank = (unsigned int)__builtin_popcountll(idle & below);
