@@ -439,8 +439,11 @@ __device__ __forceinline__ void leave_sample_chunk(const RenderArgs &a, unsigned
 // ---------------------------------------------------------------------------------------
 enum { kCached = 0, kRegenerate = 1, kLockstep = 2, kCachedR1 = 3 };   // kCachedR1: round 1's loop [shade][shade][trace], without the frozen-shade shortcut (ablation)
 
+#ifndef PTMI_INLINE_WAVES
+#define PTMI_INLINE_WAVES 6
+#endif
 template <bool LDS_SCENE, int MODE, int TILE_W = 0>
-__global__ void __launch_bounds__(kRenderBlock, (MODE == kCached || MODE == kCachedR1) ? 6 : 4) render_inline_kernel(const RenderArgs a)
+__global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? PTMI_INLINE_WAVES : (MODE == kCachedR1 ? 6 : 4)) render_inline_kernel(const RenderArgs a)
 {
     __shared__ float pixel_const[(MODE == kCached || MODE == kCachedR1) ? 19 : 1][kRenderBlock];   // kCached: per-lane restart record (see below)
     extern __shared__ float4 lds_scene[];
@@ -1066,8 +1069,11 @@ __global__ void __launch_bounds__(kRenderBlock) render_inline_persistent_kernel(
 //     draw (Trace.hs:151, :190-191).
 // ---------------------------------------------------------------------------------------
 
+#ifndef PTMI_STREAMS_WAVES
+#define PTMI_STREAMS_WAVES 7     // 72 VGPRs (one pair spilled around the loop, not in it): C2 4.27 -> 4.17 ms
+#endif
 template <bool LDS_SCENE, int TILE_W = 0>
-__global__ void __launch_bounds__(kRenderBlock, 6) render_streams_kernel(const RenderArgs a)
+__global__ void __launch_bounds__(kRenderBlock, PTMI_STREAMS_WAVES) render_streams_kernel(const RenderArgs a)
 {
     __shared__ float pixel_const[13][kRenderBlock];         // per-lane restart record (rows 0..8) and the last hit's seed (9..12)
     extern __shared__ float4 lds_scene[];
