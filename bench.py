@@ -115,23 +115,26 @@ def load_traffic():
 
 
 def valu_accounting(kernel_ms):
-    """The kernel's real bound.  The instruction mix is a property of the code and the workload, not of the run:
-    profiles/r02_valu_roofline.json holds, for the C2 launch, the VALU wave-instructions per launch (PMC), the issue
-    cycles the measured per-opcode costs (tools/valu_rates.hip) assign to that mix, and the active-lane fraction.
-    frac = the cycles the issued instruction mix needs at one instruction stream per SIMD / the SIMD cycles this run's
-    launch took."""
+    """The kernel's real bound.  The instruction mix and the cycle count are properties of the code and the workload, not
+    of the run (two boxes of the pool at 2.28 and 2.36 GHz spent the same cycles): profiles/r02_valu_roofline.json holds,
+    for the C2 launch, the VALU wave-instructions per launch by category (PMC), the issue cycles their class costs assign
+    to that mix (a lower bound), the SIMD cycles the launch took (GRBM_GUI_ACTIVE) and the active-lane fraction.
+    frac = issue cycles needed / SIMD cycles taken, both from that profile; implied_clock_ghz = the shader clock this
+    run's launch time implies for the same cycle count -- outside 2.1-2.5 GHz the profile no longer describes the binary."""
     d = load_json("r02_valu_roofline.json")
     if not d:
         return None
     try:
-        clock_hz = float(d["clock_ghz"]) * 1e9
-        measured = d["n_simds"] * kernel_ms * 1e-3 * clock_hz
+        measured = float(d["measured_cycles_in_profile"])
+        implied = measured / (d["n_simds"] * kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
         return {"min_issue_cycles": round(d["min_issue_cycles"]), "measured_cycles": round(measured),
                 "frac": round(d["min_issue_cycles"] / measured, 4),
+                "frac_priced_with_measured_opcode_costs": round(d["priced_with_measured_rates"]["frac"], 4),
                 "active_lane_frac": round(d["active_lane_frac"], 4),
                 "valu_wave_instr_per_launch": round(d["valu_wave_instr_per_launch"]),
                 "avg_issue_cycles_per_instr": round(d["avg_issue_cycles_per_instr"], 3),
-                "clock_ghz": d["clock_ghz"], "source": "profiles/r02_valu_roofline.json"}
+                "implied_clock_ghz": round(implied, 3) if implied else None,
+                "profile_clock_ghz": d["clock_ghz"], "source": "profiles/r02_valu_roofline.json"}
     except Exception:
         return None
 
