@@ -440,12 +440,13 @@ __device__ __forceinline__ void leave_sample_chunk(const RenderArgs &a, unsigned
 enum { kCached = 0, kRegenerate = 1, kLockstep = 2, kCachedR1 = 3 };   // kCachedR1: round 1's loop [shade][shade][trace], without the frozen-shade shortcut (ablation)
 
 #ifndef PTMI_INLINE_WAVES
-#define PTMI_INLINE_WAVES 6
+#define PTMI_INLINE_WAVES 7      // 72 VGPRs (three registers spilled around the loop, not in it) and a 16-word LDS column: C2 3.10 -> 3.04 ms
 #endif
 template <bool LDS_SCENE, int MODE, int TILE_W = 0>
 __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? PTMI_INLINE_WAVES : (MODE == kCachedR1 ? 6 : 4)) render_inline_kernel(const RenderArgs a)
 {
-    __shared__ float pixel_const[(MODE == kCached || MODE == kCachedR1) ? 19 : 1][kRenderBlock];   // kCached: per-lane restart record (see below)
+    // kCached: per-lane restart record (see below), 16 words; round 1's loop (kCachedR1) keeps the first shade's result there too
+    __shared__ float pixel_const[MODE == kCached ? 16 : (MODE == kCachedR1 ? 19 : 1)][kRenderBlock];
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -523,7 +524,7 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? PTMI_INLINE_WA
                     bounce_axis(mb0, normal, primary, axis, hk);
                     const V3 first_result = mk(0.0f, 0.0f, 0.0f) + (scale_r(mk(ma0.x, ma0.y, ma0.z), ma0.w) * mk(1.0f, 1.0f, 1.0f));
                     put(12, axis.x); put(13, axis.y); put(14, axis.z); put(15, hk);
-                    put(16, first_result.x); put(17, first_result.y); put(18, first_result.z);
+                    if (MODE == kCachedR1) { put(16, first_result.x); put(17, first_result.y); put(18, first_result.z); }
                 }
                 int s = 0, it = 0, idx = idx0;
                 V3 d = primary;                                       // the ray that produced the hit / the next ray
@@ -2182,7 +2183,7 @@ hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t st
     if (variant == 17 || variant == 13) {
         RenderArgs b = a;
         const unsigned int per_copy = tile_grid(a, 8);
-        if (hipError_t e = choose_sample_chunks(b, per_copy, 6, stream)) return e;
+        if (hipError_t e = choose_sample_chunks(b, per_copy, PTMI_INLINE_WAVES, stream)) return e;
         const dim3 cgrid(per_copy * (unsigned int)b.spp_chunks);
         if (variant == 17) hipLaunchKernelGGL((render_inline_kernel<false, kCached, 8>), cgrid, block, 0, stream, b);
         else               hipLaunchKernelGGL((render_inline_kernel<true, kCached, 8>), cgrid, block, lds, stream, b);
@@ -2238,7 +2239,7 @@ hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t s
     if (tiles) {
         RenderArgs b = a;
         const unsigned int per_copy = tile_grid(a, 8);
-        if (hipError_t ce = choose_sample_chunks(b, per_copy, 6, stream)) return ce;
+        if (hipError_t ce = choose_sample_chunks(b, per_copy, PTMI_STREAMS_WAVES, stream)) return ce;
         const dim3 tgrid(per_copy * (unsigned int)b.spp_chunks);
         if (scalar_scene) hipLaunchKernelGGL((render_streams_kernel<false, 8>), tgrid, block, 0, stream, b);
         else              hipLaunchKernelGGL((render_streams_kernel<true, 8>), tgrid, block, lds, stream, b);
