@@ -20,7 +20,8 @@ import __graft_entry__ as graft  # noqa: E402
 WORKLOADS = {
     "c2": ("s16", "inline", "auto"), "streams": ("s16", "streams", "auto"), "s16_stream": ("s16", "streams", "stream"),
     "glass_tree": ("glass", "streams", "auto"), "glass_stream": ("glass", "streams", "stream"),
-    "s16_stream_b16": ("s16", "streams", "stream16"),
+    "s16_stream_b16": ("s16", "streams", "stream16"), "glass_stream_b8": ("glass", "streams", "stream8"),
+    "glass_stream_b32": ("glass", "streams", "stream32"),
 }
 
 
@@ -40,8 +41,8 @@ def one(lib, names, width=1920, height=1080, spp=64, repeats=7):
             c.set_scene(sp, pl)
             c.resize(width, height)
             c.set_option(pkg.binding.OPT_STREAMS_FORM, pkg.binding.FORM_STREAM if form.startswith("stream") else pkg.binding.FORM_AUTO)
-            if form == "stream16":
-                c.set_option(pkg.binding.OPT_STREAM_BATCH, 16)
+            if form.startswith("stream") and form[6:]:
+                c.set_option(pkg.binding.OPT_STREAM_BATCH, int(form[6:]))
             c.init_output(0x5EED1234)
             algorithm = pkg.INLINE if alg == "inline" else pkg.STREAMS
             t_end = time.perf_counter() + 0.25
