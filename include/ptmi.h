@@ -162,7 +162,7 @@ enum {
     PTMI_OPT_STREAMS_FORM = 4,
     /* Stream form only: how many samples of every pixel share one stream (one `awhile` loop).  0 (default) = automatic:
      * ONE for scenes without GLASS, which keeps a pixel's additions in sample order (bit-identical to the per-pixel
-     * kernels), up to 16 -- memory permitting -- with GLASS, where the order is undefined anyway.  A value > 1 without
+     * kernels), up to 32 -- memory permitting -- with GLASS, where the order is undefined anyway.  A value > 1 without
      * GLASS trades that order for fewer, longer launches: colours then agree to rounding only (Accelerate's `permute`
      * does not define the order either); the RNG planes stay exact. */
     PTMI_OPT_STREAM_BATCH = 5,

@@ -7,6 +7,7 @@ SRC=$ROOT/gpurun_out/prof_$TAG
 cp "$SRC/bench.json" "$ROOT/profiles/${TAG}_bench.json"
 cp "$SRC/bench_c4_one_gpu.json" "$ROOT/profiles/${TAG}_bench_c4_one_gpu.json"
 cp "$SRC/bench_c5_part.json" "$ROOT/profiles/${TAG}_bench_c5_part.json"
+[ -f "$SRC/bench_c5_part_stream.json" ] && cp "$SRC/bench_c5_part_stream.json" "$ROOT/profiles/${TAG}_bench_c5_part_stream.json"
 cp "$SRC"/stats_default/*/*_kernel_stats.csv "$ROOT/profiles/${TAG}_kernel_stats.csv"
 for w in c2 streams glass_tree glass_stream s16_stream; do
     python3 "$ROOT/tools/pmc_summary.py" "$ROOT/gpurun_out/pmc_$w" > "$ROOT/profiles/${TAG}_pmc_$w.json"

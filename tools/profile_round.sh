@@ -14,6 +14,7 @@ cd /tmp; export TMPDIR=/tmp; cd "$ROOT"
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.log"; echo "bench rc=$?"
 python3 bench.py --scaling strong --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c4_one_gpu.json" 2>> "$OUT/bench.log"; echo "bench C4 rc=$?"
 python3 bench.py --scene glass --algorithm streams --width 3840 --height 2160 --spp 512 --part-of 8 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c5_part.json" 2>> "$OUT/bench.log"; echo "bench C5 part rc=$?"
+python3 bench.py --scene glass --algorithm streams --streams-form stream --width 3840 --height 2160 --spp 512 --part-of 8 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c5_part_stream.json" 2>> "$OUT/bench.log"; echo "bench C5 part, stream form rc=$?"
 # the kernel trace of the driver's own command (default steps): its mean for render_inline_kernel must agree with roofline.kernel_ms
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_default" --output-format csv -- python3 bench.py --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats_default.log"; echo "stats rc=$?"
 
