@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? PTMI_INLINE_WA
             } else {
                 // The per-pixel constants a sample restarts from (primary hit record + primary direction, 10
                 // words) are read once per sample: they live in a lane-private LDS column instead of VGPRs,
-                // which is what lets the kernel fit 80 VGPRs = 6 waves per SIMD.
+                // which is what lets the kernel fit 72 VGPRs = 7 waves per SIMD (16 words: 28 waves fit the LDS of a CU).
                 float *mine = &pixel_const[0][threadIdx.x];
                 auto put = [&](int k, float v) { mine[k * kRenderBlock] = v; };
                 auto get = [&](int k) { return mine[k * kRenderBlock]; };
@@ -2149,7 +2149,7 @@ hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t st
     if (a.bounce_limit <= 0 || a.n_spp <= 0) variant = 2;   // degenerate counts: the plain loop handles them
     const bool big_scene = lds > kMaxSceneLds;               // every route reads such a scene through scalar loads, not LDS
     if (variant == 0) {
-        // static mapping wins at every size measured; a scene too big to keep 6 waves/SIMD in LDS is
+        // static mapping wins at every size measured; a scene so big that staging it per wave would cost more occupancy than scalar loads cost speed is
         // read through scalar loads; 8x8 tiles once the image is big enough for whole tiles to dominate
         const bool tiles = tiles_pay(a);
         variant = lds <= kMaxSceneLds ? (tiles ? 13 : 4) : (tiles ? 17 : 5);
