@@ -446,7 +446,7 @@ template <bool LDS_SCENE, int MODE, int TILE_W = 0>
 __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? PTMI_INLINE_WAVES : (MODE == kCachedR1 ? 6 : 4)) render_inline_kernel(const RenderArgs a)
 {
     // kCached: per-lane restart record (see below), 16 words; round 1's loop (kCachedR1) keeps the first shade's result there too
-    __shared__ float pixel_const[MODE == kCached ? 16 : (MODE == kCachedR1 ? 19 : 1)][kRenderBlock];
+    __shared__ float pixel_const[MODE == kCached ? 10 : (MODE == kCachedR1 ? 19 : 1)][kRenderBlock];
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -491,8 +491,128 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? PTMI_INLINE_WA
         if (limit <= 0) {
             // iterate 0: every sample returns (0, seed); new + old
             if (n_spp > 0) acc = mk(0.0f, 0.0f, 0.0f) + acc;
-        } else if (MODE == kCached || MODE == kCachedR1) {
-            constexpr bool kFinish = MODE == kCached;
+        } else if (MODE == kCached) {
+            // primaryRays has no sub-pixel jitter (Trace.hs:244-262): every sample of a pixel shoots the same primary ray, so
+            // its checkHit + hit are evaluated ONCE per pixel and every sample starts from that record.
+            // Loop shape: [finish frozen shades][restart][shade][trace].  A lane comes round with a hit to shade (`pending`) or
+            // with its sample over (`over`: the trace missed, or the last shade left a throughput that the next prepareRay
+            // freezes).  The shades whose outcome is CERTAIN to be frozen (the iteration limit, or surely_frozen_after) are
+            // finished first -- emittance + three draws, no sin/cos, no rotation -- and those lanes are `over` too; then ONE
+            // block restarts every `over` lane on its pixel's next sample, from the cached primary hit, with the rotation axis
+            // and half-angle scale that every first shade of the pixel uses; then one full shade and one trace for all.  A
+            // sample whose path ends by a certain freeze -- 64 % of them on C2 -- costs k-1 full shades and k-1 traces.
+            const HitSel h0 = check_hit(S, ns, np, origin, primary);
+            if (!h0.just) {
+                if (n_spp > 0) acc = mk(0.0f, 0.0f, 0.0f) + acc;     // every sample: result 0, seed untouched
+            } else {
+                // What a sample restarts from lives in a lane-private LDS column (10 words), not in VGPRs: the position of the
+                // primary hit, the axis and half-angle scale of its bounce, and the pixel's accumulator (touched once per sample).
+                float *mine = &pixel_const[0][threadIdx.x];
+                auto put = [&](int k, float v) { mine[k * kRenderBlock] = v; };
+                auto get = [&](int k) { return mine[k * kRenderBlock]; };
+                V3 pos, normal;                                       // pos: the hit to shade, then the next ray's origin
+                hit_record(S, ns, h0.idx, origin, primary, h0.t, pos, normal);
+                const int idx0 = h0.idx;
+                {
+                    const float4 mb0 = M[2 * idx0 + 1];
+                    V3 axis0; float hk0;
+                    bounce_axis(mb0, normal, primary, axis0, hk0);
+                    put(0, pos.x); put(1, pos.y); put(2, pos.z);
+                    put(3, axis0.x); put(4, axis0.y); put(5, axis0.z); put(6, hk0);
+                    put(7, acc.x); put(8, acc.y); put(9, acc.z);
+                }
+                int s = -1, it = 0, idx = idx0;                       // s: the sample being rendered (the first restart makes it 0)
+                V3 d = primary;
+                V3 throughput = mk(1.0f, 1.0f, 1.0f), result = mk(0.0f, 0.0f, 0.0f);
+                bool pending = false, has_ray = false, over = n_spp > 0;
+#ifdef PTMI_PHASE_STATS
+                unsigned int st_iter = 0, st_a = 0, st_b = 0, st_c = 0, st_f = 0;   // this lane's participation per round
+                unsigned long long cyc_a = 0, cyc_b = 0, cyc_c = 0;
+#endif
+                while (pending || over) {
+                    ++trips;
+#ifdef PTMI_PHASE_STATS
+                    ++st_iter;
+                    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+                    if (pending || over) ++st_a;
+#endif
+                    float4 mb = M[2 * idx + 1];
+                    V3 axis = mk(0.0f, 0.0f, 0.0f); float hk = 0.0f;
+                    if (pending) {
+                        bounce_axis(mb, normal, d, axis, hk);
+                        const float4 ma = M[2 * idx];
+                        if (it + 1 >= limit || surely_frozen_after(ma, mb, axis, throughput)) {
+                            finish_frozen(ma, throughput, result, seed);
+                            ++live;
+#ifdef PTMI_PHASE_STATS
+                            ++st_f;
+#endif
+                            pending = false; over = true;
+                        }
+                    }
+                    if (over) {                                        // next sample of this pixel
+                        // \(new, seed') (old, _) -> (new + old, seed') -- once a sample has been rendered (the first time round
+                        // the lane only starts sample 0)
+                        if (s >= 0) { put(7, result.x + get(7)); put(8, result.y + get(8)); put(9, result.z + get(9)); }
+                        ++s; it = 0;
+                        throughput = mk(1.0f, 1.0f, 1.0f); result = mk(0.0f, 0.0f, 0.0f);
+                        pos = mk(get(0), get(1), get(2)); idx = idx0;
+                        mb = M[2 * idx0 + 1];
+                        axis = mk(get(3), get(4), get(5)); hk = get(6);
+                        over = false; pending = s < n_spp;
+                    }
+                    if (pending) {
+                        V3 next; float brdf;
+                        next_about_axis(mb, axis, hk, seed, next, brdf);
+                        apply_bounce(M, idx, pos, next, brdf, pos, d, throughput, result);
+                        ++it; ++live;
+                        pending = false;
+                        // the next prepareRay would freeze the path (Trace.hs:364-365)
+                        if (it >= limit || near_zero(throughput)) over = true;
+                        else has_ray = true;
+                    }
+#ifdef PTMI_PHASE_STATS
+                    { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); cyc_a += t_now - t_prev; t_prev = t_now; }
+                    if (has_ray) ++st_c;
+#endif
+                    if (has_ray) {
+#ifdef PTMI_SPHERE_STATS
+                        const HitSel h = check_hit(S, ns, np, pos, d, a.work_counter);
+#else
+                        const HitSel h = check_hit(S, ns, np, pos, d);
+#endif
+                        has_ray = false;
+                        if (h.just) {
+                            hit_record(S, ns, h.idx, pos, d, h.t, pos, normal);
+                            idx = h.idx;
+                            pending = true;
+                        } else {
+                            over = true;
+                        }
+                    }
+#ifdef PTMI_PHASE_STATS
+                    cyc_c += __builtin_amdgcn_s_memtime() - t_prev;
+#endif
+                }
+                acc = mk(get(7), get(8), get(9));
+#ifdef PTMI_PHASE_STATS
+                {
+                    const unsigned long long m = __ballot(1);
+                    unsigned int mx = st_iter;
+                    for (int off = 32; off > 0; off >>= 1) { const unsigned int o2 = __shfl_xor(mx, off, 64); mx = o2 > mx ? o2 : mx; }
+                    atomicAdd(a.work_counter + 1, st_iter); atomicAdd(a.work_counter + 2, st_a);
+                    atomicAdd(a.work_counter + 3, st_b); atomicAdd(a.work_counter + 4, st_c); atomicAdd(a.work_counter + 6, st_f);
+                    if ((threadIdx.x & 63) == (int)__builtin_ctzll(m)) {
+                        atomicAdd(a.work_counter + 5, mx * 64u);
+                        atomicAdd(reinterpret_cast<unsigned long long *>(a.work_counter + 8), cyc_a);
+                        atomicAdd(reinterpret_cast<unsigned long long *>(a.work_counter + 10), cyc_b);
+                        atomicAdd(reinterpret_cast<unsigned long long *>(a.work_counter + 12), cyc_c);
+                    }
+                }
+#endif
+            }
+        } else if (MODE == kCachedR1) {
+            constexpr bool kFinish = false;
             // primaryRays has no sub-pixel jitter (Trace.hs:244-262): every sample of a pixel shoots the
             // same primary ray, so its checkHit + hit are evaluated ONCE per pixel and every sample starts
             // from that record.  A sample then costs k shades and k-1 traces (k = its live bounces).
