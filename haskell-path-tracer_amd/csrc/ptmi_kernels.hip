@@ -1196,7 +1196,7 @@ __global__ void __launch_bounds__(kRenderBlock) render_inline_persistent_kernel(
 template <bool LDS_SCENE, int TILE_W = 0>
 __global__ void __launch_bounds__(kRenderBlock, PTMI_STREAMS_WAVES) render_streams_kernel(const RenderArgs a)
 {
-    __shared__ float pixel_const[13][kRenderBlock];         // per-lane restart record (rows 0..8) and the last hit's seed (9..12)
+    __shared__ float pixel_const[11][kRenderBlock];         // per-lane restart record (rows 0..6) and the last hit's seed (7..10)
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -1235,56 +1235,74 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_STREAMS_WAVES) render_strea
             auto get = [&](int k) { return mine[k * kRenderBlock]; };
             V3 pos, normal;                                       // pos: the hit to shade, then the next ray's origin
             hit_record(S, ns, h0.idx, origin, primary, h0.t, pos, normal);
-            put(0, pos.x); put(1, pos.y); put(2, pos.z);
-            put(3, normal.x); put(4, normal.y); put(5, normal.z);
-            put(6, primary.x); put(7, primary.y); put(8, primary.z);
             const int idx0 = h0.idx;
-            // PTMI_SEED_FROM_RESULT (combine new old): every hit leaves the seed its ray carried in rows 9..12 of the lane's
+            {   // what every sample of this pixel starts from: the primary hit and the axis / half-angle scale of its bounce
+                const float4 mb0 = M[2 * idx0 + 1];
+                V3 axis0; float hk0;
+                bounce_axis(mb0, normal, primary, axis0, hk0);
+                put(0, pos.x); put(1, pos.y); put(2, pos.z);
+                put(3, axis0.x); put(4, axis0.y); put(5, axis0.z); put(6, hk0);
+            }
+            // PTMI_SEED_FROM_RESULT (combine new old): every hit leaves the seed its ray carried in rows 7..10 of the lane's
             // LDS column (four ds_writes per hit instead of four more registers); the sample's last one survives.
             auto note_hit_seed = [&](const Sfc32 &sd) {
-                if (a.seed_from_result) { put(9, u2f(sd.a)); put(10, u2f(sd.b)); put(11, u2f(sd.c)); put(12, u2f(sd.counter)); }
+                if (a.seed_from_result) { put(7, u2f(sd.a)); put(8, u2f(sd.b)); put(9, u2f(sd.c)); put(10, u2f(sd.counter)); }
             };
-            int s = 0, idx = idx0;
+            int s = -1, idx = idx0;                               // s: the sample being rendered (the first pass through the block below makes it 0)
             unsigned int steps = 0;
             V3 d = primary;
             V3 throughput = mk(1.0f, 1.0f, 1.0f);
             Sfc32 seed = pixel_seed;
-            bool pending = n_spp > 0, has_ray = false;
-            auto end_sample = [&]() {
-                if (a.seed_from_result && steps > 0u) {           // combine new old: the seed the sample's last hit carried
-                    pixel_seed.a = f2u(get(9)); pixel_seed.b = f2u(get(10)); pixel_seed.c = f2u(get(11)); pixel_seed.counter = f2u(get(12));
-                }
-                (void)random_float(pixel_seed);                   // updateSeed
-                seed = pixel_seed;
-                ++s; longest = steps > longest ? steps : longest; steps = 0;
-                throughput = mk(1.0f, 1.0f, 1.0f);
-                pos = mk(get(0), get(1), get(2)); normal = mk(get(3), get(4), get(5));
-                d = mk(get(6), get(7), get(8)); idx = idx0;
-                pending = s < n_spp;
-            };
-            while (pending) {
+            bool pending = false, has_ray = false, over = n_spp > 0;
+            // Loop shape [finish dead rays][next sample][shade][trace]: a lane comes round with a hit to shade (`pending`) or with
+            // its sample over (`over`: the trace missed, or the cap cut the child).  ONE block per trip ends the samples that
+            // are over and starts the pixel's next one from the cached primary hit, so that those lanes take part in this
+            // trip's full shade.
+            while (pending || over) {
                 ++trips;
-                // shade round.  A ray whose throughput is already near zero dies at this hit (numNewRays, Trace.hs:329-331):
-                // the hit still adds its emittance (computeResult runs for every intersection) and nothing else of it
-                // survives -- no child, and the ray's seed is discarded -- so such lanes skip the three sin/cos pairs and the
-                // rotation, end their sample and take part in THIS round's full shade with the pixel's next sample.
-                if (pending && !has_ray) {
+                float4 mb = M[2 * idx + 1];
+                V3 axis = mk(0.0f, 0.0f, 0.0f); float hk = 0.0f;
+                if (pending) {
+                    // A ray whose throughput is already near zero dies at this hit (numNewRays, Trace.hs:329-331): the hit still
+                    // adds its emittance (computeResult runs for every intersection) and nothing else of it survives -- no
+                    // child, and the ray's seed is discarded -- so such lanes skip the three sin/cos pairs and the rotation.
                     if (near_zero(throughput)) {
                         const float4 ma = M[2 * idx];
                         acc = acc + (scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);
                         note_hit_seed(seed);
                         ++steps;
-                        end_sample();
+                        pending = false; over = true;
+                    } else {
+                        bounce_axis(mb, normal, d, axis, hk);
                     }
-                    if (pending) {                                 // alive: a fresh sample starts with throughput 1
-                        const bool capped = steps + 1u >= step_cap;
-                        note_hit_seed(seed);
-                        // results: colour += emittance * throughput for EVERY hit; then the new ray
-                        shade(M, idx, pos, normal, pos, d, throughput, acc, seed);
-                        ++steps; ++live;                           // the child exists even if the cap then cuts it
-                        if (capped) { ++cut; end_sample(); }
-                        else { pending = false; has_ray = true; }
+                }
+                if (over) {
+                    if (s >= 0) {                                  // a sample has been rendered
+                        if (a.seed_from_result && steps > 0u) {    // combine new old: the seed the sample's last hit carried
+                            pixel_seed.a = f2u(get(7)); pixel_seed.b = f2u(get(8)); pixel_seed.c = f2u(get(9)); pixel_seed.counter = f2u(get(10));
+                        }
+                        (void)random_float(pixel_seed);            // updateSeed
+                        longest = steps > longest ? steps : longest;
                     }
+                    seed = pixel_seed;
+                    ++s; steps = 0;
+                    throughput = mk(1.0f, 1.0f, 1.0f);
+                    pos = mk(get(0), get(1), get(2)); idx = idx0;
+                    mb = M[2 * idx0 + 1];
+                    axis = mk(get(3), get(4), get(5)); hk = get(6);
+                    over = false; pending = s < n_spp;
+                }
+                if (pending) {                                     // alive (a fresh sample starts with throughput 1)
+                    const bool capped = steps + 1u >= step_cap;
+                    note_hit_seed(seed);
+                    // results: colour += emittance * throughput for EVERY hit; then the new ray (shade, with the axis in hand)
+                    V3 next; float brdf;
+                    next_about_axis(mb, axis, hk, seed, next, brdf);
+                    apply_bounce(M, idx, pos, next, brdf, pos, d, throughput, acc);
+                    ++steps; ++live;                               // the child exists even if the cap then cuts it
+                    pending = false;
+                    if (capped) { ++cut; over = true; }
+                    else has_ray = true;
                 }
                 if (has_ray) {
                     const HitSel h = check_hit(S, ns, np, pos, d);
@@ -1294,7 +1312,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_STREAMS_WAVES) render_strea
                         idx = h.idx;
                         pending = true;
                     } else {
-                        end_sample();
+                        over = true;
                     }
                 }
             }
