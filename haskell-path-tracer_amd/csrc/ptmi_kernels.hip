@@ -1544,7 +1544,8 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
 #ifdef PTMI_TREE_STATS
             unsigned int st_dead = 0, st_shade = 0, st_trace = 0;      // this lane's participation per round (diagnostic build)
 #endif
-            while (pending || has_ray) {
+            bool ended = false;                                   // the lane's lineage is over: its next piece of work is fetched at the top of the trip
+            while (pending || has_ray || ended) {
                 ++trips;
 #ifdef PTMI_TREE_STATS
                 if (pending && !has_ray && near_zero(throughput)) ++st_dead;
@@ -1552,15 +1553,16 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                 // shade round.  A ray whose throughput is already near zero dies at this hit (numNewRays): the hit adds its
                 // emittance and nothing else of it survives, so such lanes skip the expensive half and go on with their most
                 // recent waiting child, their sample's next start hit or the pixel's next sample -- in the latter cases they
-                // take part in this round's full shade.  (lineage_ended is a large block -- next start hit, its normal, its
-                // seed: it is expanded at two places only, here and at the end of the trip.)
+                // take part in this round's full shade.  A lineage that ended in the previous trip (miss, cap) fetches its next
+                // piece of work here too: lineage_ended is a large block -- next start hit, its normal, its seed -- and is expanded
+                // once.
                 if (pending && !has_ray && near_zero(throughput)) {
                     const float4 ma = M[2 * idx];
                     acc = acc + (scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);   // computeResult (Trace.hs:318-323)
                     ++steps;
-                    lineage_ended();
+                    pending = false; ended = true;
                 }
-                bool ended = false;
+                if (ended) { lineage_ended(); ended = false; }     // the one expansion of that block (it is large)
                 // (The start hit that the block above may just have loaded can itself belong to a dead ray -- a reflection of
                 // weight ~0: it must not be shaded; it waits for the next trip's dead-ray block.  A test inside next_start
                 // instead cost 12 %.)
@@ -1614,7 +1616,6 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                         ended = true;
                     }
                 }
-                if (ended) lineage_ended();
             }
 #ifdef PTMI_TREE_STATS
             // [1] lane-trips needed, [2] dead-ray finishes, [3] shades, [4] traces (lane participations)
