@@ -1882,7 +1882,9 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
         if (c.z != 0.0f) atomicAdd(a.planes.b + pixel, c.z);
     };
 
+    bool ended = false;                                       // the lane's lineage is over: lineage_ended runs at the top of the next trip
     for (;;) {
+        if (ended) { pending = lineage_ended(); ended = false; }   // the one expansion of that block (IN_LANE: the lane's next sample)
         // ---- refill: idle lanes take the next items of the wave's current chunk.  The block runs for the whole wave
         // whenever it runs, so it waits until kRefillBatch lanes are idle -- or nothing else is in flight.  IN_LANE a lane
         // keeps its item for many samples and refills are rare: it refills at once (S16: 6.2 -> 5.3 ms; batches of 2, 4 and 8 equal).
@@ -1927,7 +1929,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
                         } else {
                             ++hits;
                             add_colour(term);
-                            pending = lineage_ended();
+                            pending = false; ended = true;
                         }
                     }
                 } else {
@@ -1944,7 +1946,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
             taken += take;
             if (taken >= chunk_len) { chunk = next_chunk(chunk); taken = 0; open_chunk(); }
         }
-        if (!__any(has_ray || pending)) {
+        if (!__any(has_ray || pending || ended)) {
             if (chunk >= n_chunks) break;
             continue;                                         // a chunk of holes: look at the next one
         }
@@ -1995,12 +1997,12 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
         cut_w += (unsigned int)__builtin_popcountll(__ballot(has_ray && depth >= step_cap));
         if (has_ray) {
             if (depth >= step_cap) {                          // the safety cap (the reference has none): the ray is in the stream, never traced
-                has_ray = false; pending = lineage_ended();
+                has_ray = false; ended = true;
             } else {
                 deepest = depth + 1u > deepest ? depth + 1u : deepest;
                 const HitSel h = check_hit(S, ns, np, o, d);
                 if (!h.just) {
-                    has_ray = false; pending = lineage_ended();
+                    has_ray = false; ended = true;
                 } else {
                     hit_record(S, ns, h.idx, o, d, h.t, o, normal);
                     idx = h.idx;
@@ -2008,7 +2010,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
                         const float4 ma = M[2 * idx];
                         if (!IN_LANE) ++hits;
                         add_colour(scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);
-                        has_ray = false; pending = lineage_ended();
+                        has_ray = false; ended = true;
                     } else {
                         has_ray = false; pending = true;
                     }
