@@ -17,34 +17,26 @@ def resources(tmp_path_factory):
     return mod.collect(out_dir=str(tmp_path_factory.mktemp("isa")))
 
 
-# kernel -> (VGPRs for its waves per SIMD, scratch bytes, static LDS bytes)
+# kernel -> (VGPRs for its waves per SIMD, scratch bytes, static LDS bytes, scratch loads, scratch stores).  The few scratch
+# instructions allowed are spills AROUND a render loop and around the rare call of the literal fold (check_hit_exact).
 BUDGETS = {
-    "render_inline_kernel<true, 0, 8>": (72, 16, 4096),          # 7 waves/SIMD; three registers spilled around the loop
-    "render_inline_kernel<false, 0, 8>": (72, 32, 4096),         # scene through scalar loads (big scenes): one more pair around the loop
-    "render_streams_kernel<true, 8>": (72, 16, 3328),            # 7 waves/SIMD
-    "render_streams_kernel<false, 8>": (72, 16, 3328),
-    "render_streams_tree_kernel<true, 8>": (96, 16 * 14 * 4 + 16, 5632),   # 5 waves/SIMD; the lane stack IS scratch: 16 entries x 14 words
-    "streams_level_kernel<true, true, true>": (80, 0, 4608),     # 6 waves/SIMD, nothing in scratch
-    "streams_level_kernel<true, true, false>": (80, 0, 0),
-    "streams_level_kernel<true, false, false>": (80, 0, 0),
+    "render_inline_kernel<true, 0, 8>": (72, 32, 2560, 4, 4),          # 7 waves/SIMD
+    "render_inline_kernel<false, 0, 8>": (72, 32, 2560, 6, 6),         # scene through scalar loads (big scenes)
+    "render_streams_kernel<true, 8>": (72, 32, 2816, 3, 3),            # 7 waves/SIMD
+    "render_streams_kernel<false, 8>": (72, 32, 2816, 3, 3),
+    "render_streams_tree_kernel<true, 8>": (96, 16 * 14 * 4 + 16, 5632, 6, 6),   # 5 waves/SIMD; the lane stack IS scratch: 16 entries x 14 words
+    "streams_level_kernel<true, true, true>": (80, 0, 4608, 0, 0),     # 6 waves/SIMD, nothing in scratch
+    "streams_level_kernel<true, true, false>": (80, 0, 0, 0, 0),
+    "streams_level_kernel<true, false, false>": (80, 0, 0, 0, 0),
 }
 
 
 @pytest.mark.parametrize("kernel", sorted(BUDGETS))
 def test_render_kernel_stays_within_its_budget(resources, kernel):
     assert kernel in resources, sorted(resources)
-    vgpr, scratch, lds = BUDGETS[kernel]
+    vgpr, scratch, lds, loads, stores = BUDGETS[kernel]
     r = resources[kernel]
     assert r["vgpr"] <= vgpr, r
     assert r["scratch"] <= scratch, r
     assert r["lds"] <= lds, r
-
-
-def test_no_render_loop_touches_scratch_except_the_lane_stack(resources):
-    """Spills around a loop show up as a handful of scratch instructions; the per-pixel tree walk's stack as 8 loads / 4
-    stores.  Anything more means registers or flags went to memory inside a loop."""
-    for name, r in resources.items():
-        loads, stores = (8 + 2, 4 + 2) if "tree" in name else (4, 4)
-        if name.startswith(("render_inline_kernel<true, 0", "render_inline_kernel<false, 0", "render_streams_kernel",
-                            "render_streams_tree_kernel", "streams_level_kernel")):
-            assert r["scratch_loads"] <= loads and r["scratch_stores"] <= stores, (name, r)
+    assert r["scratch_loads"] <= loads and r["scratch_stores"] <= stores, r
