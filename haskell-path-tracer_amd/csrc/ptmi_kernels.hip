@@ -1665,9 +1665,11 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
 //     wave sees the whole image, no hand-out atomics);
 //   * a lane follows its ray's LINEAGE: a Matte / Glossy hit spawns one child, which simply is the lane's next ray; at
 //     a GLASS hit (two children) the reflection stays in the lane and only the refraction goes to the output stream;
-//   * loop shape [refill][shade][trace].  A hit found by the trace round whose ray arrived with near-zero throughput
-//     (numNewRays = 0, Trace.hs:329-331) adds its emittance right there and ends the lineage, so every lane that enters
-//     the shade round is alive, and a lineage that ends that way costs one shade and one trace per trip;
+//   * loop shape [finish dead hits][next piece of work][refill][shade][trace].  A hit whose ray arrived with near-zero
+//     throughput (numNewRays = 0, Trace.hs:329-331) adds its emittance in the trip's first block and ends the lineage, so
+//     every lane that enters the shade round is alive, and a lineage that ends that way costs one shade and one trace per
+//     trip; every "lineage over" site only sets a flag and the block that fetches the lane's next piece of work (IN_LANE:
+//     its next sample) is expanded once;
 //   * REFILL: when a lineage ends the lane takes the next unprocessed item of the wave's current chunk -- ballot of the
 //     idle lanes + popcount prefix for the rank -- so the rounds run dense although lineages differ in length (round 1's
 //     step kernel idled until the slowest of 64 lineages had ended);
@@ -1884,6 +1886,14 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
 
     bool ended = false;                                       // the lane's lineage is over: lineage_ended runs at the top of the next trip
     for (;;) {
+        // ---- a hit whose ray arrived with near-zero throughput (numNewRays = 0, Trace.hs:329-331) adds its emittance and nothing
+        // else of it survives: the lineage ends here, before the block that fetches the lane's next piece of work
+        if (pending && near_zero(throughput)) {
+            const float4 ma = M[2 * idx];
+            if (!IN_LANE) ++hits;
+            add_colour(scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);
+            pending = false; ended = true;
+        }
         if (ended) { pending = lineage_ended(); ended = false; }   // the one expansion of that block (IN_LANE: the lane's next sample)
         // ---- refill: idle lanes take the next items of the wave's current chunk.  The block runs for the whole wave
         // whenever it runs, so it waits until kRefillBatch lanes are idle -- or nothing else is in flight.  IN_LANE a lane
@@ -1918,20 +1928,8 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
                         lane_hit[10][threadIdx.x] = throughput.x; lane_hit[11][threadIdx.x] = throughput.y; lane_hit[12][threadIdx.x] = throughput.z;
                         lane_hit[13][threadIdx.x] = u2f(meta);
                     }
-                    depth = meta & 0xffu; hits = 0; pending = true;
+                    depth = meta & 0xffu; hits = 0; pending = true;   // (a start hit of a dead ray -- a reflection of weight ~0 -- waits for the next trip's first block)
                     deepest = deepest > 1u ? deepest : 1u;    // the primary ray's traceStep
-                    if (near_zero(throughput)) {               // a start hit of a dead ray (a reflection of weight ~0): its emittance, nothing else
-                        const float4 ma = M[2 * idx];
-                        const V3 term = scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput;
-                        if (IN_LANE) {                         // ... in every one of the lane's samples: the hit is the same
-                            for (int q = 0; q < lv.samples_in_lane; ++q) add_colour(term);
-                            pending = false;
-                        } else {
-                            ++hits;
-                            add_colour(term);
-                            pending = false; ended = true;
-                        }
-                    }
                 } else {
                     pixel = lv.in.pixel()[i];
                     if (pixel != kHole) {
@@ -1951,11 +1949,12 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
             continue;                                         // a chunk of holes: look at the next one
         }
 
-        // ---- shade round: every pending hit belongs to a ray that is alive (dead ones were finished after their trace)
+        // ---- shade round, for the hits of rays that are alive (a dead one just fetched waits for the next trip's first block)
         bool emits = false;
         V3 ko = o, kd = o, kt = o; Sfc32 ks = seed;
-        live_w += (unsigned int)__builtin_popcountll(__ballot(pending));      // one child per shaded hit ...
-        if (pending) {
+        const bool alive = pending && !near_zero(throughput);
+        live_w += (unsigned int)__builtin_popcountll(__ballot(alive));        // one child per shaded hit ...
+        if (alive) {
             const float4 ma = M[2 * idx], mb = M[2 * idx + 1];
             V3 contribution;
             if (!IN_LANE) ++hits;
@@ -2006,14 +2005,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
                 } else {
                     hit_record(S, ns, h.idx, o, d, h.t, o, normal);
                     idx = h.idx;
-                    if (near_zero(throughput)) {              // numNewRays = 0: the hit adds its emittance, nothing else of it survives
-                        const float4 ma = M[2 * idx];
-                        if (!IN_LANE) ++hits;
-                        add_colour(scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);
-                        has_ray = false; ended = true;
-                    } else {
-                        has_ray = false; pending = true;
-                    }
+                    has_ray = false; pending = true;
                 }
             }
         }
