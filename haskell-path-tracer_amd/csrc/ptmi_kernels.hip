@@ -11,6 +11,9 @@
 //   * the primitive list is staged into LDS once per workgroup and read as wave-wide
 //     broadcasts (every lane walks the same primitive at the same time);
 //   * a shade whose outcome the next prepareRay is certain to freeze only adds its emittance and draws (surely_frozen_after);
+//   * every render loop is written so that each LARGE block -- "start the pixel's next sample", "fetch the lineage's next
+//     piece of work" -- is expanded once per trip: the sites that end a sample or a lineage only set a per-lane flag, and
+//     one block at the top of the next trip acts on it.  (Three inlined copies of such a block cost 3-9 % per kernel.)
 //   * no MFMA: the work is scalar-per-lane f32/f64 VALU with divergent control flow.
 // Kernels in this file: render_inline_kernel (+ pooled / persistent ablations), render_streams_kernel (Streams, one chain per
 // pixel), render_streams_tree_kernel (Streams with ray splitting, one tree per pixel), streams_primary_kernel +
