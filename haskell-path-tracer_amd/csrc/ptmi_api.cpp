@@ -247,11 +247,6 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
         if (batch_max > n_spp) batch_max = n_spp;
     }
     if (a.seed_from_result) batch_max = 1;               // a sample starts from the seed the previous sample's last hit left
-    // Without ray splitting (and with the default seed rule) a lane renders up to 64 successive samples of its pixel before it
-    // refills: one adder per pixel, in sample order, and launches long enough to pay for their start and drain.  With GLASS a
-    // lane of level 0 renders the samples of the batch from its start hit one after the other (their refractions share the
-    // output stream): the start hits are read once per batch and a lane whose lineage ends goes on at once.
-    const int in_lane_max = c->has_glass ? batch_max : ((!a.seed_from_result && c->opt_batch == 0) ? 64 : 1);
     if (n * cap_factor > 0xfffffff0ull) return fail(c, PTMI_ELIMIT, "image too large for the stream form of Streams");
     static int max_grid = 0;                                 // persistent waves: 6 per SIMD
     if (!max_grid) {
@@ -260,13 +255,27 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
         max_grid = (cus > 0 ? cus : 256) * 4 * 6;
     }
     const unsigned int first_block = streams_first_block();
-    size_t capacity = n * (size_t)batch_max * cap_factor;
-    if (capacity < (size_t)max_grid * first_block + 256) capacity = (size_t)max_grid * first_block + 256;   // every wave's static block fits
-    if (capacity != c->queue_capacity) {
+    // The two child streams.  A block that is already large enough is kept (its capacity is the planes' stride); when the
+    // device cannot give what the automatic batch size asks for, fewer samples share a stream.
+    for (;;) {
+        size_t need = n * (size_t)batch_max * cap_factor;
+        if (need < (size_t)max_grid * first_block + 256) need = (size_t)max_grid * first_block + 256;   // every wave's static block fits
+        if (need <= c->queue_capacity) break;
         if (c->queue_block) { PTMI_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->queue_block); c->queue_block = nullptr; c->queue_capacity = 0; }
-        PTMI_HIP(c, hipMalloc(&c->queue_block, 2 * (size_t)kRayQueueWords * capacity * 4));
-        c->queue_capacity = capacity;
+        const hipError_t e = hipMalloc(&c->queue_block, 2 * (size_t)kRayQueueWords * need * 4);
+        if (e == hipSuccess) { c->queue_capacity = need; break; }
+        (void)hipGetLastError();
+        c->queue_block = nullptr;
+        if (e != hipErrorOutOfMemory || batch_max <= 1 || c->opt_batch > 0)      // an explicit PTMI_OPT_STREAM_BATCH is honoured or refused
+            return fail(c, e == hipErrorOutOfMemory ? PTMI_ENOMEM : PTMI_EHIP, std::string("hipMalloc of the ray streams: ") + hipGetErrorString(e));
+        batch_max = (batch_max + 1) / 2;
     }
+    const size_t capacity = c->queue_capacity;
+    // Without ray splitting (and with the default seed rule) a lane renders up to 64 successive samples of its pixel before it
+    // refills: one adder per pixel, in sample order, and launches long enough to pay for their start and drain.  With GLASS a
+    // lane of level 0 renders the samples of the batch from its start hit one after the other (their refractions share the
+    // output stream): the start hits are read once per batch and a lane whose lineage ends goes on at once.
+    const int in_lane_max = c->has_glass ? batch_max : ((!a.seed_from_result && c->opt_batch == 0) ? 64 : 1);
     if (!c->d_qcount) PTMI_HIP(c, hipMalloc(&c->d_qcount, (size_t)kLvWords * sizeof(unsigned int)));
     const size_t hit_slots = 2 * n;                          // a glass primary hit contributes up to two start hits
     if (hit_slots > 0xfffffff0ull) return fail(c, PTMI_ELIMIT, "image too large for the stream form of Streams");
