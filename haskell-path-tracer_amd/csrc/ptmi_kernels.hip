@@ -1888,7 +1888,14 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
     };
 
     bool ended = false;                                       // the lane's lineage is over: lineage_ended runs at the top of the next trip
+#ifdef PTMI_LEVEL_STATS
+    unsigned int st_trips = 0, st_dead = 0, st_next = 0, st_shade = 0, st_glass = 0, st_trace = 0, st_refills = 0;   // wave-uniform (diagnostic build)
+#endif
     for (;;) {
+#ifdef PTMI_LEVEL_STATS
+        ++st_trips;
+        st_dead += (unsigned int)__builtin_popcountll(__ballot(pending && near_zero(throughput)));
+#endif
         // ---- a hit whose ray arrived with near-zero throughput (numNewRays = 0, Trace.hs:329-331) adds its emittance and nothing
         // else of it survives: the lineage ends here, before the block that fetches the lane's next piece of work
         if (pending && near_zero(throughput)) {
@@ -1897,6 +1904,9 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
             add_colour(scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);
             pending = false; ended = true;
         }
+#ifdef PTMI_LEVEL_STATS
+        st_next += (unsigned int)__builtin_popcountll(__ballot(ended || (pending && near_zero(throughput))));
+#endif
         if (ended) { pending = lineage_ended(); ended = false; }   // the one expansion of that block (IN_LANE: the lane's next sample)
         // ---- refill: idle lanes take the next items of the wave's current chunk.  The block runs for the whole wave
         // whenever it runs, so it waits until kRefillBatch lanes are idle -- or nothing else is in flight.  IN_LANE a lane
@@ -1904,6 +1914,9 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
         const unsigned long long idle = __ballot(!has_ray && !pending);
         constexpr unsigned int refill_batch = IN_LANE ? kRefillBatchInLane : kRefillBatch;
         if (chunk < n_chunks && ((unsigned int)__builtin_popcountll(idle) >= refill_batch || (idle && !~idle))) {   // wave-uniform
+#ifdef PTMI_LEVEL_STATS
+            ++st_refills;
+#endif
             const unsigned int want = (unsigned int)__builtin_popcountll(idle), avail = chunk_len - taken;
             const unsigned int take = want < avail ? want : avail;
             const unsigned int rank = (unsigned int)__builtin_popcountll(idle & below);
@@ -1956,6 +1969,10 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
         bool emits = false;
         V3 ko = o, kd = o, kt = o; Sfc32 ks = seed;
         const bool alive = pending && !near_zero(throughput);
+#ifdef PTMI_LEVEL_STATS
+        st_shade += (unsigned int)__builtin_popcountll(__ballot(alive));
+        st_glass += (unsigned int)__builtin_popcountll(__ballot(alive && f2u(M[2 * idx + 1].x) == 2u));
+#endif
         live_w += (unsigned int)__builtin_popcountll(__ballot(alive));        // one child per shaded hit ...
         if (alive) {
             const float4 ma = M[2 * idx], mb = M[2 * idx + 1];
@@ -1997,6 +2014,9 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
         }
         // ---- trace round: one traceStep (Trace.hs:272-294) for every lane that holds a ray
         cut_w += (unsigned int)__builtin_popcountll(__ballot(has_ray && depth >= step_cap));
+#ifdef PTMI_LEVEL_STATS
+        st_trace += (unsigned int)__builtin_popcountll(__ballot(has_ray));
+#endif
         if (has_ray) {
             if (depth >= step_cap) {                          // the safety cap (the reference has none): the ray is in the stream, never traced
                 has_ray = false; ended = true;
@@ -2018,6 +2038,13 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
         const unsigned int end = blk_end < lv.out.capacity ? blk_end : lv.out.capacity;
         for (unsigned int i = blk + (unsigned int)lane; i < end; i += 64u) lv.out.pixel()[i] = kHole;
     }
+#ifdef PTMI_LEVEL_STATS
+    if (lane == 0 && a.work_counter) {                        // [20 + 8 k ...]: k = 0 level 0, 1 later levels
+        unsigned int *wc = a.work_counter + 20 + (FIRST ? 0 : 8);
+        atomicAdd(wc + 0, st_trips); atomicAdd(wc + 1, st_dead); atomicAdd(wc + 2, st_next); atomicAdd(wc + 3, st_shade);
+        atomicAdd(wc + 4, st_glass); atomicAdd(wc + 5, st_trace); atomicAdd(wc + 6, st_refills);
+    }
+#endif
     // statistics: one set of atomics per wave, on counters sharded by workgroup
     unsigned int deep = deepest;
     for (int off = 32; off > 0; off >>= 1) { const unsigned int other = __shfl_xor(deep, off, 64); deep = other > deep ? other : deep; }
