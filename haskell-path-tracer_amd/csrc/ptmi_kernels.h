@@ -54,19 +54,18 @@ struct RenderArgs {
 enum { kScTruncated = 0, kScDropped = 1, kScWords = 4 };
 constexpr int kTreeStackDepth = 16;        // per-pixel tree walk: pending children a lane can hold (render_streams_tree_kernel)
 
-// Ray stream of the wavefront Streams path: struct-of-arrays, `capacity` rays (type RayState, Trace.hs:46)
-// One base pointer + the capacity (15 word planes of `capacity` slots each): fifteen pointers per stream as kernel arguments
-// filled the scalar register file of the level kernel and pushed constants and flags into scratch memory.
+// Ray stream of the stream form of Streams: `capacity` records (type RayState, Trace.hs:46) of 16 words = one 64-byte line:
+//   [origin xyz, direction x] [direction yz, throughput xy] [throughput z, local pixel index, seed a, seed b]
+//   [seed c, seed counter, step index (traceSteps taken by the ray's ancestors = the awhile iteration it belongs to), -]
+// A record is written and read as four 16-byte accesses with one address computation (as fifteen word planes every emitted
+// child cost fifteen stores with an address each).  One base pointer + the capacity: kernel arguments live in scalar registers.
 struct RayQueue {
     uint32_t *base;
-    unsigned int capacity;  // slots
-    PTMI_HD uint32_t *plane(int k) const { return base + (size_t)k * capacity; }
-    PTMI_HD float *f(int k) const { return reinterpret_cast<float *>(plane(k)); }   // 0..8: origin xyz, direction xyz, throughput xyz
-    PTMI_HD uint32_t *pixel() const { return plane(9); }                             // local pixel index
-    PTMI_HD uint32_t *seed(int k) const { return plane(10 + k); }                    // SFC32 a, b, c, counter
-    PTMI_HD uint32_t *depth() const { return plane(14); }    // traceSteps already taken by the ray's ancestors (= the awhile iteration it belongs to)
+    unsigned int capacity;  // records
+    PTMI_HD float4 *record(unsigned int i) const { return reinterpret_cast<float4 *>(base) + (size_t)i * 4; }
+    PTMI_HD uint32_t *pixel_word(unsigned int i) const { return base + (size_t)i * 16 + 9; }     // kHole marks an unused slot
 };
-constexpr int kRayQueueWords = 15;
+constexpr int kRayQueueWords = 16;
 constexpr int kCounterStride = 32;          // device counters sit 128 B apart (one per cache line)
 constexpr int kStreamStepCapDefault = 1 << 16;   // traceSteps per ray lineage; the reference has no bound (Trace.hs:166-170) -- this only guarantees termination
 // Counters of the stream form, each kCounterStride words apart:
@@ -82,17 +81,12 @@ constexpr int kLvWords = (kLvCursor + 3 * kLvMaxLevels) * kCounterStride;
 // beyond updateSeed).  For a GLASS primary hit -- whose two children are the same two rays in every sample, a glass hit
 // draws nothing that changes a direction -- the first hit of each child instead (0, 1 or 2 records), with the
 // throughput, the step index and the number of raw draws its ray's seed is ahead of the sample's.
-struct HitList {
+struct HitList {             // records of 16 words: [position xyz, normal x] [normal yz, direction xy] [direction z, throughput xyz] [primitive, local pixel index, meta, -]
     uint32_t *base;
     unsigned int slots;
-    PTMI_HD uint32_t *plane(int k) const { return base + (size_t)k * slots; }
-    PTMI_HD float *f(int k) const { return reinterpret_cast<float *>(plane(k)); }       // 0..8: hit position, normal, incoming direction
-    PTMI_HD float *t(int k) const { return reinterpret_cast<float *>(plane(9 + k)); }   // throughput of the incoming ray
-    PTMI_HD uint32_t *idx() const { return plane(12); }      // primitive hit
-    PTMI_HD uint32_t *pixel() const { return plane(13); }    // local pixel index
-    PTMI_HD uint32_t *meta() const { return plane(14); }     // step index of the incoming ray | raw draws << 8
+    PTMI_HD float4 *record(unsigned int i) const { return reinterpret_cast<float4 *>(base) + (size_t)i * 4; }
 };
-constexpr int kHitListWords = 15;
+constexpr int kHitListWords = 16;
 struct LevelArgs {
     RayQueue in, out;               // `in` is unused by level 0 (it starts from the cached primary hits)
     HitList hits;                   // level 0

@@ -1355,12 +1355,11 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_STREAMS_WAVES) render_strea
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void queue_store(const RayQueue &q, unsigned int i, V3 o, V3 d, V3 t, uint32_t pixel, Sfc32 s, uint32_t depth)
 {
-    q.depth()[i] = depth;
-    q.f(0)[i] = o.x; q.f(1)[i] = o.y; q.f(2)[i] = o.z;
-    q.f(3)[i] = d.x; q.f(4)[i] = d.y; q.f(5)[i] = d.z;
-    q.f(6)[i] = t.x; q.f(7)[i] = t.y; q.f(8)[i] = t.z;
-    q.pixel()[i] = pixel;
-    q.seed(0)[i] = s.a; q.seed(1)[i] = s.b; q.seed(2)[i] = s.c; q.seed(3)[i] = s.counter;
+    float4 *r = q.record(i);
+    r[0] = float4{o.x, o.y, o.z, d.x};
+    r[1] = float4{d.y, d.z, t.x, t.y};
+    r[2] = float4{t.z, u2f(pixel), u2f(s.a), u2f(s.b)};
+    r[3] = float4{u2f(s.c), u2f(s.counter), u2f(depth), 0.0f};
 }
 
 // GLASS ior (extension): reflection child + refraction child; see the oracle's glass_children for the spec.
@@ -1772,23 +1771,26 @@ __global__ void __launch_bounds__(kBlock) streams_primary_kernel(const RenderArg
             const unsigned int i = slot + (e == 0 ? (unsigned int)__builtin_popcountll(m0 & below)
                                                   : (unsigned int)(__builtin_popcountll(m0) + __builtin_popcountll(m1 & below)));
             const V3 p = e == 0 ? pos[0] : pos[1], n = e == 0 ? nor[0] : nor[1], dd = e == 0 ? dir[0] : dir[1], tt = e == 0 ? thr[0] : thr[1];
-            out.f(0)[i] = p.x; out.f(1)[i] = p.y; out.f(2)[i] = p.z;
-            out.f(3)[i] = n.x; out.f(4)[i] = n.y; out.f(5)[i] = n.z;
-            out.f(6)[i] = dd.x; out.f(7)[i] = dd.y; out.f(8)[i] = dd.z;
-            out.t(0)[i] = tt.x; out.t(1)[i] = tt.y; out.t(2)[i] = tt.z;
-            out.idx()[i] = (uint32_t)(e == 0 ? prim[0] : prim[1]); out.pixel()[i] = (uint32_t)pixel;
-            out.meta()[i] = e == 0 ? meta[0] : meta[1];
+            float4 *r = out.record(i);
+            r[0] = float4{p.x, p.y, p.z, n.x};
+            r[1] = float4{n.y, n.z, dd.x, dd.y};
+            r[2] = float4{dd.z, tt.x, tt.y, tt.z};
+            r[3] = float4{u2f((uint32_t)(e == 0 ? prim[0] : prim[1])), u2f((uint32_t)pixel), u2f(e == 0 ? meta[0] : meta[1]), 0.0f};
         }
     }
 }
 
 // level 0: a hit pixel (re)starts a sample from its cached primary hit
-__device__ __forceinline__ void load_cached_hit(const HitList &h, unsigned int i, V3 &pos, V3 &normal, V3 &dir, int &idx)
+__device__ __forceinline__ void load_cached_hit(const HitList &h, unsigned int i, V3 &pos, V3 &normal, V3 &dir, V3 &throughput,
+                                                int &idx, uint32_t &pixel, uint32_t &meta)
 {
-    pos = mk(h.f(0)[i], h.f(1)[i], h.f(2)[i]);
-    normal = mk(h.f(3)[i], h.f(4)[i], h.f(5)[i]);
-    dir = mk(h.f(6)[i], h.f(7)[i], h.f(8)[i]);
-    idx = (int)h.idx()[i];
+    const float4 *r = h.record(i);
+    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+    pos = mk(r0.x, r0.y, r0.z);
+    normal = mk(r0.w, r1.x, r1.y);
+    dir = mk(r1.z, r1.w, r2.x);
+    throughput = mk(r2.y, r2.z, r2.w);
+    idx = (int)f2u(r3.x); pixel = f2u(r3.y); meta = f2u(r3.z);
 }
 
 // IN_LANE (level 0): a lane renders lv.samples_in_lane successive samples from its start hit before it refills -- the hit
@@ -1925,17 +1927,15 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
                 if (FIRST) {
                     // initialState (Trace.hs:158-162) one step on: the pixel's cached primary hit; sample j of the batch
                     // starts from the pixel's seed advanced by j draws, which is what j updateSeeds leave (Trace.hs:190-191)
-                    pixel = lv.hits.pixel()[i];
+                    uint32_t meta;
+                    load_cached_hit(lv.hits, i, o, normal, d, throughput, idx, pixel, meta);
                     seed.a = a.planes.sa[pixel]; seed.b = a.planes.sb[pixel]; seed.c = a.planes.sc[pixel]; seed.counter = a.planes.sctr[pixel];
                     for (unsigned int q = 0; q < chunk_j; ++q) (void)random_float(seed);
                     if (IN_LANE) {
                         sample_j = 0;
                         sample_seed[0][threadIdx.x] = seed.a; sample_seed[1][threadIdx.x] = seed.b; sample_seed[2][threadIdx.x] = seed.c; sample_seed[3][threadIdx.x] = seed.counter;
                     }
-                    load_cached_hit(lv.hits, i, o, normal, d, idx);
-                    const uint32_t meta = lv.hits.meta()[i];
                     for (uint32_t q = 0; q < (meta >> 8); ++q) (void)sfc32_next(seed);      // the draws its ray's ancestors made
-                    throughput = mk(lv.hits.t(0)[i], lv.hits.t(1)[i], lv.hits.t(2)[i]);
                     if (IN_LANE) {
                         lane_hit[0][threadIdx.x] = o.x; lane_hit[1][threadIdx.x] = o.y; lane_hit[2][threadIdx.x] = o.z;
                         lane_hit[3][threadIdx.x] = normal.x; lane_hit[4][threadIdx.x] = normal.y; lane_hit[5][threadIdx.x] = normal.z;
@@ -1947,13 +1947,16 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
                     depth = meta & 0xffu; hits = 0; pending = true;   // (a start hit of a dead ray -- a reflection of weight ~0 -- waits for the next trip's first block)
                     deepest = deepest > 1u ? deepest : 1u;    // the primary ray's traceStep
                 } else {
-                    pixel = lv.in.pixel()[i];
+                    const float4 *r = lv.in.record(i);
+                    const float4 r2 = r[2];
+                    pixel = f2u(r2.y);
                     if (pixel != kHole) {
-                        o = mk(lv.in.f(0)[i], lv.in.f(1)[i], lv.in.f(2)[i]);
-                        d = mk(lv.in.f(3)[i], lv.in.f(4)[i], lv.in.f(5)[i]);
-                        throughput = mk(lv.in.f(6)[i], lv.in.f(7)[i], lv.in.f(8)[i]);
-                        seed.a = lv.in.seed(0)[i]; seed.b = lv.in.seed(1)[i]; seed.c = lv.in.seed(2)[i]; seed.counter = lv.in.seed(3)[i];
-                        depth = lv.in.depth()[i]; hits = 0; has_ray = true;
+                        const float4 r0 = r[0], r1 = r[1], r3 = r[3];
+                        o = mk(r0.x, r0.y, r0.z);
+                        d = mk(r0.w, r1.x, r1.y);
+                        throughput = mk(r1.z, r1.w, r2.x);
+                        seed.a = f2u(r2.z); seed.b = f2u(r2.w); seed.c = f2u(r3.x); seed.counter = f2u(r3.y);
+                        depth = f2u(r3.z); hits = 0; has_ray = true;
                     }
                 }
             }
@@ -2036,7 +2039,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
     // what is left of this wave's last block: holes
     if (lv.may_emit) {
         const unsigned int end = blk_end < lv.out.capacity ? blk_end : lv.out.capacity;
-        for (unsigned int i = blk + (unsigned int)lane; i < end; i += 64u) lv.out.pixel()[i] = kHole;
+        for (unsigned int i = blk + (unsigned int)lane; i < end; i += 64u) *lv.out.pixel_word(i) = kHole;
     }
 #ifdef PTMI_LEVEL_STATS
     if (lane == 0 && a.work_counter) {                        // [20 + 8 k ...]: k = 0 level 0, 1 later levels
