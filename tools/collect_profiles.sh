@@ -29,3 +29,5 @@ cp "$SRC/c4_part.json" "$ROOT/profiles/${TAG}_c4_part.json"
 cp "$SRC/extra.json" "$ROOT/profiles/${TAG}_extra_measurements.json"
 cp "$SRC/phase_stats.json" "$ROOT/profiles/${TAG}_phase_stats.json"
 echo "profiles/${TAG}_* written"
+for f in level_stats tree_stats; do [ -s "$SRC/$f.json" ] && cp "$SRC/$f.json" "$ROOT/profiles/${TAG}_$f.json"; done
+true
