@@ -119,6 +119,24 @@ def main():
         out["c5_part_of_8_4k_512spp_ms"] = round(dt * 1e3, 2)
         out["c5_part_live_Grays_s"] = round(st["live_bounces"] / dt / 1e9, 2)
         out["c5_part_dropped"] = st["stream_rays_dropped"]
+    # --- C0, the reference's own configuration: 800x600, mainScene (7 primitives), limit 15 -- per resident call of 1 spp (what
+    #     `compileFor`'s closure does per iteration) and of 30 spp (computationLoop's smallest batch, app/Main.hs:209-211)
+    with pkg.Context(0) as ctx:
+        ctx.set_scene(*pkg.world.main_scene())
+        ctx.resize(800, 600)
+        ctx.init_output(0x5EED1234)
+        for n_spp, key in ((1, "c0_800x600_limit15_1spp_call_us"), (30, "c0_800x600_limit15_30spp_call_us")):
+            for _ in range(20):
+                ctx.render(cam, 15, n_spp)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            reps = 200
+            for _ in range(reps):
+                ctx.render(cam, 15, n_spp)
+            ctx.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            out[key] = round(dt * 1e6, 1)
+        out["c0_Msamples_s_at_30spp"] = round(800 * 600 * 30 * 15 / (out["c0_800x600_limit15_30spp_call_us"] * 1e-6) / 1e6, 1)
     print(json.dumps(out))
 
 
