@@ -212,6 +212,8 @@ void pack_scene(const ptmi_sphere *sph, int ns, const ptmi_plane *pl, int np, st
     for (int j = 0; j < np; ++j) mat(pl[j].color, pl[j].illuminance, pl[j].brdf_tag, pl[j].brdf_param);
 }
 
+constexpr size_t kLiveBytes = (size_t)kStatShards * kStatStride * sizeof(unsigned long long);     // sharded statistics (ptmi_kernels.h)
+constexpr size_t kItersBytes = (size_t)kStatShards * 2 * kStatStride * sizeof(unsigned int);
 constexpr size_t kStreamQueueBudget = 64ull << 30;  // bytes the two ray streams may take together (of 288 GB)
 constexpr int kStreamBatchMax = 32;                 // samples of every pixel that share one stream when rays can split (1080p: 8 / 16 / 32 -> 13.3 / 12.0 / 11.5 ms)
 
@@ -371,6 +373,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
     c->rays_truncated += raw[(size_t)kLvCut * kCounterStride] + cut_in_streams;
     unsigned int longest = raw[(size_t)kLvDeepest * kCounterStride];            // stream_iterations: the deepest step of this call
     if (longest == 0) longest = 1;                                              // every primary ray missed: one traceStep all the same
+    PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, kItersBytes, c->stream));             // (sharded for the per-pixel kernels: shard 0 carries this form's figure)
     PTMI_HIP(c, hipMemcpyAsync(c->d_iters, &longest, sizeof longest, hipMemcpyHostToDevice, c->stream));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
     return PTMI_OK;
@@ -511,15 +514,15 @@ int ptmi_create(ptmi_ctx **out, int device)
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreateWithFlags(&c->ev_snap, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
-    if ((e = hipMalloc(&c->d_live, sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc(&c->d_live, kLiveBytes)) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc(&c->d_work, 64 * sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipMalloc(&c->d_iters, sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc(&c->d_iters, kItersBytes)) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc(&c->d_stream_counters, kScWords * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMemsetAsync(c->d_stream_counters, 0, kScWords * sizeof(unsigned long long), c->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
     // stream-ordered fills: the context's stream is non-blocking, so a NULL-stream hipMemset would race with it
-    if ((e = hipMemsetAsync(c->d_live, 0, sizeof(unsigned long long), c->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
+    if ((e = hipMemsetAsync(c->d_live, 0, kLiveBytes, c->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
     if ((e = hipMemsetAsync(c->d_work, 0, 64 * sizeof(unsigned int), c->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
-    if ((e = hipMemsetAsync(c->d_iters, 0, sizeof(unsigned int), c->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
+    if ((e = hipMemsetAsync(c->d_iters, 0, kItersBytes, c->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
     *out = c;
     return PTMI_OK;
@@ -922,10 +925,17 @@ int ptmi_get_stats(ptmi_ctx *c, ptmi_stats *out)
     PTMI_HIP(c, hipSetDevice(c->device));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
     unsigned long long live = 0, sc[kScWords] = {0, 0, 0, 0}; unsigned int iters = 0;
-    PTMI_HIP(c, hipMemcpyAsync(&live, c->d_live, sizeof live, hipMemcpyDeviceToHost, c->stream));
+    std::vector<unsigned long long> live_shards((size_t)kStatShards * kStatStride);     // the sharded statistics: sum / maximum over the shards
+    std::vector<unsigned int> iter_shards((size_t)kStatShards * 2 * kStatStride);
+    PTMI_HIP(c, hipMemcpyAsync(live_shards.data(), c->d_live, kLiveBytes, hipMemcpyDeviceToHost, c->stream));
     PTMI_HIP(c, hipMemcpyAsync(sc, c->d_stream_counters, sizeof sc, hipMemcpyDeviceToHost, c->stream));
-    PTMI_HIP(c, hipMemcpyAsync(&iters, c->d_iters, sizeof iters, hipMemcpyDeviceToHost, c->stream));
+    PTMI_HIP(c, hipMemcpyAsync(iter_shards.data(), c->d_iters, kItersBytes, hipMemcpyDeviceToHost, c->stream));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < kStatShards; ++k) {
+        live += live_shards[(size_t)k * kStatStride];
+        const unsigned int it = iter_shards[(size_t)k * 2 * kStatStride];
+        iters = it > iters ? it : iters;
+    }
     out->live_bounces = live + c->live_host; out->nominal_bounces = c->nominal; out->samples = c->samples;
     out->stream_iterations = iters;
     out->stream_rays_dropped = c->rays_dropped + sc[kScDropped];
@@ -952,8 +962,8 @@ int ptmi_reset_stats(ptmi_ctx *c)
     std::lock_guard<std::mutex> lock(c->mu);
     PTMI_HIP(c, hipSetDevice(c->device));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
-    PTMI_HIP(c, hipMemsetAsync(c->d_live, 0, sizeof(unsigned long long), c->stream));
-    PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, sizeof(unsigned int), c->stream));
+    PTMI_HIP(c, hipMemsetAsync(c->d_live, 0, kLiveBytes, c->stream));
+    PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, kItersBytes, c->stream));
     PTMI_HIP(c, hipMemsetAsync(c->d_work, 0, 64 * sizeof(unsigned int), c->stream));
     PTMI_HIP(c, hipMemsetAsync(c->d_stream_counters, 0, kScWords * sizeof(unsigned long long), c->stream));
     c->nominal = 0; c->samples = 0; c->rays_dropped = 0; c->rays_truncated = 0; c->live_host = 0;

@@ -33,7 +33,9 @@ struct RenderArgs {
     int rows_local;                       // rows held by this context
     int stripe_rows, n_parts, part;       // row-stripe partition
     int bounce_limit, n_spp;
-    unsigned long long *live_counter;     // device counter, += live bounces
+    // device statistics, SHARDED: kStatShards words kStatStride words apart, a wave adds to shard (workgroup & (kStatShards - 1)).
+    // One word serves ~90 atomics per microsecond: 7 500 waves of a 1-spp launch ending together took 83 us to count themselves.
+    unsigned long long *live_counter;     // += live bounces (the host sums the shards)
     unsigned int *work_counter;           // device counter for dynamic pixel hand-out (variants)
     unsigned int *stream_iterations;      // Streams: steps taken by the last sample (max over waves)
     // Cost-ordered dispatch of the tiled kernels (see lane_pixel in ptmi_kernels.hip).  A "quad" is a run of four
@@ -59,6 +61,8 @@ constexpr int kTreeStackDepth = 16;        // per-pixel tree walk: pending child
 //   [seed c, seed counter, step index (traceSteps taken by the ray's ancestors = the awhile iteration it belongs to), -]
 // A record is written and read as four 16-byte accesses with one address computation (as fifteen word planes every emitted
 // child cost fifteen stores with an address each).  One base pointer + the capacity: kernel arguments live in scalar registers.
+constexpr int kStatShards = 256, kStatStride = 16;    // 128 B apart (u64) -- u32 shards use the same byte distance (stride 32)
+
 struct RayQueue {
     uint32_t *base;
     unsigned int capacity;  // records

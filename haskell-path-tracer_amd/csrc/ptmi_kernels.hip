@@ -819,7 +819,7 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? PTMI_INLINE_WA
     if (TILE_W > 0) record_cost(a, quad, trips);
     if (a.live_counter) {
         const unsigned long long total = wave_sum(live);
-        if ((threadIdx.x & 63) == 0 && total) atomicAdd(a.live_counter, total);
+        if ((threadIdx.x & 63) == 0 && total) atomicAdd(a.live_counter + (size_t)(blockIdx.x & (kStatShards - 1)) * kStatStride, total);
     }
 }
 
@@ -996,7 +996,7 @@ __global__ void __launch_bounds__(64 * W, 6) render_inline_pooled_kernel(const R
     }
     if (a.live_counter) {
         const unsigned long long total = wave_sum(live);
-        if (lane == 0 && total) atomicAdd(a.live_counter, total);
+        if (lane == 0 && total) atomicAdd(a.live_counter + (size_t)(blockIdx.x & (kStatShards - 1)) * kStatStride, total);
     }
 #ifdef PTMI_POOL_STATS
     // diagnostic build only: per wave [1] trips, [2] trips with own work, [3] B batches executed, [4] B items executed,
@@ -1165,7 +1165,7 @@ __global__ void __launch_bounds__(kRenderBlock) render_inline_persistent_kernel(
 
     if (a.live_counter) {
         const unsigned long long total = wave_sum(live);
-        if (lane == 0 && total) atomicAdd(a.live_counter, total);
+        if (lane == 0 && total) atomicAdd(a.live_counter + (size_t)(blockIdx.x & (kStatShards - 1)) * kStatStride, total);
     }
 #ifdef PTMI_PHASE_STATS
     // diagnostic build only: [1] wave-iterations x 64, [2..4] lane participations in rounds A, B, C
@@ -1328,11 +1328,11 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_STREAMS_WAVES) render_strea
     if (TILE_W > 0) record_cost(a, quad, trips);
     if (a.live_counter) {
         const unsigned long long total = wave_sum(live);
-        if ((threadIdx.x & 63) == 0 && total) atomicAdd(a.live_counter, total);
+        if ((threadIdx.x & 63) == 0 && total) atomicAdd(a.live_counter + (size_t)(blockIdx.x & (kStatShards - 1)) * kStatStride, total);
     }
     if (a.stream_iterations) {
         for (int off = 32; off > 0; off >>= 1) { const unsigned int other = __shfl_xor(longest, off, 64); longest = other > longest ? other : longest; }
-        if ((threadIdx.x & 63) == 0 && longest) atomicMax(a.stream_iterations, longest);
+        if ((threadIdx.x & 63) == 0 && longest) atomicMax(a.stream_iterations + (size_t)(blockIdx.x & (kStatShards - 1)) * (2 * kStatStride), longest);
     }
     if (__any(cut != 0u)) {                                           // rare: only when the safety cap bites
         const unsigned long long total = wave_sum(cut);
@@ -1643,11 +1643,11 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
     if (TILE_W > 0) record_cost(a, quad, trips);
     if (a.live_counter) {
         const unsigned long long total = wave_sum(live);
-        if ((threadIdx.x & 63) == 0 && total) atomicAdd(a.live_counter, total);
+        if ((threadIdx.x & 63) == 0 && total) atomicAdd(a.live_counter + (size_t)(blockIdx.x & (kStatShards - 1)) * kStatStride, total);
     }
     if (a.stream_iterations) {
         for (int off = 32; off > 0; off >>= 1) { const unsigned int other = __shfl_xor(longest, off, 64); longest = other > longest ? other : longest; }
-        if ((threadIdx.x & 63) == 0 && longest) atomicMax(a.stream_iterations, longest);
+        if ((threadIdx.x & 63) == 0 && longest) atomicMax(a.stream_iterations + (size_t)(blockIdx.x & (kStatShards - 1)) * (2 * kStatStride), longest);
     }
     if (__any((cut | dropped) != 0u)) {                               // rare
         const unsigned long long n_cut = wave_sum(cut), n_dropped = wave_sum(dropped);
