@@ -307,9 +307,14 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
         const int span = in_lane_max > 1 ? in_lane_max : batch_max;       // samples this pass covers
         const int covered = n_spp - s < span ? n_spp - s : span;
         const int batch = in_lane_max > 1 ? 1 : covered;                  // samples that share the stream
-        auto cursor_of = [&](int level) { return (size_t)(kLvCursor + 3 * (level % kLvMaxLevels)) * kCounterStride; };
+        auto cursor_of = [&](int level) { return (size_t)(kLvCursor + kLvPerLevel * (level % kLvMaxLevels)) * kCounterStride; };
+        auto emitted_of = [&](int level) {                    // children the level stored: the sum of its shards (read back into `raw`)
+            unsigned long long total = 0;
+            for (int k = 0; k < kLvEmitShards; ++k) total += raw[cursor_of(level) + (size_t)(2 + k) * kCounterStride];
+            return total;
+        };
         PTMI_HIP(c, hipMemsetAsync(c->d_qcount + (size_t)kLvCursor * kCounterStride, 0,
-                                   (size_t)3 * kLvMaxLevels * kCounterStride * sizeof(unsigned int), c->stream));
+                                   (size_t)kLvPerLevel * kLvMaxLevels * kCounterStride * sizeof(unsigned int), c->stream));
         auto launch_level = [&](int level, size_t expected_items) -> int {
             LevelArgs lv{};
             lv.in = q[(level + 1) & 1]; lv.out = q[level & 1];
@@ -319,15 +324,15 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
             lv.in_count = level == 0 ? d_hit_count : c->d_qcount + cursor_of(level - 1);
             lv.in_base = level == 0 ? 0u : base[(size_t)((level - 1) % kLvMaxLevels)];
             lv.out_count = c->d_qcount + cursor_of(level);
-            lv.emitted = lv.out_count + kCounterStride;
-            lv.chunk_cursor = lv.out_count + 2 * kCounterStride;
+            lv.chunk_cursor = lv.out_count + kCounterStride;
+            lv.emitted = lv.out_count + 2 * kCounterStride;
             lv.may_emit = c->has_glass ? 1 : 0;
             lv.samples_in_lane = in_lane_max > 1 ? covered : 1;
             const unsigned int grid = grid_for(expected_items);
             lv.out_base = grid * first_block;
             base[(size_t)(level % kLvMaxLevels)] = lv.out_base;
             if (level >= kLvMaxLevels)                         // the counter words come round again: this level's are long idle
-                PTMI_HIP(c, hipMemsetAsync(lv.out_count, 0, (size_t)3 * kCounterStride * sizeof(unsigned int), c->stream));
+                PTMI_HIP(c, hipMemsetAsync(lv.out_count, 0, (size_t)kLvPerLevel * kCounterStride * sizeof(unsigned int), c->stream));
             PTMI_HIP(c, launch_streams_level(a, lv, level == 0, grid, c->stream));
             return PTMI_OK;
         };
@@ -344,7 +349,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
             PTMI_HIP(c, hipMemcpyAsync(raw.data(), c->d_qcount, (size_t)kLvWords * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
             PTMI_HIP(c, hipStreamSynchronize(c->stream));
             // `null state` (Trace.hs:166-170): the loop goes on while the last level emitted a child that a further step may trace
-            const bool more = raw[cursor_of(level) + kCounterStride] > 0u && level + 1 < a.stream_step_cap;
+            const bool more = emitted_of(level) > 0u && level + 1 < a.stream_step_cap;
             if (!more) break;
             const size_t cursor = (size_t)raw[cursor_of(level)] + base[(size_t)(level % kLvMaxLevels)];
             ++level;
@@ -353,20 +358,20 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
         if (c->has_glass) {
             now.clear();
             for (int l = 0; l < level; ++l) {                // stream lengths (holes included) the levels 1.. read, while they held rays
-                if (raw[cursor_of(l) + kCounterStride] == 0u) break;
+                if (emitted_of(l) == 0u) break;
                 const size_t cursor = (size_t)raw[cursor_of(l)] + base[(size_t)(l % kLvMaxLevels)];
                 now.push_back((unsigned int)(cursor < capacity ? cursor : capacity));
             }
             seen.swap(now);
             // children of the deepest allowed level sit in a stream no level will read: the cap cut them
-            cut_in_streams += raw[cursor_of(level) + kCounterStride];
+            cut_in_streams += emitted_of(level);
         }
         PTMI_HIP(c, launch_streams_update_seed(a.planes, (long long)n, covered, c->stream));
         s += covered;
     }
     PTMI_HIP(c, hipMemcpyAsync(raw.data(), c->d_qcount, (size_t)kLvCursor * kCounterStride * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
-    for (int k = 0; k < 8; ++k) c->live_host += raw[(size_t)(kLvLive + k) * kCounterStride];
+    for (int k = 0; k < kLvLiveShards; ++k) c->live_host += raw[(size_t)(kLvLive + k) * kCounterStride];
     // the two children of every glass primary hit whose split is cached in the start list: counted here, per sample
     c->live_host += 2ull * raw[(size_t)kLvSplitPixels * kCounterStride] * (uint64_t)n_spp;
     c->rays_dropped += raw[(size_t)kLvDropped * kCounterStride];

@@ -72,14 +72,18 @@ struct RayQueue {
 constexpr int kRayQueueWords = 16;
 constexpr int kCounterStride = 32;          // device counters sit 128 B apart (one per cache line)
 constexpr int kStreamStepCapDefault = 1 << 16;   // traceSteps per ray lineage; the reference has no bound (Trace.hs:166-170) -- this only guarantees termination
-// Counters of the stream form, each kCounterStride words apart:
-//   [kLvLive, +8) children emitted, sharded by workgroup | kLvCut rays cut by the step cap | kLvDropped children that found
-//   the output stream full | kLvDeepest deepest step + 1 | kLvCursor + 3 l: the reservation cursor of the stream level l WRITES,
-//   counted from the end of its waves' static blocks (grid * first block: LevelArgs.out_base / in_base; that sum = the item
-//   count, holes included, of the stream level l + 1 reads) | + 1: the children level l stored | + 2: level l's chunk hand-out
-constexpr int kLvLive = 0, kLvCut = 8, kLvDropped = 9, kLvDeepest = 10, kLvHits = 11, kLvSplitPixels = 12, kLvCursor = 13, kLvMaxLevels = 64;
-// kLvHits: start hits in the list; kLvSplitPixels: pixels whose (glass) primary hit was replaced by its children's hits
-constexpr int kLvWords = (kLvCursor + 3 * kLvMaxLevels) * kCounterStride;
+// Counters of the stream form, each kCounterStride words (one cache line) apart; sums are sharded by workgroup, because one
+// word serves only ~90 atomics per microsecond and the 6 144 waves of a level end together:
+//   [kLvLive, +kLvLiveShards) children emitted | kLvCut rays cut by the step cap | kLvDropped children that found the output
+//   stream full | kLvDeepest deepest step + 1 | kLvHits start hits in the list | kLvSplitPixels pixels whose (glass) primary hit
+//   was replaced by its children's hits | per level l, kLvPerLevel lines from kLvCursor + kLvPerLevel l:
+//     + 0: the reservation cursor of the stream level l WRITES, counted from the end of its waves' static blocks (grid * first
+//          block: LevelArgs.out_base / in_base; that sum = the item count, holes included, of the stream level l + 1 reads)
+//     + 1: level l's chunk hand-out | + 2 .. + 2 + kLvEmitShards: the children level l stored (shards)
+constexpr int kLvLiveShards = 64, kLvEmitShards = 8, kLvPerLevel = 2 + kLvEmitShards;
+constexpr int kLvLive = 0, kLvCut = kLvLiveShards, kLvDropped = kLvCut + 1, kLvDeepest = kLvCut + 2, kLvHits = kLvCut + 3, kLvSplitPixels = kLvCut + 4,
+              kLvCursor = kLvCut + 5, kLvMaxLevels = 64;
+constexpr int kLvWords = (kLvCursor + kLvPerLevel * kLvMaxLevels) * kCounterStride;
 // The hits the samples of the held pixels START from, compacted, struct-of-arrays, written once per render call
 // (streams_primary_kernel).  Usually the pixel's primary hit (pixels whose primary ray misses take no part in a sample
 // beyond updateSeed).  For a GLASS primary hit -- whose two children are the same two rays in every sample, a glass hit
@@ -98,7 +102,7 @@ struct LevelArgs {
     unsigned int in_base;           // ... which counts from here (the producer's out_base)
     unsigned int *out_count;        // device: this level's reservation cursor, zero at launch
     unsigned int out_base;          // grid * (first block size): where reserved blocks start
-    unsigned int *emitted;          // device: children this level stored in `out`
+    unsigned int *emitted;          // device: children this level stored in `out`: kLvEmitShards words, kCounterStride apart
     unsigned int *stats;            // device: base of the counter block
     unsigned int n_px;              // pixels held by the context
     int batch;                      // level 0: samples of every pixel in this stream

@@ -1704,15 +1704,16 @@ constexpr unsigned int kRefillBatchInLane = PTMI_REFILL_BATCH_IN_LANE;
 // A glass primary hit is replaced by the first hits of its two children when that changes nothing observable: the
 // step cap cannot cut the children (>= 3) and the glass hit itself emits nothing (its emittance would have to be added
 // once per sample).  `counters`: the stream form's counter block (kLvHits, kLvSplitPixels, kLvDeepest).
-__global__ void __launch_bounds__(kBlock) streams_primary_kernel(const RenderArgs a, const HitList out, unsigned int *counters)
+constexpr int kPrimaryBlock = 1024;   // one returning atomic per workgroup reserves its slots in the list: few, large workgroups
+__global__ void __launch_bounds__(kPrimaryBlock) streams_primary_kernel(const RenderArgs a, const HitList out, unsigned int *counters)
 {
-    __shared__ unsigned int wave_hits[kBlock / 64];
+    __shared__ unsigned int wave_hits[kPrimaryBlock / 64];
     __shared__ unsigned int block_base;
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     const float4 *S = a.scene.packed;                        // one evaluation per pixel and call: scalar loads will do
     const float4 *M = S + a.scene.geom_f4();
     const long long n_local = (long long)a.rows_local * a.width;
-    const long long pixel = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long pixel = (long long)blockIdx.x * kPrimaryBlock + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int n_rec = 0;                                            // records this pixel contributes: 0, 1 or 2
     V3 pos[2], nor[2], dir[2], thr[2];
@@ -1755,7 +1756,7 @@ __global__ void __launch_bounds__(kBlock) streams_primary_kernel(const RenderArg
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int total = 0;
-        for (int w = 0; w < kBlock / 64; ++w) total += wave_hits[w];
+        for (int w = 0; w < kPrimaryBlock / 64; ++w) total += wave_hits[w];
         block_base = total ? atomicAdd(counters + kLvHits * kCounterStride, total) : 0u;
     }
     if (lane == 0 && ms) {
@@ -2053,9 +2054,10 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
     for (int off = 32; off > 0; off >>= 1) { const unsigned int other = __shfl_xor(deep, off, 64); deep = other > deep ? other : deep; }
     if (lane == 0) {
         unsigned int *st = lv.stats;
-        if (live_w) atomicAdd(st + (kLvLive + (w & 7u)) * kCounterStride, live_w);
-        if (stored_w) atomicAdd(lv.emitted, stored_w);
-        if (deep) atomicMax(st + kLvDeepest * kCounterStride, deep);
+        if (live_w) atomicAdd(st + (kLvLive + (w & (unsigned int)(kLvLiveShards - 1))) * kCounterStride, live_w);
+        if (stored_w) atomicAdd(lv.emitted + (size_t)(w & (unsigned int)(kLvEmitShards - 1)) * kCounterStride, stored_w);
+        // a maximum: most waves find it already there (a plain load first; the atomic only when it would raise the word)
+        if (deep > __hip_atomic_load(st + kLvDeepest * kCounterStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(st + kLvDeepest * kCounterStride, deep);
         if (cut_w) atomicAdd(st + kLvCut * kCounterStride, cut_w);
         if (dropped_w) atomicAdd(st + kLvDropped * kCounterStride, dropped_w);
     }
@@ -2465,7 +2467,7 @@ hipError_t launch_streams_primary(const RenderArgs &a, HitList hits, unsigned in
 {
     const long long n = (long long)a.rows_local * a.width;
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(streams_primary_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, a, hits, counters);
+    hipLaunchKernelGGL(streams_primary_kernel, dim3(blocks_for(n, kPrimaryBlock)), dim3(kPrimaryBlock), 0, stream, a, hits, counters);
     return hipGetLastError();
 }
 
