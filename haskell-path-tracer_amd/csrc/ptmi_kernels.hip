@@ -55,8 +55,9 @@ __device__ __forceinline__ float sqrt_rn(float x)
 
 // v ^/ s for the three components of a sphere normal: three IEEE divisions by ONE denominator.  The compiler's division is
 // div_scale (both operands), rcp, two refinements of the reciprocal, quotient, two residual corrections, div_fmas, div_fixup;
-// when neither operand needs scaling and nothing is special -- the denominator within [2^-20, 2^40], the numerators at least
-// 2^-100 in magnitude and (being components of the vector whose length the denominator is) not above it -- div_scale is the
+// when neither operand needs scaling and nothing is special -- the denominator within [2^-20, 2^20], the numerators at least
+// 2^-100 in magnitude (so every quotient is a normal number, >= 2^-120) and, being components of the vector whose length the
+// denominator is, not above it -- div_scale is the
 // identity, div_fmas a plain fma and div_fixup passes the quotient through, so the same operations with the reciprocal and its
 // refinements formed ONCE give the same three quotients bit for bit (18 instead of 33 instructions, one v_rcp_f32 instead of
 // three).  If any lane of the wave falls outside (a zero component, a huge sphere, a NaN) the wave takes the compiler's form.
@@ -66,7 +67,7 @@ __device__ __forceinline__ V3 div3_by_length(V3 v, float s)
     return div_r(v, s);
 #else
     const float amin = __builtin_fminf(__builtin_fminf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), __builtin_fabsf(v.z));
-    const bool plain = s >= 0x1p-20f && s <= 0x1p40f && amin >= 0x1p-100f;
+    const bool plain = s >= 0x1p-20f && s <= 0x1p20f && amin >= 0x1p-100f;
     if (__builtin_expect(!__all(plain), 0)) return div_r(v, s);
     const float r0 = __builtin_amdgcn_rcpf(s);
     const float r = __builtin_fmaf(__builtin_fmaf(-s, r0, 1.0f), r0, r0);

@@ -136,6 +136,21 @@ def test_sphere_normals_equal_oracle_when_every_lane_hits(ctx, pkg, ora):
     assert batch(n, lambda k: np.exp(r.uniform(np.log(1e-7), np.log(1e-5), k)), False) > 0
     assert batch(n, lambda k: np.exp(r.uniform(np.log(1e13), np.log(1e17), k)), False) > 0
 
+    # tiny components of a long vector: the quotients approach (shared form, radius <= 2^20) or enter (compiler's form) the
+    # denormal range, where an unscaled division sequence would round differently
+    for radius in (5.0e5, 1.0e8, 3.0e11):
+        k = 2048
+        tiny = np.exp(r.uniform(np.log(1e-30), np.log(1e-24), (k, 2))).astype(F) * r.choice([-1.0, 1.0], (k, 2)).astype(F)
+        o = np.concatenate([tiny, np.full((k, 1), 2.0 * radius, F)], 1).astype(F)
+        d = np.tile(np.array([0.0, 0.0, -1.0], F), (k, 1))
+        sph = np.array([rp.make_sphere(pkg.world.SPHERE_DTYPE, np.zeros(3, F), F(radius)) for _ in range(k)])
+        just, t, nrm = ctx.eval_distance_to_sphere(sph, np.concatenate([o, d], 1))
+        assert np.all(just == 1)
+        for i in range(k):
+            want = ora.distance_to_sphere(o[i], d[i], sph[i])
+            pos, nor, _ = ora.hit_sphere(o[i], d[i], want, sph[i])
+            assert np.array_equal(nrm[i, 3:].view(np.uint32), nor.view(np.uint32)), (radius, i, nrm[i, 3:], nor)
+
 
 def test_device_sincos_equals_oracle_and_libm(ctx, ora):
     """The device's sin/cos (binary64 evaluation of glibc's algorithm) == oracle == host libm, bitwise."""
