@@ -68,8 +68,13 @@ struct ptmi_ctx {
     bool has_glass = false;
     void *queue_block = nullptr;
     size_t queue_capacity = 0;
-    void *hit_block = nullptr;       // stream form: the compacted primary hits (HitList)
+    void *hit_block = nullptr;       // stream form: the start hits of the pixels, in regions (HitList)
     size_t hit_capacity = 0;
+    unsigned int *d_hit_counts = nullptr;   // ... records per region
+    unsigned int hit_regions = 0;
+    void *d_snapshots = nullptr;     // stream form, split kernel: the seed every item starts from
+    size_t snapshot_bytes = 0;
+    int cus = 0;                     // compute units of the device (persistent grids)
     unsigned int *d_qcount = nullptr;
     uint64_t rays_dropped = 0;
     uint64_t rays_truncated = 0;
@@ -214,8 +219,6 @@ void pack_scene(const ptmi_sphere *sph, int ns, const ptmi_plane *pl, int np, st
 
 constexpr size_t kLiveBytes = (size_t)kStatShards * kStatStride * sizeof(unsigned long long);     // sharded statistics (ptmi_kernels.h)
 constexpr size_t kItersBytes = (size_t)kStatShards * 2 * kStatStride * sizeof(unsigned int);
-constexpr size_t kStreamQueueBudget = 64ull << 30;  // bytes the two ray streams may take together (of 288 GB)
-constexpr int kStreamBatchMax = 32;                 // samples of every pixel that share one stream when rays can split (1080p: 8 / 16 / 32 -> 13.3 / 12.0 / 11.5 ms)
 
 RayQueue carve_queue(void *block, size_t capacity, int which)
 {
@@ -225,157 +228,151 @@ RayQueue carve_queue(void *block, size_t capacity, int which)
     return q;
 }
 
-// `render Streams` as a stream: awhile (Trace.hs:142-150) on the host, one launch per LEVEL of the ray tree
-// (streams_level_kernel).  The predicate `null state` is the next stream's length, which lives on the device: the first
-// batch reads it back after every level; later batches launch as many levels as the previous batch needed (+1), each
-// reading its input length from device memory, and read the counters back ONCE per batch -- if the last level still
-// emitted rays the loop simply goes on level by level.  Without GLASS nothing is ever emitted (one child per hit stays in
-// its lane) and a batch is one sample, so that a pixel's additions happen in sample order (bit-identical to the
-// per-pixel kernel); with GLASS the order is undefined anyway and up to 32 samples share a stream.
+// `render Streams` as a stream ("wavefront" form, ptmi_kernels.hip).  Every sample of a pixel shoots the same primary ray: its
+// hit is evaluated once per call into the start-hit list (regions in dispatch order), then ONE persistent launch renders all
+// samples of the call:
+//   * scenes whose rays never split (default batch): streams_pixels_kernel -- a lane owns a pixel for the launch, no atomics,
+//     bit-identical to the per-pixel kernel under both seed rules; nothing is read back, the call is asynchronous;
+//   * GLASS (or PTMI_OPT_STREAM_BATCH > 0): streams_split_kernel -- items of (start hit, sample range), children through the
+//     waves' LDS rings.  The predicate `null state` (Trace.hs:166-170) is the overflow stream's length: read back ONCE, after
+//     the launch; only if children really travelled through HBM does the host play `awhile`, one launch per overflow level.
 int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
 {
     const size_t n = (size_t)a.rows_local * a.width;
     if (n == 0 || n_spp <= 0) return PTMI_OK;
-    const size_t cap_factor = (size_t)c->opt_capacity;   // rays per pixel-sample the child streams hold (PTMI_OPT_STREAM_CAPACITY)
-    if (n > 0xfffffff0ull) return fail(c, PTMI_ELIMIT, "image too large for the stream form of Streams");
-    int batch_max = c->opt_batch > 0 ? c->opt_batch : 1;
-    if (c->has_glass || c->opt_batch > 0) {
-        const size_t per_sample = n * cap_factor * (size_t)kRayQueueWords * 4 * 2;      // both streams
-        size_t fit = kStreamQueueBudget / (per_sample ? per_sample : 1);
-        const size_t index_fit = 0xfffffff0ull / (n * cap_factor);
-        fit = fit < index_fit ? fit : index_fit;
-        const size_t wanted = c->opt_batch > 0 ? (size_t)c->opt_batch : (size_t)kStreamBatchMax;
-        batch_max = (int)(fit < 1 ? 1 : (fit > wanted ? wanted : fit));
-        if (batch_max > n_spp) batch_max = n_spp;
-    }
-    if (a.seed_from_result) batch_max = 1;               // a sample starts from the seed the previous sample's last hit left
-    if (n * cap_factor > 0xfffffff0ull) return fail(c, PTMI_ELIMIT, "image too large for the stream form of Streams");
-    static int max_grid = 0;                                 // persistent waves: 6 per SIMD
-    if (!max_grid) {
-        int cus = 0;
-        PTMI_HIP(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-        max_grid = (cus > 0 ? cus : 256) * 4 * 6;
-    }
-    const unsigned int first_block = streams_first_block();
-    // The two child streams.  A block that is already large enough is kept (its capacity is the planes' stride); when the
-    // device cannot give what the automatic batch size asks for, fewer samples share a stream.
-    for (;;) {
-        size_t need = n * (size_t)batch_max * cap_factor;
-        if (need < (size_t)max_grid * first_block + 256) need = (size_t)max_grid * first_block + 256;   // every wave's static block fits
-        if (need <= c->queue_capacity) break;
-        if (c->queue_block) { PTMI_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->queue_block); c->queue_block = nullptr; c->queue_capacity = 0; }
-        const hipError_t e = hipMalloc(&c->queue_block, 2 * (size_t)kRayQueueWords * need * 4);
-        if (e == hipSuccess) { c->queue_capacity = need; break; }
-        (void)hipGetLastError();
-        c->queue_block = nullptr;
-        if (e != hipErrorOutOfMemory || batch_max <= 1 || c->opt_batch > 0)      // an explicit PTMI_OPT_STREAM_BATCH is honoured or refused
-            return fail(c, e == hipErrorOutOfMemory ? PTMI_ENOMEM : PTMI_EHIP, std::string("hipMalloc of the ray streams: ") + hipGetErrorString(e));
-        batch_max = (batch_max + 1) / 2;
-    }
-    const size_t capacity = c->queue_capacity;
-    // Without ray splitting (and with the default seed rule) a lane renders up to 64 successive samples of its pixel before it
-    // refills: one adder per pixel, in sample order, and launches long enough to pay for their start and drain.  With GLASS a
-    // lane of level 0 renders the samples of the batch from its start hit one after the other (their refractions share the
-    // output stream): the start hits are read once per batch and a lane whose lineage ends goes on at once.
-    const int in_lane_max = c->has_glass ? batch_max : ((!a.seed_from_result && c->opt_batch == 0) ? 64 : 1);
-    if (!c->d_qcount) PTMI_HIP(c, hipMalloc(&c->d_qcount, (size_t)kLvWords * sizeof(unsigned int)));
-    const size_t hit_slots = 2 * n;                          // a glass primary hit contributes up to two start hits
+    if (n > 0x3ffffff0ull) return fail(c, PTMI_ELIMIT, "image too large for the stream form of Streams");   // 32-bit byte offsets into the planes
+    const bool ordered = !c->has_glass && (c->opt_batch == 0 || a.seed_from_result);
+    const unsigned int n_regions = streams_regions(a.width, a.rows_local);
+    const unsigned int region_slots = ordered ? 64u : 128u;    // a glass primary hit contributes up to two start hits
+    const size_t hit_slots = (size_t)n_regions * region_slots;
     if (hit_slots > 0xfffffff0ull) return fail(c, PTMI_ELIMIT, "image too large for the stream form of Streams");
-    if (hit_slots != c->hit_capacity) {
-        if (c->hit_block) { PTMI_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->hit_block); c->hit_block = nullptr; c->hit_capacity = 0; }
+    if (hit_slots > c->hit_capacity || n_regions > c->hit_regions) {
+        PTMI_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->hit_block) { (void)hipFree(c->hit_block); c->hit_block = nullptr; c->hit_capacity = 0; }
+        if (c->d_hit_counts) { (void)hipFree(c->d_hit_counts); c->d_hit_counts = nullptr; c->hit_regions = 0; }
         PTMI_HIP(c, hipMalloc(&c->hit_block, (size_t)kHitListWords * hit_slots * 4));
         c->hit_capacity = hit_slots;
+        PTMI_HIP(c, hipMalloc(&c->d_hit_counts, (size_t)n_regions * sizeof(unsigned int)));
+        c->hit_regions = n_regions;
     }
+    if (!c->d_qcount) PTMI_HIP(c, hipMalloc(&c->d_qcount, (size_t)kLvWords * sizeof(unsigned int)));
     HitList hits;
     hits.base = static_cast<uint32_t *>(c->hit_block);
-    hits.slots = (unsigned int)hit_slots;
-    const RayQueue q[2] = {carve_queue(c->queue_block, capacity, 0), carve_queue(c->queue_block, capacity, 1)};
-    auto grid_for = [&](size_t items) {                      // (more chunks per wave, i.e. fewer waves, measured no faster: 1, 2, 4 equal, 8 slower)
-        const size_t chunks = (items + 63) / 64;
-        return (unsigned int)(chunks < 1 ? 1 : (chunks > (size_t)max_grid ? (size_t)max_grid : chunks));
-    };
-    std::vector<unsigned int> raw((size_t)kLvWords);
-    std::vector<unsigned int> seen;                          // stream lengths of the previous batch, per level (level 1 first)
-    // the statistics accumulate on the device over the whole call; the per-level cursors are cleared once per batch
-    PTMI_HIP(c, hipMemsetAsync(c->d_qcount, 0, (size_t)kLvCursor * kCounterStride * sizeof(unsigned int), c->stream));
-    std::vector<unsigned int> base((size_t)kLvMaxLevels, 0u);   // per level (mod kLvMaxLevels): where its reserved blocks start
-    // every sample of a pixel shoots the same primary ray: its hit is evaluated once per call, pixels that miss stay out
-    unsigned int *d_hit_count = c->d_qcount + (size_t)kLvHits * kCounterStride;
-    PTMI_HIP(c, launch_streams_primary(a, hits, c->d_qcount, c->stream));
-    uint64_t cut_in_streams = 0;
-    for (int s = 0; s < n_spp;) {
-        const int span = in_lane_max > 1 ? in_lane_max : batch_max;       // samples this pass covers
-        const int covered = n_spp - s < span ? n_spp - s : span;
-        const int batch = in_lane_max > 1 ? 1 : covered;                  // samples that share the stream
-        auto cursor_of = [&](int level) { return (size_t)(kLvCursor + kLvPerLevel * (level % kLvMaxLevels)) * kCounterStride; };
-        auto emitted_of = [&](int level) {                    // children the level stored: the sum of its shards (read back into `raw`)
-            unsigned long long total = 0;
-            for (int k = 0; k < kLvEmitShards; ++k) total += raw[cursor_of(level) + (size_t)(2 + k) * kCounterStride];
-            return total;
-        };
-        PTMI_HIP(c, hipMemsetAsync(c->d_qcount + (size_t)kLvCursor * kCounterStride, 0,
-                                   (size_t)kLvPerLevel * kLvMaxLevels * kCounterStride * sizeof(unsigned int), c->stream));
-        auto launch_level = [&](int level, size_t expected_items) -> int {
-            LevelArgs lv{};
-            lv.in = q[(level + 1) & 1]; lv.out = q[level & 1];
-            lv.hits = hits;
-            lv.n_px = (unsigned int)n; lv.batch = batch;
-            lv.stats = c->d_qcount;
-            lv.in_count = level == 0 ? d_hit_count : c->d_qcount + cursor_of(level - 1);
-            lv.in_base = level == 0 ? 0u : base[(size_t)((level - 1) % kLvMaxLevels)];
-            lv.out_count = c->d_qcount + cursor_of(level);
-            lv.chunk_cursor = lv.out_count + kCounterStride;
-            lv.emitted = lv.out_count + 2 * kCounterStride;
-            lv.may_emit = c->has_glass ? 1 : 0;
-            lv.samples_in_lane = in_lane_max > 1 ? covered : 1;
-            const unsigned int grid = grid_for(expected_items);
-            lv.out_base = grid * first_block;
-            base[(size_t)(level % kLvMaxLevels)] = lv.out_base;
-            if (level >= kLvMaxLevels)                         // the counter words come round again: this level's are long idle
-                PTMI_HIP(c, hipMemsetAsync(lv.out_count, 0, (size_t)kLvPerLevel * kCounterStride * sizeof(unsigned int), c->stream));
-            PTMI_HIP(c, launch_streams_level(a, lv, level == 0, grid, c->stream));
-            return PTMI_OK;
-        };
-        int level = 0;
-        if (int rc = launch_level(0, (c->has_glass ? 2 * n : n) * (size_t)batch)) return rc;
-        // the levels the previous batch needed, each with a grid that covers the stream it is EXPECTED to read (the length
-        // seen there last time plus a margin; the grid only sets the parallelism, any grid processes any length)
-        for (size_t k = 0; k < seen.size(); ++k) {
-            ++level;
-            if (int rc = launch_level(level, (size_t)seen[k] + (size_t)seen[k] / 2 + 4096)) return rc;
-        }
-        std::vector<unsigned int> now;
-        for (; c->has_glass;) {                               // without GLASS no ray is ever emitted: nothing to ask the device
-            PTMI_HIP(c, hipMemcpyAsync(raw.data(), c->d_qcount, (size_t)kLvWords * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
-            PTMI_HIP(c, hipStreamSynchronize(c->stream));
-            // `null state` (Trace.hs:166-170): the loop goes on while the last level emitted a child that a further step may trace
-            const bool more = emitted_of(level) > 0u && level + 1 < a.stream_step_cap;
-            if (!more) break;
-            const size_t cursor = (size_t)raw[cursor_of(level)] + base[(size_t)(level % kLvMaxLevels)];
-            ++level;
-            if (int rc = launch_level(level, cursor < capacity ? cursor : capacity)) return rc;
-        }
-        if (c->has_glass) {
-            now.clear();
-            for (int l = 0; l < level; ++l) {                // stream lengths (holes included) the levels 1.. read, while they held rays
-                if (emitted_of(l) == 0u) break;
-                const size_t cursor = (size_t)raw[cursor_of(l)] + base[(size_t)(l % kLvMaxLevels)];
-                now.push_back((unsigned int)(cursor < capacity ? cursor : capacity));
-            }
-            seen.swap(now);
-            // children of the deepest allowed level sit in a stream no level will read: the cap cut them
-            cut_in_streams += emitted_of(level);
-        }
-        PTMI_HIP(c, launch_streams_update_seed(a.planes, (long long)n, covered, c->stream));
-        s += covered;
+    hits.counts = c->d_hit_counts;
+    hits.region_slots = region_slots;
+    hits.n_regions = n_regions;
+    // the statistics accumulate on the device over the whole call; cursors start from zero
+    PTMI_HIP(c, hipMemsetAsync(c->d_qcount, 0, (size_t)kLvWords * sizeof(unsigned int), c->stream));
+    auto cursor_of = [&](int level) { return (size_t)(kLvCursor + kLvPerLevel * (level % kLvMaxLevels)) * kCounterStride; };
+    ItemArgs it{};
+    it.hits = hits;
+    it.n_chunks = n_regions * (region_slots / 64u);
+    it.chunk_cursor = c->d_qcount + cursor_of(0) + kCounterStride;
+    it.n_px = (unsigned int)n;
+    it.stats = c->d_qcount;
+    const int cus = c->cus > 0 ? c->cus : 256;
+    if (ordered) {
+        PTMI_HIP(c, launch_streams_primary(a, hits, c->d_qcount, n_spp, c->stream));
+        PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, kItersBytes, c->stream));
+        unsigned int grid = (unsigned int)(cus * 4 * streams_pixels_waves());
+        if (grid > it.n_chunks) grid = it.n_chunks;
+        PTMI_HIP(c, launch_streams_pixels(a, it, grid, c->stream));
+        return PTMI_OK;
     }
-    PTMI_HIP(c, hipMemcpyAsync(raw.data(), c->d_qcount, (size_t)kLvCursor * kCounterStride * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
-    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+
+    // ---- rays may split, or the samples of a pixel run as unordered items
+    unsigned int grid = (unsigned int)(cus * 4 * streams_split_waves());
+    // samples per item: a pixel's samples are cut into items so that a lane sees ~16 of them (the end of the launch is as
+    // long as the last items); PTMI_OPT_STREAM_BATCH sets the figure
+    int per_item = c->opt_batch;
+    if (per_item <= 0) {
+        const double items_wanted = 16.0 * 64.0 * (double)grid;
+        int passes = (int)(items_wanted / (double)n + 0.999);
+        if (passes < 1) passes = 1;
+        if (passes > 64) passes = 64;
+        per_item = (n_spp + passes - 1) / passes;
+        if (per_item < 8) per_item = n_spp < 8 ? n_spp : 8;
+    }
+    if (per_item > n_spp) per_item = n_spp;
+    const int passes = (n_spp + per_item - 1) / per_item;
+    if ((unsigned long long)it.n_chunks * (unsigned long long)passes > 0x7fffffffull) return fail(c, PTMI_ELIMIT, "too many items for the stream form of Streams");
+    if (grid > it.n_chunks * (unsigned int)passes) grid = it.n_chunks * (unsigned int)passes;
+    const size_t snap_bytes = (size_t)passes * n * sizeof(uint4);
+    if (snap_bytes > c->snapshot_bytes) {
+        PTMI_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->d_snapshots) { (void)hipFree(c->d_snapshots); c->d_snapshots = nullptr; c->snapshot_bytes = 0; }
+        PTMI_HIP(c, hipMalloc(&c->d_snapshots, snap_bytes));
+        c->snapshot_bytes = snap_bytes;
+    }
+    // the overflow streams: rays per pixel (PTMI_OPT_STREAM_CAPACITY) x pixels, at least every wave's static block
+    const unsigned int first_block = streams_first_block();
+    const unsigned int level_grid_max = (unsigned int)(cus * 4 * 6);
+    size_t need = n * (size_t)c->opt_capacity;
+    const size_t floor_slots = (size_t)(grid > level_grid_max ? grid : level_grid_max) * first_block + 256;
+    if (need < floor_slots) need = floor_slots;
+    if (need > 0xfffffff0ull) return fail(c, PTMI_ELIMIT, "image too large for the stream form of Streams");
+    if (need > c->queue_capacity) {
+        PTMI_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->queue_block) { (void)hipFree(c->queue_block); c->queue_block = nullptr; c->queue_capacity = 0; }
+        PTMI_HIP(c, hipMalloc(&c->queue_block, 2 * (size_t)kRayQueueWords * need * 4));
+        c->queue_capacity = need;
+    }
+    const size_t capacity = c->queue_capacity;
+    const RayQueue q[2] = {carve_queue(c->queue_block, capacity, 0), carve_queue(c->queue_block, capacity, 1)};
+    std::vector<unsigned int> base((size_t)kLvMaxLevels, 0u);   // per level (mod kLvMaxLevels): where its reserved blocks start
+
+    PTMI_HIP(c, launch_streams_primary(a, hits, c->d_qcount, 0, c->stream));
+    PTMI_HIP(c, launch_streams_seeds(a.planes, static_cast<uint4 *>(c->d_snapshots), (long long)n, passes, per_item, n_spp, c->stream));
+    it.passes = passes; it.samples_per_pass = per_item;
+    it.seed_snapshots = static_cast<const uint4 *>(c->d_snapshots);
+    it.out = q[0];
+    it.out_count = c->d_qcount + cursor_of(0);
+    it.out_base = grid * first_block;
+    it.emitted = it.out_count + 2 * kCounterStride;
+    it.may_emit = c->has_glass ? 1 : 0;
+    base[0] = it.out_base;
+    PTMI_HIP(c, launch_streams_split(a, it, grid, c->stream));
+
+    std::vector<unsigned int> raw((size_t)kLvWords);
+    auto emitted_of = [&](int level) {                        // children the level stored: the sum of its shards (read back into `raw`)
+        unsigned long long total = 0;
+        for (int k = 0; k < kLvEmitShards; ++k) total += raw[cursor_of(level) + (size_t)(2 + k) * kCounterStride];
+        return total;
+    };
+    auto read_counters = [&]() -> int {
+        PTMI_HIP(c, hipMemcpyAsync(raw.data(), c->d_qcount, (size_t)kLvWords * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+        PTMI_HIP(c, hipStreamSynchronize(c->stream));
+        return PTMI_OK;
+    };
+    if (int rc = read_counters()) return rc;
+    // `null state` (Trace.hs:166-170): the loop goes on while the last level left children in its overflow stream (a level
+    // cuts the rays the step cap forbids as it reads them, and counts them)
+    for (int level = 0; c->has_glass && emitted_of(level) > 0u;) {
+        const size_t cursor = (size_t)raw[cursor_of(level)] + base[(size_t)(level % kLvMaxLevels)];
+        const size_t items = cursor < capacity ? cursor : capacity;
+        ++level;
+        LevelArgs lv{};
+        lv.in = q[(level + 1) & 1]; lv.out = q[level & 1];
+        lv.stats = c->d_qcount;
+        lv.in_count = c->d_qcount + cursor_of(level - 1);
+        lv.in_base = base[(size_t)((level - 1) % kLvMaxLevels)];
+        lv.out_count = c->d_qcount + cursor_of(level);
+        lv.emitted = lv.out_count + 2 * kCounterStride;
+        lv.may_emit = 1;
+        const size_t chunks = (items + 63) / 64;
+        const unsigned int lgrid = (unsigned int)(chunks < 1 ? 1 : (chunks > level_grid_max ? level_grid_max : chunks));
+        lv.out_base = lgrid * first_block;
+        base[(size_t)(level % kLvMaxLevels)] = lv.out_base;
+        // the counter words of this level: long idle when they come round again
+        PTMI_HIP(c, hipMemsetAsync(lv.out_count, 0, (size_t)kLvPerLevel * kCounterStride * sizeof(unsigned int), c->stream));
+        PTMI_HIP(c, launch_streams_level(a, lv, lgrid, c->stream));
+        if (int rc = read_counters()) return rc;
+    }
     for (int k = 0; k < kLvLiveShards; ++k) c->live_host += raw[(size_t)(kLvLive + k) * kCounterStride];
     // the two children of every glass primary hit whose split is cached in the start list: counted here, per sample
     c->live_host += 2ull * raw[(size_t)kLvSplitPixels * kCounterStride] * (uint64_t)n_spp;
     c->rays_dropped += raw[(size_t)kLvDropped * kCounterStride];
-    c->rays_truncated += raw[(size_t)kLvCut * kCounterStride] + cut_in_streams;
+    c->rays_truncated += raw[(size_t)kLvCut * kCounterStride];
     unsigned int longest = raw[(size_t)kLvDeepest * kCounterStride];            // stream_iterations: the deepest step of this call
     if (longest == 0) longest = 1;                                              // every primary ray missed: one traceStep all the same
     PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, kItersBytes, c->stream));             // (sharded for the per-pixel kernels: shard 0 carries this form's figure)
@@ -405,7 +402,8 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
     // (sorted on the device).  Everything is enqueued on the stream; results do not depend on it.
     const bool per_pixel_kernel = !stream_form;
     int next_order_state = c->order_state;
-    if (per_pixel_kernel && uses_quad_order(a, algorithm == PTMI_INLINE, c->variant)) {
+    // (the stream form orders its start-hit list the same way, under a key of its own; its items record their costs)
+    if (stream_form ? (quad_positions(width, rows_local) > 0 && !sx) : uses_quad_order(a, algorithm == PTMI_INLINE, c->variant)) {
         const unsigned int n_quads = quad_positions(width, rows_local);
         if (n_quads > c->quad_capacity) {
             if (c->d_quad_cost) { PTMI_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_quad_cost); (void)hipFree(c->d_quad_order); (void)hipFree(c->d_quad_class); }
@@ -417,7 +415,7 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
         }
         ptmi_ctx::OrderKey key{};
         key.cam = *camera; key.scene_version = c->scene_version;
-        const int dims[8] = {width, height, rows_local, stripe_rows, n_parts, part, bounce_limit, algorithm};
+        const int dims[8] = {width, height, rows_local, stripe_rows, n_parts, part, bounce_limit, stream_form ? 2 : algorithm};
         std::memcpy(key.dims, dims, sizeof dims);
         if (std::memcmp(&key, &c->order_key, sizeof key) != 0) { c->order_key = key; c->order_state = 0; }
         // order_state counts the launches made with this key.  Every launch adds its costs (a 1-spp launch says little
@@ -426,7 +424,7 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
         if (launches == 0) PTMI_HIP(c, hipMemsetAsync(c->d_quad_cost, 0, n_quads * sizeof(unsigned int), c->stream));
         else if ((launches & (launches - 1)) == 0 && launches < (1 << 20)) PTMI_HIP(c, launch_quad_order(c->d_quad_cost, c->d_quad_order, c->d_quad_class, n_quads, c->stream));
         if (launches > 0) a.quad_order = c->d_quad_order;
-        if (launches < (1 << 20)) { a.quad_cost = c->d_quad_cost; next_order_state = launches + 1; }   // the sums stay far from 2^32
+        if (launches < (stream_form ? (1 << 12) : (1 << 20))) { a.quad_cost = c->d_quad_cost; next_order_state = launches + 1; }   // the sums stay far from 2^32
     }
     if (per_pixel_kernel) {
         // one word per tile workgroup for the sample chunks of the tiled per-pixel kernels (ptmi_kernels.hip)
@@ -514,6 +512,7 @@ int ptmi_create(ptmi_ctx **out, int device)
         return PTMI_EHIP;
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+    if ((e = hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return bail(e, "hipDeviceGetAttribute");
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     c->stream = c->own_stream;
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -547,6 +546,8 @@ void ptmi_destroy(ptmi_ctx *c)
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->queue_block) (void)hipFree(c->queue_block);
     if (c->hit_block) (void)hipFree(c->hit_block);
+    if (c->d_hit_counts) (void)hipFree(c->d_hit_counts);
+    if (c->d_snapshots) (void)hipFree(c->d_snapshots);
     if (c->d_qcount) (void)hipFree(c->d_qcount);
     if (c->d_quad_cost) (void)hipFree(c->d_quad_cost);
     if (c->d_quad_order) (void)hipFree(c->d_quad_order);

@@ -84,38 +84,61 @@ constexpr int kLvLiveShards = 64, kLvEmitShards = 8, kLvPerLevel = 2 + kLvEmitSh
 constexpr int kLvLive = 0, kLvCut = kLvLiveShards, kLvDropped = kLvCut + 1, kLvDeepest = kLvCut + 2, kLvHits = kLvCut + 3, kLvSplitPixels = kLvCut + 4,
               kLvCursor = kLvCut + 5, kLvMaxLevels = 64;
 constexpr int kLvWords = (kLvCursor + kLvPerLevel * kLvMaxLevels) * kCounterStride;
-// The hits the samples of the held pixels START from, compacted, struct-of-arrays, written once per render call
-// (streams_primary_kernel).  Usually the pixel's primary hit (pixels whose primary ray misses take no part in a sample
-// beyond updateSeed).  For a GLASS primary hit -- whose two children are the same two rays in every sample, a glass hit
-// draws nothing that changes a direction -- the first hit of each child instead (0, 1 or 2 records), with the
-// throughput, the step index and the number of raw draws its ray's seed is ahead of the sample's.
-struct HitList {             // records of 16 words: [position xyz, normal x] [normal yz, direction xy] [direction z, throughput xyz] [primitive, local pixel index, meta, -]
+// The hits the samples of the held pixels START from, written once per render call (streams_primary_kernel), in REGIONS: one
+// region per 64-pixel tile of the image (a wave of the primary kernel: an 8x8 pixel tile, or 64 consecutive pixels of a row
+// for images too small for tiles), in the order the tiles are dispatched (most expensive quad of tiles first once costs
+// are known) -- no atomics, the order is deterministic.  A region holds its tile's records compacted to the front (ballot +
+// popcount prefix in the wave) and `counts[region]` says how many: usually one per pixel whose primary ray hits, none for
+// a pixel whose ray misses.  For a GLASS primary hit -- whose two children are the same two rays in every sample, a glass
+// hit draws nothing that changes a direction -- the first hit of each child instead (0, 1 or 2 records), with the
+// throughput, the step index and the number of raw draws its ray's seed is ahead of the sample's: regions then have 128 slots.
+struct HitList {             // records of 16 words: [position xyz, normal x] [normal yz, direction xy] [direction z, throughput xyz] [primitive, local pixel index, meta, quad]
     uint32_t *base;
-    unsigned int slots;
+    unsigned int *counts;    // records per region
+    unsigned int region_slots;   // 64, or 128 when a primary hit can split
+    unsigned int n_regions;
     PTMI_HD float4 *record(unsigned int i) const { return reinterpret_cast<float4 *>(base) + (size_t)i * 4; }
 };
 constexpr int kHitListWords = 16;
+// Overflow levels of the stream form (streams_level_kernel): children that found the wave's ring full travel through HBM.
 struct LevelArgs {
-    RayQueue in, out;               // `in` is unused by level 0 (it starts from the cached primary hits)
-    HitList hits;                   // level 0
-    const unsigned int *in_count;   // device: level 0: start hits in the list; else the producer level's reservation cursor
+    RayQueue in, out;
+    const unsigned int *in_count;   // device: the producer's reservation cursor
     unsigned int in_base;           // ... which counts from here (the producer's out_base)
     unsigned int *out_count;        // device: this level's reservation cursor, zero at launch
     unsigned int out_base;          // grid * (first block size): where reserved blocks start
     unsigned int *emitted;          // device: children this level stored in `out`: kLvEmitShards words, kCounterStride apart
     unsigned int *stats;            // device: base of the counter block
-    unsigned int n_px;              // pixels held by the context
-    int batch;                      // level 0: samples of every pixel in this stream
     int may_emit;                   // 0: the scene has no ray-splitting material -- nothing is ever written to `out`
-    unsigned int *chunk_cursor;     // device: chunks handed out beyond the waves' own when samples_in_lane > 1 (zero at launch)
-    int samples_in_lane;            // level 0: a lane renders this many successive samples from its start hit before it
-                                    // refills (the stream then holds every start hit once; batch is 1)
+};
+// The item kernels of the stream form (streams_pixels_kernel, streams_split_kernel): persistent waves take the regions of the
+// start-hit list as chunks -- the first gridDim chunks are the waves' own, later ones come from a ticket counter.
+struct ItemArgs {
+    HitList hits;
+    unsigned int n_chunks;          // chunks of 64 records per pass: n_regions * region_slots / 64
+    unsigned int *chunk_cursor;     // device: tickets handed out beyond the waves' own chunks (zero at launch)
+    // streams_split_kernel only
+    int passes, samples_per_pass;   // a pixel's samples are cut into `passes` items of this many samples (the last one shorter)
+    const uint4 *seed_snapshots;    // [passes][n_px]: the seed sample (pass * samples_per_pass) of a pixel starts from
+    unsigned int n_px;
+    RayQueue out;                   // overflow stream: children that found the wave's ring full
+    unsigned int *out_count;        // device: reservation cursor of `out`, zero at launch
+    unsigned int out_base;
+    unsigned int *emitted;
+    unsigned int *stats;
+    int may_emit;
 };
 
-hipError_t launch_streams_level(const RenderArgs &a, const LevelArgs &lv, bool first, unsigned int grid, hipStream_t stream);
-hipError_t launch_streams_primary(const RenderArgs &a, HitList hits, unsigned int *counters, hipStream_t stream);
+hipError_t launch_streams_pixels(const RenderArgs &a, const ItemArgs &it, unsigned int grid, hipStream_t stream);
+hipError_t launch_streams_split(const RenderArgs &a, const ItemArgs &it, unsigned int grid, hipStream_t stream);
+int streams_pixels_waves();           // waves per SIMD the item kernels are built for (persistent grids)
+int streams_split_waves();
+unsigned int streams_regions(int width, int rows_local);    // regions of the start-hit list
+hipError_t launch_streams_seeds(Planes p, uint4 *snapshots, long long n, int passes, int samples_per_pass, int draws, hipStream_t stream);
+hipError_t launch_streams_level(const RenderArgs &a, const LevelArgs &lv, unsigned int grid, hipStream_t stream);
+// advance_missed: updateSeeds a pixel without start hits receives here (the ordered item kernel advances the others itself)
+hipError_t launch_streams_primary(const RenderArgs &a, HitList hits, unsigned int *counters, int advance_missed, hipStream_t stream);
 unsigned int streams_first_block();   // output slots every wave of a level owns from the start
-hipError_t launch_streams_update_seed(Planes p, long long n, int draws, hipStream_t stream);
 
 hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t stream);
 hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t stream);

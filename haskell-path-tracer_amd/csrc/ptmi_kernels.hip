@@ -1660,31 +1660,35 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
 }
 
 // ---------------------------------------------------------------------------------------
-// render Streams as a stream, the kernels.  One launch per LEVEL of the ray tree; a level's input is a compacted stream
-// in HBM -- level 0: the cached primary HITS of the pixels (streams_primary_kernel: every sample of a pixel shoots the
-// same primary ray, Trace.hs:244-262, so its checkHit + hit are evaluated once per render call, and pixels whose primary
-// ray misses never enter a stream), later levels: the ray states of the children that could not stay in a lane.
-//   * persistent waves: wave w takes the 64-item chunks w, w + G, w + 2G, ... of the input (static striding: every
-//     wave sees the whole image, no hand-out atomics);
-//   * a lane follows its ray's LINEAGE: a Matte / Glossy hit spawns one child, which simply is the lane's next ray; at
-//     a GLASS hit (two children) the reflection stays in the lane and only the refraction goes to the output stream;
-//   * loop shape [finish dead hits][next piece of work][refill][shade][trace].  A hit whose ray arrived with near-zero
-//     throughput (numNewRays = 0, Trace.hs:329-331) adds its emittance in the trip's first block and ends the lineage, so
-//     every lane that enters the shade round is alive, and a lineage that ends that way costs one shade and one trace per
-//     trip; every "lineage over" site only sets a flag and the block that fetches the lane's next piece of work (IN_LANE:
-//     its next sample) is expanded once;
-//   * REFILL: when a lineage ends the lane takes the next unprocessed item of the wave's current chunk -- ballot of the
-//     idle lanes + popcount prefix for the rank -- so the rounds run dense although lineages differ in length (round 1's
-//     step kernel idled until the slowest of 64 lineages had ended);
-//   * `expand` (Trace.hs:284-289) = wave-level compaction into the output stream: ballot of the lanes that emit a
-//     child, popcount prefix for the slot, space reserved a BLOCK at a time (the first block of every wave is static,
-//     later ones cost one atomic per 256 children: a single counter word serves only ~90 requests/us).  What is left
-//     of a wave's last block is marked as holes, which the next level skips;
-//   * `permute (+)` (Trace.hs:179-184) = float atomics into the colour planes (exact zeros are skipped).  Without
-//     GLASS a pixel has ONE lineage per launch, hence one adder per colour word in a defined order: bit-identical to
-//     the per-pixel kernel and the oracle.  With GLASS the order of a pixel's additions is undefined, as in Accelerate.
+// render Streams as a stream ("wavefront" form), the kernels.
+//
+//   streams_primary_kernel   every sample of a pixel shoots the same primary ray (Trace.hs:244-262), so its checkHit + hit are
+//                            evaluated ONCE per render call; the hits the samples start from go into the start-hit list, in
+//                            regions of one 64-pixel tile each, compacted inside the wave by ballot + popcount prefix (HitList);
+//                            pixels whose primary ray misses never enter a stream.
+//   streams_pixels_kernel    scenes whose rays never split (and PTMI_OPT_STREAM_BATCH = 0): one launch, persistent waves take
+//                            the regions as chunks (the first gridDim statically, later ones by ticket), a lane takes a start
+//                            hit and renders ALL samples of its pixel from it, colour and seed in registers -- read once,
+//                            written once, no atomics, additions in sample order: bit-identical to the per-pixel kernel and
+//                            the oracle under both seed rules.  `expand` (Trace.hs:284-289) with numNewRays in {0, 1} is "the
+//                            child is the lane's next ray"; a lane whose pixel is done REFILLS from the wave's chunk (ballot of
+//                            the idle lanes + popcount prefix), so the rounds stay dense although pixels differ in cost.
+//   streams_split_kernel     scenes with a ray-splitting material (the build-defined GLASS), or samples cut into unordered
+//                            items (PTMI_OPT_STREAM_BATCH): the same persistent shape; an item is (start hit, a range of the
+//                            pixel's samples).  At a GLASS hit the reflection stays in the lane and the refraction goes into the
+//                            wave's CHILD RING in LDS -- `expand` as wave-level compaction: ballot of the emitting lanes,
+//                            popcount prefix for the slot -- from which lanes that have no ray take their next one (ballot +
+//                            prefix again) before they start their item's next sample.  Nearly every child is traced by the
+//                            wave that emitted it, in the same launch; only when the ring is full does a child travel through
+//                            the overflow stream in HBM (blocks of slots reserved per wave, one atomic per 256 children).
+//                            `permute (+)` (Trace.hs:179-184): a lane's own lineages add into its LDS accumulator, flushed with
+//                            one float atomic per colour word per item; rays taken from the ring add with float atomics (exact
+//                            zeros skipped).  The order of a pixel's additions is undefined, as in Accelerate's permute.
+//   streams_level_kernel     the overflow levels: one launch per level of what is left in the HBM stream (usually nothing).
+//   streams_seeds_kernel     updateSeed (Trace.hs:190-191) for every pixel and sample of the call, with the seed each item
+//                            starts from recorded on the way (split kernel only).
 // Every ray carries its step index (the `awhile` iteration it belongs to), so the safety cap cuts the same rays as in
-// the other forms; cut rays, dropped children (output stream full) and emitted children are counted.
+// the other forms; cut rays, dropped children (overflow stream full) and emitted children are counted.
 // ---------------------------------------------------------------------------------------
 constexpr unsigned int kHole = 0xffffffffu;                  // pixel word of an unused output slot
 constexpr unsigned int kFirstBlock = 64, kNextBlock = 256;   // output slots a wave owns at start / reserves per atomic
@@ -1694,34 +1698,55 @@ constexpr unsigned int kFirstBlock = 64, kNextBlock = 256;   // output slots a w
 #ifndef PTMI_REFILL_BATCH
 #define PTMI_REFILL_BATCH 8
 #endif
-#ifndef PTMI_REFILL_BATCH_IN_LANE
-#define PTMI_REFILL_BATCH_IN_LANE 1
-#endif
-constexpr unsigned int kRefillBatch = PTMI_REFILL_BATCH;     // idle lanes a wave waits for before it runs the refill block
-constexpr unsigned int kRefillBatchInLane = PTMI_REFILL_BATCH_IN_LANE;
+constexpr unsigned int kRefillBatch = PTMI_REFILL_BATCH;     // overflow levels: idle lanes a wave waits for before it runs the refill block
 
-// Level 0's input: the hits the samples start from (HitList), compacted -- ballot + prefix per wave, one atomic per
-// workgroup.  The order of the list does not matter: a pixel's additions are ordered (one lineage) unless rays split.
+// How many lanes below this one are set in `mask`: v_mbcnt_lo/hi, no per-lane 64-bit mask to keep in registers.
+__device__ __forceinline__ unsigned int rank_in(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+}
+// Element `byte_off / 4` of a plane through a 32-bit byte offset (the stream form holds < 2^30 pixels): the access becomes
+// scalar base + 32-bit vector offset instead of a 64-bit address pair per plane.
+template <typename T> __device__ __forceinline__ T &plane_at(T *base, uint32_t byte_off)
+{
+    return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off);
+}
+
+// The start-hit list.  One workgroup = one quad of four x-adjacent 8x8 tiles (TILES) or 256 consecutive pixels, one wave
+// = one region.  Dispatch position p works on quad quad_order[p] (most expensive first, once costs are known), and its
+// regions are 4 p .. 4 p + 3: the list is in dispatch order, which is the order the item kernels hand the chunks out.
 // A glass primary hit is replaced by the first hits of its two children when that changes nothing observable: the
 // step cap cannot cut the children (>= 3) and the glass hit itself emits nothing (its emittance would have to be added
-// once per sample).  `counters`: the stream form's counter block (kLvHits, kLvSplitPixels, kLvDeepest).
-constexpr int kPrimaryBlock = 1024;   // one returning atomic per workgroup reserves its slots in the list: few, large workgroups
-__global__ void __launch_bounds__(kPrimaryBlock) streams_primary_kernel(const RenderArgs a, const HitList out, unsigned int *counters)
+// once per sample).  advance_missed: a pixel without start hits gets its updateSeeds here (streams_pixels_kernel does
+// the others' itself).  `counters`: the stream form's counter block (kLvSplitPixels, kLvDeepest).
+template <bool TILES>
+__global__ void __launch_bounds__(256) streams_primary_kernel(const RenderArgs a, const HitList out, unsigned int *counters, int advance_missed)
 {
-    __shared__ unsigned int wave_hits[kPrimaryBlock / 64];
-    __shared__ unsigned int block_base;
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     const float4 *S = a.scene.packed;                        // one evaluation per pixel and call: scalar loads will do
     const float4 *M = S + a.scene.geom_f4();
-    const long long n_local = (long long)a.rows_local * a.width;
-    const long long pixel = (long long)blockIdx.x * kPrimaryBlock + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned int position = blockIdx.x;
+    const unsigned int quad = (TILES && a.quad_order) ? a.quad_order[position] : position;
+    const unsigned int region = position * 4u + (unsigned int)wave;
+    long long pixel; bool valid;
+    if (TILES) {
+        const unsigned int tile = quad * 4u + (unsigned int)wave;
+        const int tiles_x = (a.width + 7) / 8;
+        const int tx = (int)(tile % (unsigned)tiles_x), ty = (int)(tile / (unsigned)tiles_x);
+        const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
+        pixel = (long long)y * a.width + x;
+        valid = x < a.width && y < a.rows_local;
+    } else {
+        pixel = (long long)region * 64 + lane;
+        valid = pixel < (long long)a.rows_local * a.width;
+    }
     int n_rec = 0;                                            // records this pixel contributes: 0, 1 or 2
     V3 pos[2], nor[2], dir[2], thr[2];
     int prim[2] = {0, 0};
     uint32_t meta[2] = {0u, 0u};
     bool split = false;
-    if (pixel < n_local) {
+    if (valid) {
         const int local_row = (int)(pixel / a.width);
         const int col = (int)(pixel - (long long)local_row * a.width);
         const V3 primary = primary_direction(a.cam, col, global_row(local_row, a.stripe_rows, a.n_parts, a.part));
@@ -1731,7 +1756,7 @@ __global__ void __launch_bounds__(kPrimaryBlock) streams_primary_kernel(const Re
             hit_record(S, ns, h.idx, a.cam.pos, primary, h.t, p0, n0);
             const float4 ma = M[2 * h.idx], mb = M[2 * h.idx + 1];
             const V3 emit = scale_r(mk(ma.x, ma.y, ma.z), ma.w) * mk(1.0f, 1.0f, 1.0f);
-            split = f2u(mb.x) == 2u && a.stream_step_cap >= 3 && emit.x == 0.0f && emit.y == 0.0f && emit.z == 0.0f;
+            split = out.region_slots > 64u && f2u(mb.x) == 2u && a.stream_step_cap >= 3 && emit.x == 0.0f && emit.y == 0.0f && emit.z == 0.0f;
             if (split) {
                 V3 ko[2], kd[2], kt[2]; Sfc32 ks[2]; Sfc32 dummy; dummy.a = dummy.b = dummy.c = dummy.counter = 0;
                 glass_children(mk(ma.x, ma.y, ma.z), mb.y, p0, n0, primary, mk(1.0f, 1.0f, 1.0f), dummy, ko, kd, kt, ks);
@@ -1746,67 +1771,100 @@ __global__ void __launch_bounds__(kPrimaryBlock) streams_primary_kernel(const Re
                         else        { pos[1] = hp; nor[1] = hn; dir[1] = rd; thr[1] = rt; prim[1] = hc.idx; meta[1] = 1u | ((3u + (unsigned int)k) << 8); }
                     }
                 }
+            } else if (out.region_slots == 64u) {
+                // streams_pixels_kernel's record: what every first shade of the pixel uses -- the axis and the half-angle scale
+                // of its bounce (the same operations on the same inputs, once per pixel) -- in the normal's and direction's place
+                V3 axis0; float hk0;
+                bounce_axis(mb, n0, primary, axis0, hk0);
+                pos[0] = p0; nor[0] = axis0; dir[0] = mk(hk0, 0.0f, 0.0f); thr[0] = mk(1.0f, 1.0f, 1.0f); prim[0] = h.idx; meta[0] = 0u;
+                n_rec = 1;
             } else {
                 pos[0] = p0; nor[0] = n0; dir[0] = primary; thr[0] = mk(1.0f, 1.0f, 1.0f); prim[0] = h.idx; meta[0] = 0u;
                 n_rec = 1;
             }
         }
+        if (advance_missed > 0 && n_rec == 0) {               // updateSeed is all a sample does to this pixel
+            Sfc32 sd; sd.a = a.planes.sa[pixel]; sd.b = a.planes.sb[pixel]; sd.c = a.planes.sc[pixel]; sd.counter = a.planes.sctr[pixel];
+            for (int j = 0; j < advance_missed; ++j) (void)random_float(sd);
+            a.planes.sa[pixel] = sd.a; a.planes.sb[pixel] = sd.b; a.planes.sc[pixel] = sd.c; a.planes.sctr[pixel] = sd.counter;
+        }
     }
     const unsigned long long m0 = __ballot(n_rec > 0), m1 = __ballot(n_rec > 1), ms = __ballot(split);
-    if (lane == 0) wave_hits[wave] = (unsigned int)(__builtin_popcountll(m0) + __builtin_popcountll(m1));
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int total = 0;
-        for (int w = 0; w < kPrimaryBlock / 64; ++w) total += wave_hits[w];
-        block_base = total ? atomicAdd(counters + kLvHits * kCounterStride, total) : 0u;
+    const unsigned int c0 = (unsigned int)__builtin_popcountll(m0), c1 = (unsigned int)__builtin_popcountll(m1);
+    if (lane == 0) {
+        out.counts[region] = c0 + c1;
+        if (ms) {
+            atomicAdd(counters + kLvSplitPixels * kCounterStride, (unsigned int)__builtin_popcountll(ms));
+            if (2u > __hip_atomic_load(counters + kLvDeepest * kCounterStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(counters + kLvDeepest * kCounterStride, 2u);       // the children's traceStep
+        }
     }
-    if (lane == 0 && ms) {
-        atomicAdd(counters + kLvSplitPixels * kCounterStride, (unsigned int)__builtin_popcountll(ms));
-        atomicMax(counters + kLvDeepest * kCounterStride, 2u);       // the children's traceStep
-    }
-    __syncthreads();
-    unsigned int slot = block_base;
-    for (int w = 0; w < wave; ++w) slot += wave_hits[w];
-    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned int slot0 = region * out.region_slots;
     for (int e = 0; e < 2; ++e) {
         if (n_rec > e) {
-            const unsigned int i = slot + (e == 0 ? (unsigned int)__builtin_popcountll(m0 & below)
-                                                  : (unsigned int)(__builtin_popcountll(m0) + __builtin_popcountll(m1 & below)));
+            const unsigned int i = slot0 + (e == 0 ? rank_in(m0) : c0 + rank_in(m1));
             const V3 p = e == 0 ? pos[0] : pos[1], n = e == 0 ? nor[0] : nor[1], dd = e == 0 ? dir[0] : dir[1], tt = e == 0 ? thr[0] : thr[1];
             float4 *r = out.record(i);
             r[0] = float4{p.x, p.y, p.z, n.x};
             r[1] = float4{n.y, n.z, dd.x, dd.y};
             r[2] = float4{dd.z, tt.x, tt.y, tt.z};
-            r[3] = float4{u2f((uint32_t)(e == 0 ? prim[0] : prim[1])), u2f((uint32_t)pixel), u2f(e == 0 ? meta[0] : meta[1]), 0.0f};
+            r[3] = float4{u2f((uint32_t)(e == 0 ? prim[0] : prim[1])), u2f((uint32_t)pixel), u2f(e == 0 ? meta[0] : meta[1]), u2f(quad)};
         }
     }
 }
 
-// level 0: a hit pixel (re)starts a sample from its cached primary hit
-__device__ __forceinline__ void load_cached_hit(const HitList &h, unsigned int i, V3 &pos, V3 &normal, V3 &dir, V3 &throughput,
-                                                int &idx, uint32_t &pixel, uint32_t &meta)
+// The chunk cursor of the item kernels.  A chunk is 64 slots of a region; ticket t stands for chunk t mod n_chunks of pass
+// t div n_chunks.  Wave w starts with ticket w; later tickets come from one returning atomic each (an item is tens to
+// thousands of loop trips).  Regions without records (tiles whose primary rays all miss) are skipped.
+struct ChunkCursor {
+    unsigned int ticket, taken, len, first, pass;
+};
+__device__ __forceinline__ void open_chunk(ChunkCursor &c, const ItemArgs &it, unsigned int n_total, unsigned int G)
 {
-    const float4 *r = h.record(i);
-    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
-    pos = mk(r0.x, r0.y, r0.z);
-    normal = mk(r0.w, r1.x, r1.y);
-    dir = mk(r1.z, r1.w, r2.x);
-    throughput = mk(r2.y, r2.z, r2.w);
-    idx = (int)f2u(r3.x); pixel = f2u(r3.y); meta = f2u(r3.z);
+    const unsigned int per = it.hits.region_slots >> 6;      // chunks per region: 1 or 2
+    for (;;) {
+        c.taken = 0; c.len = 0;
+        if (c.ticket >= n_total) return;
+        c.pass = c.ticket / it.n_chunks;
+        const unsigned int k = c.ticket - c.pass * it.n_chunks, region = k / per, half = k - region * per;
+        const unsigned int have = it.hits.counts[region];
+        c.first = region * it.hits.region_slots + half * 64u;
+        c.len = have > half * 64u ? (have - half * 64u < 64u ? have - half * 64u : 64u) : 0u;
+        if (c.len) return;
+        unsigned int t = 0;
+        if ((threadIdx.x & 63) == 0) t = G + atomicAdd(it.chunk_cursor, 1u);
+        c.ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+    }
+}
+__device__ __forceinline__ void next_chunk(ChunkCursor &c, const ItemArgs &it, unsigned int n_total, unsigned int G)
+{
+    unsigned int t = 0;
+    if ((threadIdx.x & 63) == 0) t = G + atomicAdd(it.chunk_cursor, 1u);
+    c.ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+    open_chunk(c, it, n_total, G);
 }
 
-// IN_LANE (level 0): a lane renders lv.samples_in_lane successive samples from its start hit before it refills -- the hit
-// and the sample's seed live in a lane-private LDS column -- and the waves take their chunks from a global counter (a chunk is
-// then ~100 loop trips: one atomic each is cheap, and a static share of 3 or 4 such chunks per wave would leave a quarter of
-// the chip idle at the end).  Without ray splitting that covers up to 64 samples with ONE adder per pixel, in sample order
-// (bit-identical to the per-pixel kernel); with GLASS the samples of a batch, whose refractions share the output stream.
-// Cursors count from zero (the host clears all of them once per batch): the reservation cursor is relative to lv.out_base,
-// the chunk cursor to the grid size.
-template <bool LDS_SCENE, bool FIRST, bool IN_LANE = false>
-__global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_kernel(const RenderArgs a, const LevelArgs lv)
+// what an item cost, for the dispatch order of later launches with the same key: loop trips the lane spent on it (or the
+// hits it shaded, one per trip), in units of 64
+__device__ __forceinline__ void record_item_cost(const RenderArgs &a, unsigned int quad, unsigned int trips)
 {
-    __shared__ uint32_t sample_seed[IN_LANE ? 4 : 1][kRenderBlock];   // IN_LANE: the seed the lane's current sample started from
-    __shared__ float lane_hit[IN_LANE ? 14 : 1][kRenderBlock];        // IN_LANE: the lane's start hit (position, normal, direction, primitive, throughput, meta)
+    if (a.quad_cost) atomicAdd(a.quad_cost + quad, (trips + 63u) >> 6);
+}
+
+// ---------------------------------------------------------------------------------------
+// streams_pixels_kernel: the stream form for scenes whose rays never split.  The loop is render_streams_kernel's
+// [finish dead rays][next sample][shade][trace] with a [refill] block in front: a lane whose pixel is done stores its
+// seven words and becomes idle; idle lanes take the next start hits of the wave's chunk.
+// ---------------------------------------------------------------------------------------
+#ifndef PTMI_PIXELS_WAVES
+#define PTMI_PIXELS_WAVES 7
+#endif
+template <bool LDS_SCENE>
+__global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixels_kernel(const RenderArgs a, const ItemArgs it)
+{
+    // the lane's item: 0-2 position of the start hit, 3-5 axis and 6 half-angle scale of its bounce, 7-10 the seed the sample's
+    // last hit carried (PTMI_SEED_FROM_RESULT), 11 primitive, 12 quad, 13 the lane's count of shaded hits when the item began
+    __shared__ float item_const[14][kRenderBlock];
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -1817,172 +1875,290 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
     const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
     const float4 *M = S + a.scene.geom_f4();
     const int lane = threadIdx.x & 63;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const unsigned int G = gridDim.x, w = blockIdx.x;
+    const unsigned int G = gridDim.x, n_total = it.n_chunks;
     const unsigned int step_cap = (unsigned int)a.stream_step_cap;
-
-    // input: level 0 = chunks_per_sample * batch chunks of <= 64 cached primary hits; later levels = ceil(n_in / 64) chunks
-    unsigned int n_in = *lv.in_count;                         // level 0: start hits; else the producer's cursor (real items and holes)
-    if (!FIRST) { n_in += lv.in_base; n_in = n_in < lv.in.capacity ? n_in : lv.in.capacity; }
-    const unsigned int cps = (n_in + 63u) / 64u;
-    const unsigned int n_chunks = FIRST ? cps * (unsigned int)lv.batch : cps;
-    auto next_chunk = [&](unsigned int current) __attribute__((always_inline)) -> unsigned int {
-        if (!IN_LANE) return current + G;                      // static stride
-        unsigned int c = 0;
-        if (lane == 0) c = G + atomicAdd(lv.chunk_cursor, 1u); // dynamic hand-out: the first G chunks are the waves' own
-        return (unsigned int)__builtin_amdgcn_readfirstlane((int)c);
+    const int n_spp = a.n_spp;
+    float *mine = &item_const[0][threadIdx.x];
+    auto put = [&](int k, float v) { mine[k * kRenderBlock] = v; };
+    auto get = [&](int k) { return mine[k * kRenderBlock]; };
+    auto note_hit_seed = [&](const Sfc32 &sd) {
+        if (a.seed_from_result) { put(7, u2f(sd.a)); put(8, u2f(sd.b)); put(9, u2f(sd.c)); put(10, u2f(sd.counter)); }
     };
-    unsigned int chunk = w, taken = 0;                       // wave-uniform cursor: chunk index, items of it already handed out
-    unsigned int blk = w * kFirstBlock, blk_end = blk + kFirstBlock;   // wave-uniform: the output block being filled
-    // wave-uniform description of the current chunk, recomputed only when the cursor moves to another chunk
-    unsigned int chunk_len = 0, chunk_j = 0, chunk_first = 0;
-    auto open_chunk = [&]() __attribute__((always_inline)) {
-        if (chunk >= n_chunks) { chunk_len = 0; return; }
-        chunk_j = FIRST ? chunk / cps : 0u;
-        chunk_first = (chunk - chunk_j * cps) * 64u;          // first item of the chunk within the sample / the stream
-        chunk_len = n_in - chunk_first < 64u ? n_in - chunk_first : 64u;
-    };
-    open_chunk();
 
-    bool has_ray = false, pending = false;                    // a ray to trace / a hit to shade
+    ChunkCursor cur; cur.ticket = blockIdx.x;
+    open_chunk(cur, it, n_total, G);
+
+    bool busy = false, pending = false, has_ray = false, over = false;
+    V3 acc = mk(0.0f, 0.0f, 0.0f), pos = acc, normal = acc, d = acc, throughput = acc;
+    Sfc32 pixel_seed; pixel_seed.a = pixel_seed.b = pixel_seed.c = pixel_seed.counter = 0;
+    Sfc32 seed = pixel_seed;
+    int idx = 0, s = 0;
+    uint32_t pixel4 = 0;                                      // byte offset of the lane's pixel in a plane
+    unsigned int steps = 0, longest = 0, live = 0;
+    for (;;) {
+        // ---- refill: idle lanes take the next start hits of the wave's chunk (at once: an item is a pixel's whole sample chain)
+        const unsigned long long idle = __ballot(!busy);
+        if (idle && cur.ticket < n_total) {                  // wave-uniform
+            const unsigned int want = (unsigned int)__builtin_popcountll(idle), avail = cur.len - cur.taken;
+            const unsigned int take = want < avail ? want : avail;
+            const unsigned int rank = rank_in(idle);
+            if (!busy && rank < take) {
+                const float4 *r = it.hits.record(cur.first + cur.taken + rank);
+                const float4 r0 = r[0], r1 = r[1], r3 = r[3];   // [position, axis x] [axis yz, half-angle scale, -] ... [primitive, pixel, -, quad]
+                pixel4 = f2u(r3.y) << 2;
+                put(0, r0.x); put(1, r0.y); put(2, r0.z);
+                put(3, r0.w); put(4, r1.x); put(5, r1.y); put(6, r1.z);
+                put(11, r3.x); put(12, r3.w); put(13, u2f(live));
+                acc = mk(plane_at(a.planes.r, pixel4), plane_at(a.planes.g, pixel4), plane_at(a.planes.b, pixel4));
+                pixel_seed.a = plane_at(a.planes.sa, pixel4); pixel_seed.b = plane_at(a.planes.sb, pixel4);
+                pixel_seed.c = plane_at(a.planes.sc, pixel4); pixel_seed.counter = plane_at(a.planes.sctr, pixel4);
+                s = -1; busy = true; over = true; pending = false; has_ray = false;
+            }
+            cur.taken += take;
+            if (cur.taken >= cur.len) next_chunk(cur, it, n_total, G);
+        }
+        if (!__any(busy) && cur.ticket >= n_total) break;      // (no lane busy, chunks left: nothing below has a lane to run for; the next trip refills)
+        float4 mb = M[2 * idx + 1];
+        V3 axis = mk(0.0f, 0.0f, 0.0f); float hk = 0.0f;
+        if (pending) {
+            // A ray whose throughput is already near zero dies at this hit (numNewRays, Trace.hs:329-331): the hit still
+            // adds its emittance (computeResult runs for every intersection) and nothing else of it survives.
+            if (near_zero(throughput)) {
+                const float4 ma = M[2 * idx];
+                acc = acc + (scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);
+                note_hit_seed(seed);
+                ++steps;
+                pending = false; over = true;
+            } else {
+                bounce_axis(mb, normal, d, axis, hk);
+            }
+        }
+        if (over) {
+            if (s >= 0) {                                      // a sample has been rendered
+                if (a.seed_from_result && steps > 0u) {        // combine new old: the seed the sample's last hit carried
+                    pixel_seed.a = f2u(get(7)); pixel_seed.b = f2u(get(8)); pixel_seed.c = f2u(get(9)); pixel_seed.counter = f2u(get(10));
+                }
+                (void)random_float(pixel_seed);                // updateSeed
+            }
+            ++s; steps = 0;
+            over = false;
+            if (s < n_spp) {                                   // the pixel's next sample, from its cached start hit
+                longest = longest > 1u ? longest : 1u;         // the primary ray's traceStep
+                seed = pixel_seed;
+                throughput = mk(1.0f, 1.0f, 1.0f);
+                pos = mk(get(0), get(1), get(2)); idx = (int)f2u(get(11));
+                mb = M[2 * idx + 1];
+                axis = mk(get(3), get(4), get(5)); hk = get(6);
+                pending = true;
+            } else {                                           // the pixel is done: its seven words, once
+                plane_at(a.planes.r, pixel4) = acc.x; plane_at(a.planes.g, pixel4) = acc.y; plane_at(a.planes.b, pixel4) = acc.z;
+                plane_at(a.planes.sa, pixel4) = pixel_seed.a; plane_at(a.planes.sb, pixel4) = pixel_seed.b;
+                plane_at(a.planes.sc, pixel4) = pixel_seed.c; plane_at(a.planes.sctr, pixel4) = pixel_seed.counter;
+                record_item_cost(a, f2u(get(12)), live - f2u(get(13)));       // its shaded hits stand for the loop trips it took
+                busy = false;
+            }
+        }
+        if (pending) {                                         // alive (a fresh sample starts with throughput 1)
+            const bool capped = steps + 1u >= step_cap;
+            note_hit_seed(seed);
+            // results: colour += emittance * throughput for EVERY hit; then the new ray (shade, with the axis in hand)
+            V3 next; float brdf;
+            next_about_axis(mb, axis, hk, seed, next, brdf);
+            apply_bounce(M, idx, pos, next, brdf, pos, d, throughput, acc);
+            ++steps; ++live;                                   // the child exists even if the cap then cuts it
+            pending = false;
+            if (capped) {                                      // rare: only when the safety cap bites
+                over = true;
+                const unsigned long long cm = __ballot(1);
+                if (lane == (int)__builtin_ctzll(cm)) atomicAdd(a.stream_counters + kScTruncated, (unsigned long long)__builtin_popcountll(cm));
+            } else has_ray = true;
+        }
+        if (has_ray) {
+            longest = steps + 1u > longest ? steps + 1u : longest;     // the traceStep this ray belongs to
+            const HitSel h = check_hit(S, ns, np, pos, d);
+            has_ray = false;
+            if (h.just) {
+                hit_record(S, ns, h.idx, pos, d, h.t, pos, normal);
+                idx = h.idx;
+                pending = true;
+            } else {
+                over = true;
+            }
+        }
+    }
+    // statistics: the per-pixel kernels' sharded counters
+    for (int off = 32; off > 0; off >>= 1) { const unsigned int other = __shfl_xor(longest, off, 64); longest = other > longest ? other : longest; }
+    const unsigned long long live_total = wave_sum(live);
+    if (lane == 0) {
+        if (a.live_counter && live_total) atomicAdd(a.live_counter + (size_t)(blockIdx.x & (kStatShards - 1)) * kStatStride, live_total);
+        if (a.stream_iterations && longest) atomicMax(a.stream_iterations + (size_t)(blockIdx.x & (kStatShards - 1)) * (2 * kStatStride), longest);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// streams_split_kernel: items of (start hit, sample range), a child ring per wave.  Loop shape
+// [finish dead hits][refill items][next ray: ring, else the item's next sample][shade][expand][trace].
+// ---------------------------------------------------------------------------------------
+#ifndef PTMI_SPLIT_WAVES
+#define PTMI_SPLIT_WAVES 5
+#endif
+#ifndef PTMI_RING
+#define PTMI_RING 16
+#endif
+constexpr unsigned int kRing = PTMI_RING;                     // records of a wave's child ring (a power of two, <= 64)
+template <bool LDS_SCENE, bool TILES>
+__global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_kernel(const RenderArgs a, const ItemArgs it)
+{
+    // the lane's own item: 0-2 position of the start hit, 3-5 normal, 6-8 incoming direction, 9-11 throughput,
+    // 12 primitive | meta << 16, 13 pixel, 14-17 the seed its next sample starts from, 18 the wave's trip count when it began
+    __shared__ float item_rec[19][kRenderBlock];
+    __shared__ float item_acc[3][kRenderBlock];               // what the lane's own lineages have added for the item's pixel
+    __shared__ float4 ring[4][kRing];                         // children waiting for a lane (RayQueue's record layout)
+    extern __shared__ float4 lds_scene[];
+    const int ns = a.scene.n_spheres, np = a.scene.n_planes;
+    if (LDS_SCENE) {
+        const int total = a.scene.total_f4();
+        for (int i = threadIdx.x; i < total; i += kRenderBlock) lds_scene[i] = a.scene.packed[i];
+        __syncthreads();
+    }
+    const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
+    const float4 *M = S + a.scene.geom_f4();
+    const int lane = threadIdx.x & 63;
+    const unsigned int G = gridDim.x, w = blockIdx.x;
+    const unsigned int n_total = it.n_chunks * (unsigned int)it.passes;
+    const unsigned int step_cap = (unsigned int)a.stream_step_cap;
+    float *mine = &item_rec[0][threadIdx.x];
+    auto put = [&](int k, float v) { mine[k * kRenderBlock] = v; };
+    auto get = [&](int k) { return mine[k * kRenderBlock]; };
+
+    ChunkCursor cur; cur.ticket = w;
+    open_chunk(cur, it, n_total, G);
+    unsigned int ring_head = 0, ring_n = 0;                   // wave-uniform
+    unsigned int blk = w * kFirstBlock, blk_end = blk + kFirstBlock;   // wave-uniform: the overflow block being filled
+
+    bool busy = false, foreign = false, has_ray = false, pending = false;   // own item in hand / the ray came from the ring / a ray to trace / a hit to shade
     V3 o = mk(0, 0, 0), d = o, throughput = o, normal = o;    // o: the ray's origin, or the position of the pending hit
     Sfc32 seed; seed.a = seed.b = seed.c = seed.counter = 0;
-    uint32_t pixel = 0, depth = 0, hits = 0;                  // depth: step index of the lane's current ray; hits: FROM_RESULT only (never IN_LANE)
-    int idx = 0;
-    unsigned int sample_j = 0;                                // IN_LANE: which of its pixel's samples the lane is rendering
+    uint32_t pixel = 0, depth = 0;                            // depth: step index of the lane's current ray
+    int idx = 0, samples_left = 0;
     unsigned int deepest = 0;
-    unsigned int live_w = 0, cut_w = 0, dropped_w = 0, stored_w = 0;   // wave-uniform statistics (scalar registers: the lanes' are scarce)
+    unsigned int live_w = 0, cut_w = 0, dropped_w = 0, stored_w = 0, trips_w = 0;   // wave-uniform statistics
 
-    // combine new old (PTMI_SEED_FROM_RESULT; never with GLASS): the seed the lineage's last hit carried = the pixel's
-    // seed + 3 draws per earlier hit, written back so that updateSeed advances the survivor
-    // Returns whether the lane holds a hit to shade again (IN_LANE: its next sample); the callers set the flags -- a closure
-    // that captured `has_ray` / `pending` by reference kept both in scratch memory.
-    auto lineage_ended = [&]() __attribute__((always_inline)) -> bool {
-        if (IN_LANE && sample_j + 1u < (unsigned int)lv.samples_in_lane) {
-            // Without ray splitting a pixel has one lineage per sample: the lane goes on with the pixel's next sample, so that
-            // one lane adds to the pixel in sample order (bit-identical to the per-pixel kernel) and a launch is long enough
-            // to pay for its start and drain.  updateSeed (Trace.hs:190-191): the next sample starts one draw further.
-            ++sample_j;
-            Sfc32 ss; ss.a = sample_seed[0][threadIdx.x]; ss.b = sample_seed[1][threadIdx.x]; ss.c = sample_seed[2][threadIdx.x]; ss.counter = sample_seed[3][threadIdx.x];
-            (void)random_float(ss);
-            sample_seed[0][threadIdx.x] = ss.a; sample_seed[1][threadIdx.x] = ss.b; sample_seed[2][threadIdx.x] = ss.c; sample_seed[3][threadIdx.x] = ss.counter;
-            seed = ss;
-            o = mk(lane_hit[0][threadIdx.x], lane_hit[1][threadIdx.x], lane_hit[2][threadIdx.x]);
-            normal = mk(lane_hit[3][threadIdx.x], lane_hit[4][threadIdx.x], lane_hit[5][threadIdx.x]);
-            d = mk(lane_hit[6][threadIdx.x], lane_hit[7][threadIdx.x], lane_hit[8][threadIdx.x]);
-            idx = (int)f2u(lane_hit[9][threadIdx.x]);
-            throughput = mk(lane_hit[10][threadIdx.x], lane_hit[11][threadIdx.x], lane_hit[12][threadIdx.x]);
-            const uint32_t meta = f2u(lane_hit[13][threadIdx.x]);
-            for (uint32_t q = 0; q < (meta >> 8); ++q) (void)sfc32_next(seed);          // the draws its ray's ancestors made
-            depth = meta & 0xffu;
-            return true;
-        }
-        if (!IN_LANE && a.seed_from_result && hits > 0u) {
-            Sfc32 sd; sd.a = a.planes.sa[pixel]; sd.b = a.planes.sb[pixel]; sd.c = a.planes.sc[pixel]; sd.counter = a.planes.sctr[pixel];
-            for (unsigned int k = 3u; k < 3u * hits; ++k) (void)sfc32_next(sd);
-            a.planes.sa[pixel] = sd.a; a.planes.sb[pixel] = sd.b; a.planes.sc[pixel] = sd.c; a.planes.sctr[pixel] = sd.counter;
-        }
-        return false;
-    };
     // computeResult + permute (+) (Trace.hs:179-184, :318-323); adding an exact zero changes nothing
     auto add_colour = [&](V3 c) __attribute__((always_inline)) {
-        if (c.x != 0.0f) atomicAdd(a.planes.r + pixel, c.x);
-        if (c.y != 0.0f) atomicAdd(a.planes.g + pixel, c.y);
-        if (c.z != 0.0f) atomicAdd(a.planes.b + pixel, c.z);
+        if (foreign) {
+            if (c.x != 0.0f) atomicAdd(&plane_at(a.planes.r, pixel << 2), c.x);
+            if (c.y != 0.0f) atomicAdd(&plane_at(a.planes.g, pixel << 2), c.y);
+            if (c.z != 0.0f) atomicAdd(&plane_at(a.planes.b, pixel << 2), c.z);
+        } else {
+            if (c.x != 0.0f) item_acc[0][threadIdx.x] += c.x;
+            if (c.y != 0.0f) item_acc[1][threadIdx.x] += c.y;
+            if (c.z != 0.0f) item_acc[2][threadIdx.x] += c.z;
+        }
     };
 
-    bool ended = false;                                       // the lane's lineage is over: lineage_ended runs at the top of the next trip
-#ifdef PTMI_LEVEL_STATS
-    unsigned int st_trips = 0, st_dead = 0, st_next = 0, st_shade = 0, st_glass = 0, st_trace = 0, st_refills = 0;   // wave-uniform (diagnostic build)
-#endif
     for (;;) {
-#ifdef PTMI_LEVEL_STATS
-        ++st_trips;
-        st_dead += (unsigned int)__builtin_popcountll(__ballot(pending && near_zero(throughput)));
-#endif
         // ---- a hit whose ray arrived with near-zero throughput (numNewRays = 0, Trace.hs:329-331) adds its emittance and nothing
-        // else of it survives: the lineage ends here, before the block that fetches the lane's next piece of work
+        // else of it survives: the lineage ends here
         if (pending && near_zero(throughput)) {
             const float4 ma = M[2 * idx];
-            if (!IN_LANE) ++hits;
             add_colour(scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);
-            pending = false; ended = true;
+            pending = false;
         }
-#ifdef PTMI_LEVEL_STATS
-        st_next += (unsigned int)__builtin_popcountll(__ballot(ended || (pending && near_zero(throughput))));
-#endif
-        if (ended) { pending = lineage_ended(); ended = false; }   // the one expansion of that block (IN_LANE: the lane's next sample)
-        // ---- refill: idle lanes take the next items of the wave's current chunk.  The block runs for the whole wave
-        // whenever it runs, so it waits until kRefillBatch lanes are idle -- or nothing else is in flight.  IN_LANE a lane
-        // keeps its item for many samples and refills are rare: it refills at once (S16: 6.2 -> 5.3 ms; batches of 2, 4 and 8 equal).
-        const unsigned long long idle = __ballot(!has_ray && !pending);
-        constexpr unsigned int refill_batch = IN_LANE ? kRefillBatchInLane : kRefillBatch;
-        if (chunk < n_chunks && ((unsigned int)__builtin_popcountll(idle) >= refill_batch || (idle && !~idle))) {   // wave-uniform
-#ifdef PTMI_LEVEL_STATS
-            ++st_refills;
-#endif
-            const unsigned int want = (unsigned int)__builtin_popcountll(idle), avail = chunk_len - taken;
+        // ---- refill: lanes without an item take the next ones of the wave's chunk (whatever ray they are tracing meanwhile)
+        const unsigned long long empty = __ballot(!busy);
+        if (empty && cur.ticket < n_total) {                  // wave-uniform
+            const unsigned int want = (unsigned int)__builtin_popcountll(empty), avail = cur.len - cur.taken;
             const unsigned int take = want < avail ? want : avail;
-            const unsigned int rank = (unsigned int)__builtin_popcountll(idle & below);
-            if (!has_ray && !pending && rank < take) {
-                const unsigned int i = chunk_first + taken + rank;
-                if (FIRST) {
-                    // initialState (Trace.hs:158-162) one step on: the pixel's cached primary hit; sample j of the batch
-                    // starts from the pixel's seed advanced by j draws, which is what j updateSeeds leave (Trace.hs:190-191)
-                    uint32_t meta;
-                    load_cached_hit(lv.hits, i, o, normal, d, throughput, idx, pixel, meta);
-                    seed.a = a.planes.sa[pixel]; seed.b = a.planes.sb[pixel]; seed.c = a.planes.sc[pixel]; seed.counter = a.planes.sctr[pixel];
-                    for (unsigned int q = 0; q < chunk_j; ++q) (void)random_float(seed);
-                    if (IN_LANE) {
-                        sample_j = 0;
-                        sample_seed[0][threadIdx.x] = seed.a; sample_seed[1][threadIdx.x] = seed.b; sample_seed[2][threadIdx.x] = seed.c; sample_seed[3][threadIdx.x] = seed.counter;
-                    }
-                    for (uint32_t q = 0; q < (meta >> 8); ++q) (void)sfc32_next(seed);      // the draws its ray's ancestors made
-                    if (IN_LANE) {
-                        lane_hit[0][threadIdx.x] = o.x; lane_hit[1][threadIdx.x] = o.y; lane_hit[2][threadIdx.x] = o.z;
-                        lane_hit[3][threadIdx.x] = normal.x; lane_hit[4][threadIdx.x] = normal.y; lane_hit[5][threadIdx.x] = normal.z;
-                        lane_hit[6][threadIdx.x] = d.x; lane_hit[7][threadIdx.x] = d.y; lane_hit[8][threadIdx.x] = d.z;
-                        lane_hit[9][threadIdx.x] = u2f((uint32_t)idx);
-                        lane_hit[10][threadIdx.x] = throughput.x; lane_hit[11][threadIdx.x] = throughput.y; lane_hit[12][threadIdx.x] = throughput.z;
-                        lane_hit[13][threadIdx.x] = u2f(meta);
-                    }
-                    depth = meta & 0xffu; hits = 0; pending = true;   // (a start hit of a dead ray -- a reflection of weight ~0 -- waits for the next trip's first block)
-                    deepest = deepest > 1u ? deepest : 1u;    // the primary ray's traceStep
-                } else {
-                    const float4 *r = lv.in.record(i);
-                    const float4 r2 = r[2];
-                    pixel = f2u(r2.y);
-                    if (pixel != kHole) {
-                        const float4 r0 = r[0], r1 = r[1], r3 = r[3];
-                        o = mk(r0.x, r0.y, r0.z);
-                        d = mk(r0.w, r1.x, r1.y);
-                        throughput = mk(r1.z, r1.w, r2.x);
-                        seed.a = f2u(r2.z); seed.b = f2u(r2.w); seed.c = f2u(r3.x); seed.counter = f2u(r3.y);
-                        depth = f2u(r3.z); hits = 0; has_ray = true;
-                    }
-                }
+            const unsigned int rank = rank_in(empty);
+            if (!busy && rank < take) {
+                const float4 *r = it.hits.record(cur.first + cur.taken + rank);
+                const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+                const uint32_t px = f2u(r3.y);
+                // initialState (Trace.hs:158-162) one step on: the cached start hit; the item's first sample starts from the
+                // pixel's seed advanced by (pass * samples_per_pass) draws, which is what that many updateSeeds leave
+                const uint4 s0 = it.seed_snapshots[(size_t)cur.pass * it.n_px + px];
+                put(0, r0.x); put(1, r0.y); put(2, r0.z); put(3, r0.w); put(4, r1.x); put(5, r1.y);
+                put(6, r1.z); put(7, r1.w); put(8, r2.x); put(9, r2.y); put(10, r2.z); put(11, r2.w);
+                put(12, u2f(f2u(r3.x) | (f2u(r3.z) << 16))); put(13, r3.y);
+                put(14, u2f(s0.x)); put(15, u2f(s0.y)); put(16, u2f(s0.z)); put(17, u2f(s0.w)); put(18, u2f(trips_w));
+                item_acc[0][threadIdx.x] = 0.0f; item_acc[1][threadIdx.x] = 0.0f; item_acc[2][threadIdx.x] = 0.0f;
+                const int first_sample = (int)cur.pass * it.samples_per_pass;
+                samples_left = a.n_spp - first_sample < it.samples_per_pass ? a.n_spp - first_sample : it.samples_per_pass;
+                busy = true;
             }
-            taken += take;
-            if (taken >= chunk_len) { chunk = next_chunk(chunk); taken = 0; open_chunk(); }
+            cur.taken += take;
+            if (cur.taken >= cur.len) next_chunk(cur, it, n_total, G);
         }
-        if (!__any(has_ray || pending || ended)) {
-            if (chunk >= n_chunks) break;
-            continue;                                         // a chunk of holes: look at the next one
+        // ---- the next ray of every lane that holds neither a ray nor a hit: a child from the wave's ring first ...
+        const bool free_lane = !pending && !has_ray;
+        const unsigned long long free_m = __ballot(free_lane);
+        bool took = false;
+        if (ring_n && free_m) {                               // wave-uniform
+            const unsigned int want = (unsigned int)__builtin_popcountll(free_m);
+            const unsigned int take = want < ring_n ? want : ring_n;
+            const unsigned int rank = rank_in(free_m);
+            if (free_lane && rank < take) {
+                const unsigned int slot = (ring_head + rank) & (kRing - 1u);
+                const float4 r0 = ring[0][slot], r1 = ring[1][slot], r2 = ring[2][slot], r3 = ring[3][slot];
+                o = mk(r0.x, r0.y, r0.z);
+                d = mk(r0.w, r1.x, r1.y);
+                throughput = mk(r1.z, r1.w, r2.x);
+                pixel = f2u(r2.y);
+                seed.a = f2u(r2.z); seed.b = f2u(r2.w); seed.c = f2u(r3.x); seed.counter = f2u(r3.y);
+                depth = f2u(r3.z);
+                has_ray = true; foreign = true; took = true;
+            }
+            ring_head = (ring_head + take) & (kRing - 1u); ring_n -= take;
         }
+        // ---- ... else the next sample of its own item (its start hit and that sample's seed are in the lane's LDS column); an
+        // item without samples left is over: its colour goes to the planes, one atomic per word
+        if (free_lane && !took && busy) {
+            if (samples_left > 0) {
+                --samples_left;
+                o = mk(get(0), get(1), get(2));
+                normal = mk(get(3), get(4), get(5));
+                d = mk(get(6), get(7), get(8));
+                throughput = mk(get(9), get(10), get(11));
+                const uint32_t pm = f2u(get(12));
+                idx = (int)(pm & 0xffffu);
+                pixel = f2u(get(13));
+                Sfc32 ss; ss.a = f2u(get(14)); ss.b = f2u(get(15)); ss.c = f2u(get(16)); ss.counter = f2u(get(17));
+                seed = ss;
+                (void)random_float(ss);                        // updateSeed (Trace.hs:190-191): the next sample starts one draw further
+                put(14, u2f(ss.a)); put(15, u2f(ss.b)); put(16, u2f(ss.c)); put(17, u2f(ss.counter));
+                for (uint32_t q = 0; q < (pm >> 24); ++q) (void)sfc32_next(seed);          // the draws its ray's ancestors made
+                depth = (pm >> 16) & 0xffu;
+                deepest = deepest > 1u ? deepest : 1u;        // the primary ray's traceStep
+                pending = true; foreign = false;              // (a start hit of a dead ray -- a reflection of weight ~0 -- waits for the next trip's first block)
+            } else {
+                const uint32_t px = f2u(get(13));
+                const V3 c = mk(item_acc[0][threadIdx.x], item_acc[1][threadIdx.x], item_acc[2][threadIdx.x]);
+                if (c.x != 0.0f) atomicAdd(&plane_at(a.planes.r, px << 2), c.x);
+                if (c.y != 0.0f) atomicAdd(&plane_at(a.planes.g, px << 2), c.y);
+                if (c.z != 0.0f) atomicAdd(&plane_at(a.planes.b, px << 2), c.z);
+                if (TILES && a.quad_cost) {
+                    const unsigned int y = px / (unsigned int)a.width, x = px - y * (unsigned int)a.width;
+                    const unsigned int tile = (y >> 3) * (unsigned int)((a.width + 7) / 8) + (x >> 3);
+                    record_item_cost(a, tile >> 2, trips_w - f2u(get(18)));
+                }
+                busy = false;
+            }
+        }
+        // no lane holds a ray or a hit: every lane was free, so the ring is empty (64 free lanes would have emptied it) and no lane
+        // holds an item with samples left.  (With chunks left nothing below has a lane to run for and the next trip refills: a
+        // `continue` here would be a second back edge, and cost the loop its register allocation.)
+        if (!__any(has_ray || pending) && cur.ticket >= n_total && !__any(busy)) break;
+        ++trips_w;
 
         // ---- shade round, for the hits of rays that are alive (a dead one just fetched waits for the next trip's first block)
         bool emits = false;
         V3 ko = o, kd = o, kt = o; Sfc32 ks = seed;
         const bool alive = pending && !near_zero(throughput);
-#ifdef PTMI_LEVEL_STATS
-        st_shade += (unsigned int)__builtin_popcountll(__ballot(alive));
-        st_glass += (unsigned int)__builtin_popcountll(__ballot(alive && f2u(M[2 * idx + 1].x) == 2u));
-#endif
         live_w += (unsigned int)__builtin_popcountll(__ballot(alive));        // one child per shaded hit ...
         if (alive) {
             const float4 ma = M[2 * idx], mb = M[2 * idx + 1];
             V3 contribution;
-            if (!IN_LANE) ++hits;
             if (f2u(mb.x) == 2u) {                            // GLASS (extension): reflection stays, refraction is emitted
                 contribution = scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput;
                 V3 co[2], cd[2], ct[2]; Sfc32 cs[2];
@@ -1997,14 +2173,182 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
             add_colour(contribution);
             ++depth; pending = false; has_ray = true;          // the child: next traceStep, same lane
         }
-        // ---- expand: compaction of the emitted children into the output stream
-        const unsigned long long kids = lv.may_emit ? __ballot(emits) : 0ull;
+        // ---- expand: compaction of the emitted children into the wave's ring; what the ring cannot hold goes to the overflow stream
+        const unsigned long long kids = it.may_emit ? __ballot(emits) : 0ull;
         if (kids) {                                           // wave-uniform
-            const unsigned int cnt = (unsigned int)__builtin_popcountll(kids), rank = (unsigned int)__builtin_popcountll(kids & below);
+            const unsigned int cnt = (unsigned int)__builtin_popcountll(kids), rank = rank_in(kids);
             live_w += cnt;                                    // ... and a second one per GLASS hit
+            const unsigned int room_ring = kRing - ring_n;
+            const unsigned int to_ring = cnt < room_ring ? cnt : room_ring;
+            if (emits && rank < to_ring) {
+                const unsigned int slot = (ring_head + ring_n + rank) & (kRing - 1u);
+                ring[0][slot] = float4{ko.x, ko.y, ko.z, kd.x};
+                ring[1][slot] = float4{kd.y, kd.z, kt.x, kt.y};
+                ring[2][slot] = float4{kt.z, u2f(pixel), u2f(ks.a), u2f(ks.b)};
+                ring[3][slot] = float4{u2f(ks.c), u2f(ks.counter), u2f(depth), 0.0f};
+            }
+            ring_n += to_ring;
+            if (cnt > to_ring) {                              // the ring is full: the others travel through HBM
+                const unsigned int cnt2 = cnt - to_ring, rank2 = rank - to_ring;      // (rank2 is meaningful for rank >= to_ring only)
+                const bool spills = emits && rank >= to_ring;
+                const unsigned int room = blk_end - blk;
+                unsigned int slot = blk + rank2;
+                if (cnt2 > room) {                            // the block is full: one atomic reserves the next for the whole wave
+                    unsigned int fresh = 0;
+                    if (lane == 0) fresh = it.out_base + atomicAdd(it.out_count, kNextBlock);
+                    fresh = (unsigned int)__builtin_amdgcn_readfirstlane((int)fresh);
+                    if (rank2 >= room) slot = fresh + (rank2 - room);
+                    blk = fresh + (cnt2 - room); blk_end = fresh + kNextBlock;
+                } else {
+                    blk += cnt2;
+                }
+                const unsigned int lost = (unsigned int)__builtin_popcountll(__ballot(spills && slot >= it.out.capacity));
+                stored_w += cnt2 - lost; dropped_w += lost;
+                if (spills && slot < it.out.capacity) queue_store(it.out, slot, ko, kd, kt, pixel, ks, depth);   // depth: the child's step index
+            }
+        }
+        // ---- trace round: one traceStep (Trace.hs:272-294) for every lane that holds a ray
+        cut_w += (unsigned int)__builtin_popcountll(__ballot(has_ray && depth >= step_cap));
+        if (has_ray) {
+            if (depth >= step_cap) {                          // the safety cap (the reference has none): the ray exists, but is never traced
+                has_ray = false;
+            } else {
+                deepest = depth + 1u > deepest ? depth + 1u : deepest;
+                const HitSel h = check_hit(S, ns, np, o, d);
+                has_ray = false;
+                if (h.just) {
+                    hit_record(S, ns, h.idx, o, d, h.t, o, normal);
+                    idx = h.idx;
+                    pending = true;
+                }
+            }
+        }
+    }
+    // what is left of this wave's last overflow block: holes
+    if (it.may_emit) {
+        const unsigned int end = blk_end < it.out.capacity ? blk_end : it.out.capacity;
+        for (unsigned int i = blk + (unsigned int)lane; i < end; i += 64u) *it.out.pixel_word(i) = kHole;
+    }
+    // statistics: one set of atomics per wave, on counters sharded by workgroup
+    unsigned int deep = deepest;
+    for (int off = 32; off > 0; off >>= 1) { const unsigned int other = __shfl_xor(deep, off, 64); deep = other > deep ? other : deep; }
+    if (lane == 0) {
+        unsigned int *st = it.stats;
+        if (live_w) atomicAdd(st + (kLvLive + (w & (unsigned int)(kLvLiveShards - 1))) * kCounterStride, live_w);
+        if (stored_w) atomicAdd(it.emitted + (size_t)(w & (unsigned int)(kLvEmitShards - 1)) * kCounterStride, stored_w);
+        // a maximum: most waves find it already there (a plain load first; the atomic only when it would raise the word)
+        if (deep > __hip_atomic_load(st + kLvDeepest * kCounterStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(st + kLvDeepest * kCounterStride, deep);
+        if (cut_w) atomicAdd(st + kLvCut * kCounterStride, cut_w);
+        if (dropped_w) atomicAdd(st + kLvDropped * kCounterStride, dropped_w);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// streams_level_kernel: one overflow level.  Input: the stream the previous level (or the split kernel) wrote -- ray
+// states and holes; persistent waves take its 64-record chunks in a static stride; a lane follows its ray's lineage (at a
+// GLASS hit the reflection stays, the refraction goes to the output stream); lanes whose lineage has ended refill from
+// the wave's chunk in batches.  Colours through float atomics.
+// ---------------------------------------------------------------------------------------
+template <bool LDS_SCENE>
+__global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_kernel(const RenderArgs a, const LevelArgs lv)
+{
+    extern __shared__ float4 lds_scene[];
+    const int ns = a.scene.n_spheres, np = a.scene.n_planes;
+    if (LDS_SCENE) {
+        const int total = a.scene.total_f4();
+        for (int i = threadIdx.x; i < total; i += kRenderBlock) lds_scene[i] = a.scene.packed[i];
+        __syncthreads();
+    }
+    const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
+    const float4 *M = S + a.scene.geom_f4();
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned int G = gridDim.x, w = blockIdx.x;
+    const unsigned int step_cap = (unsigned int)a.stream_step_cap;
+
+    unsigned int n_in = *lv.in_count + lv.in_base;            // the producer's cursor (real items and holes)
+    n_in = n_in < lv.in.capacity ? n_in : lv.in.capacity;
+    const unsigned int n_chunks = (n_in + 63u) / 64u;
+    unsigned int chunk = w, taken = 0;                        // wave-uniform cursor: chunk index, items of it already handed out
+    unsigned int blk = w * kFirstBlock, blk_end = blk + kFirstBlock;   // wave-uniform: the output block being filled
+    unsigned int chunk_len = 0, chunk_first = 0;
+    auto open = [&]() __attribute__((always_inline)) {
+        if (chunk >= n_chunks) { chunk_len = 0; return; }
+        chunk_first = chunk * 64u;
+        chunk_len = n_in - chunk_first < 64u ? n_in - chunk_first : 64u;
+    };
+    open();
+
+    bool has_ray = false, pending = false;                    // a ray to trace / a hit to shade
+    V3 o = mk(0, 0, 0), d = o, throughput = o, normal = o;
+    Sfc32 seed; seed.a = seed.b = seed.c = seed.counter = 0;
+    uint32_t pixel = 0, depth = 0;
+    int idx = 0;
+    unsigned int deepest = 0;
+    unsigned int live_w = 0, cut_w = 0, dropped_w = 0, stored_w = 0;
+
+    auto add_colour = [&](V3 c) __attribute__((always_inline)) {
+        if (c.x != 0.0f) atomicAdd(a.planes.r + pixel, c.x);
+        if (c.y != 0.0f) atomicAdd(a.planes.g + pixel, c.y);
+        if (c.z != 0.0f) atomicAdd(a.planes.b + pixel, c.z);
+    };
+
+    for (;;) {
+        if (pending && near_zero(throughput)) {
+            const float4 ma = M[2 * idx];
+            add_colour(scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);
+            pending = false;
+        }
+        const unsigned long long idle = __ballot(!has_ray && !pending);
+        if (chunk < n_chunks && ((unsigned int)__builtin_popcountll(idle) >= kRefillBatch || (idle && !~idle))) {   // wave-uniform
+            const unsigned int want = (unsigned int)__builtin_popcountll(idle), avail = chunk_len - taken;
+            const unsigned int take = want < avail ? want : avail;
+            const unsigned int rank = (unsigned int)__builtin_popcountll(idle & below);
+            if (!has_ray && !pending && rank < take) {
+                const float4 *r = lv.in.record(chunk_first + taken + rank);
+                const float4 r2 = r[2];
+                pixel = f2u(r2.y);
+                if (pixel != kHole) {
+                    const float4 r0 = r[0], r1 = r[1], r3 = r[3];
+                    o = mk(r0.x, r0.y, r0.z);
+                    d = mk(r0.w, r1.x, r1.y);
+                    throughput = mk(r1.z, r1.w, r2.x);
+                    seed.a = f2u(r2.z); seed.b = f2u(r2.w); seed.c = f2u(r3.x); seed.counter = f2u(r3.y);
+                    depth = f2u(r3.z); has_ray = true;
+                }
+            }
+            taken += take;
+            if (taken >= chunk_len) { chunk += G; taken = 0; open(); }
+        }
+        if (!__any(has_ray || pending) && chunk >= n_chunks) break;     // (a chunk of holes: nothing below runs, the next trip looks at the next one)
+        bool emits = false;
+        V3 ko = o, kd = o, kt = o; Sfc32 ks = seed;
+        const bool alive = pending && !near_zero(throughput);
+        live_w += (unsigned int)__builtin_popcountll(__ballot(alive));
+        if (alive) {
+            const float4 ma = M[2 * idx], mb = M[2 * idx + 1];
+            V3 contribution;
+            if (f2u(mb.x) == 2u) {
+                contribution = scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput;
+                V3 co[2], cd[2], ct[2]; Sfc32 cs[2];
+                glass_children(mk(ma.x, ma.y, ma.z), mb.y, o, normal, d, throughput, seed, co, cd, ct, cs);
+                o = co[0]; d = cd[0]; throughput = ct[0]; seed = cs[0];
+                ko = co[1]; kd = cd[1]; kt = ct[1]; ks = cs[1];
+                emits = true;
+            } else {
+                contribution = mk(0.0f, 0.0f, 0.0f);
+                shade(M, idx, o, normal, o, d, throughput, contribution, seed);
+            }
+            add_colour(contribution);
+            ++depth; pending = false; has_ray = true;
+        }
+        const unsigned long long kids = lv.may_emit ? __ballot(emits) : 0ull;
+        if (kids) {
+            const unsigned int cnt = (unsigned int)__builtin_popcountll(kids), rank = (unsigned int)__builtin_popcountll(kids & below);
+            live_w += cnt;
             const unsigned int room = blk_end - blk;
             unsigned int slot = blk + rank;
-            if (cnt > room) {                                 // the block is full: one atomic reserves the next for the whole wave
+            if (cnt > room) {
                 unsigned int fresh = 0;
                 if (lane == 0) fresh = lv.out_base + atomicAdd(lv.out_count, kNextBlock);
                 fresh = (unsigned int)__builtin_amdgcn_readfirstlane((int)fresh);
@@ -2015,61 +2359,54 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
             }
             const unsigned int lost = (unsigned int)__builtin_popcountll(__ballot(emits && slot >= lv.out.capacity));
             stored_w += cnt - lost; dropped_w += lost;
-            if (emits && slot < lv.out.capacity) queue_store(lv.out, slot, ko, kd, kt, pixel, ks, depth);   // depth: the child's step index
+            if (emits && slot < lv.out.capacity) queue_store(lv.out, slot, ko, kd, kt, pixel, ks, depth);
         }
-        // ---- trace round: one traceStep (Trace.hs:272-294) for every lane that holds a ray
         cut_w += (unsigned int)__builtin_popcountll(__ballot(has_ray && depth >= step_cap));
-#ifdef PTMI_LEVEL_STATS
-        st_trace += (unsigned int)__builtin_popcountll(__ballot(has_ray));
-#endif
         if (has_ray) {
-            if (depth >= step_cap) {                          // the safety cap (the reference has none): the ray is in the stream, never traced
-                has_ray = false; ended = true;
+            if (depth >= step_cap) {
+                has_ray = false;
             } else {
                 deepest = depth + 1u > deepest ? depth + 1u : deepest;
                 const HitSel h = check_hit(S, ns, np, o, d);
-                if (!h.just) {
-                    has_ray = false; ended = true;
-                } else {
+                has_ray = false;
+                if (h.just) {
                     hit_record(S, ns, h.idx, o, d, h.t, o, normal);
                     idx = h.idx;
-                    has_ray = false; pending = true;
+                    pending = true;
                 }
             }
         }
     }
-    // what is left of this wave's last block: holes
     if (lv.may_emit) {
         const unsigned int end = blk_end < lv.out.capacity ? blk_end : lv.out.capacity;
         for (unsigned int i = blk + (unsigned int)lane; i < end; i += 64u) *lv.out.pixel_word(i) = kHole;
     }
-#ifdef PTMI_LEVEL_STATS
-    if (lane == 0 && a.work_counter) {                        // [20 + 8 k ...]: k = 0 level 0, 1 later levels
-        unsigned int *wc = a.work_counter + 20 + (FIRST ? 0 : 8);
-        atomicAdd(wc + 0, st_trips); atomicAdd(wc + 1, st_dead); atomicAdd(wc + 2, st_next); atomicAdd(wc + 3, st_shade);
-        atomicAdd(wc + 4, st_glass); atomicAdd(wc + 5, st_trace); atomicAdd(wc + 6, st_refills);
-    }
-#endif
-    // statistics: one set of atomics per wave, on counters sharded by workgroup
     unsigned int deep = deepest;
     for (int off = 32; off > 0; off >>= 1) { const unsigned int other = __shfl_xor(deep, off, 64); deep = other > deep ? other : deep; }
     if (lane == 0) {
         unsigned int *st = lv.stats;
         if (live_w) atomicAdd(st + (kLvLive + (w & (unsigned int)(kLvLiveShards - 1))) * kCounterStride, live_w);
         if (stored_w) atomicAdd(lv.emitted + (size_t)(w & (unsigned int)(kLvEmitShards - 1)) * kCounterStride, stored_w);
-        // a maximum: most waves find it already there (a plain load first; the atomic only when it would raise the word)
         if (deep > __hip_atomic_load(st + kLvDeepest * kCounterStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(st + kLvDeepest * kCounterStride, deep);
         if (cut_w) atomicAdd(st + kLvCut * kCounterStride, cut_w);
         if (dropped_w) atomicAdd(st + kLvDropped * kCounterStride, dropped_w);
     }
 }
 
-__global__ void __launch_bounds__(kBlock) streams_update_seed_kernel(Planes p, long long n, int draws)
+// updateSeed (Trace.hs:190-191) for every sample of the call: `draws` draws per pixel, and on the way the seed each of the
+// `passes` items of the pixel starts from (snapshots[pass][pixel]: the pixel's seed after pass * samples_per_pass draws).
+__global__ void __launch_bounds__(kBlock) streams_seeds_kernel(Planes p, uint4 *snapshots, long long n, int passes, int samples_per_pass, int draws)
 {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     Sfc32 s; s.a = p.sa[i]; s.b = p.sb[i]; s.c = p.sc[i]; s.counter = p.sctr[i];
-    for (int j = 0; j < draws; ++j) (void)random_float(s);                  // updateSeed (Trace.hs:190-191), once per sample
+    int done = 0;
+    for (int k = 0; k < passes; ++k) {
+        snapshots[(size_t)k * (size_t)n + (size_t)i] = uint4{s.a, s.b, s.c, s.counter};
+        const int upto = (k + 1) * samples_per_pass < draws ? (k + 1) * samples_per_pass : draws;
+        for (; done < upto; ++done) (void)random_float(s);
+    }
+    for (; done < draws; ++done) (void)random_float(s);
     p.sa[i] = s.a; p.sb[i] = s.b; p.sc[i] = s.c; p.sctr[i] = s.counter;
 }
 
@@ -2401,7 +2738,7 @@ hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t s
     if (n_local <= 0) return hipSuccess;
     const dim3 grid(blocks_for(n_local, kRenderBlock)), block(kRenderBlock);
     const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
-    hipError_t e = hipMemsetAsync(a.stream_iterations, 0, sizeof(unsigned int), stream);
+    hipError_t e = hipMemsetAsync(a.stream_iterations, 0, (size_t)kStatShards * 2 * kStatStride * sizeof(unsigned int), stream);   // every shard: the figure is per launch
     if (e != hipSuccess) return e;
     const bool scalar_scene = variant == 5 || variant == 6 || variant == 17 || lds > kMaxSceneLds;
     const bool tiles = variant == 4 || variant == 5 ? false : tiles_pay(a);      // 4 / 5 keep the row mapping (ablation)
@@ -2425,7 +2762,7 @@ hipError_t launch_render_streams_tree(const RenderArgs &a, int variant, hipStrea
     if (n_local <= 0) return hipSuccess;
     const dim3 grid(blocks_for(n_local, kRenderBlock)), block(kRenderBlock);
     const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
-    hipError_t e = hipMemsetAsync(a.stream_iterations, 0, sizeof(unsigned int), stream);
+    hipError_t e = hipMemsetAsync(a.stream_iterations, 0, (size_t)kStatShards * 2 * kStatStride * sizeof(unsigned int), stream);   // every shard: the figure is per launch
     if (e != hipSuccess) return e;
     const bool scalar_scene = variant == 5 || variant == 17 || lds > kMaxSceneLds;
     const bool tiles = variant == 4 || variant == 5 ? false : tiles_pay(a);
@@ -2443,39 +2780,68 @@ hipError_t launch_render_streams_tree(const RenderArgs &a, int variant, hipStrea
     return hipGetLastError();
 }
 
-hipError_t launch_streams_level(const RenderArgs &a, const LevelArgs &lv, bool first, unsigned int grid, hipStream_t stream)
+hipError_t launch_streams_level(const RenderArgs &a, const LevelArgs &lv, unsigned int grid, hipStream_t stream)
 {
     if (grid == 0) return hipSuccess;
     const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
-    const bool scalar_scene = lds > kMaxSceneLds;              // a scene too big for LDS at this occupancy: scalar loads
     const dim3 g(grid), b(kRenderBlock);
-    if (first && lv.samples_in_lane > 1) {
-        if (scalar_scene) hipLaunchKernelGGL((streams_level_kernel<false, true, true>), g, b, 0, stream, a, lv);
-        else              hipLaunchKernelGGL((streams_level_kernel<true, true, true>), g, b, lds, stream, a, lv);
-    } else if (first) {
-        if (scalar_scene) hipLaunchKernelGGL((streams_level_kernel<false, true>), g, b, 0, stream, a, lv);
-        else              hipLaunchKernelGGL((streams_level_kernel<true, true>), g, b, lds, stream, a, lv);
+    if (lds > kMaxSceneLds) hipLaunchKernelGGL((streams_level_kernel<false>), g, b, 0, stream, a, lv);      // a scene too big for LDS at this occupancy: scalar loads
+    else                    hipLaunchKernelGGL((streams_level_kernel<true>), g, b, lds, stream, a, lv);
+    return hipGetLastError();
+}
+
+hipError_t launch_streams_pixels(const RenderArgs &a, const ItemArgs &it, unsigned int grid, hipStream_t stream)
+{
+    if (grid == 0) return hipSuccess;
+    const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
+    const dim3 g(grid), b(kRenderBlock);
+    if (lds > kMaxSceneLds) hipLaunchKernelGGL((streams_pixels_kernel<false>), g, b, 0, stream, a, it);
+    else                    hipLaunchKernelGGL((streams_pixels_kernel<true>), g, b, lds, stream, a, it);
+    return hipGetLastError();
+}
+
+hipError_t launch_streams_split(const RenderArgs &a, const ItemArgs &it, unsigned int grid, hipStream_t stream)
+{
+    if (grid == 0) return hipSuccess;
+    const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
+    const dim3 g(grid), b(kRenderBlock);
+    const bool tiles = tiles_pay(a);
+    if (lds > kMaxSceneLds) {
+        if (tiles) hipLaunchKernelGGL((streams_split_kernel<false, true>), g, b, 0, stream, a, it);
+        else       hipLaunchKernelGGL((streams_split_kernel<false, false>), g, b, 0, stream, a, it);
     } else {
-        if (scalar_scene) hipLaunchKernelGGL((streams_level_kernel<false, false>), g, b, 0, stream, a, lv);
-        else              hipLaunchKernelGGL((streams_level_kernel<true, false>), g, b, lds, stream, a, lv);
+        if (tiles) hipLaunchKernelGGL((streams_split_kernel<true, true>), g, b, lds, stream, a, it);
+        else       hipLaunchKernelGGL((streams_split_kernel<true, false>), g, b, lds, stream, a, it);
     }
     return hipGetLastError();
 }
 
+int streams_pixels_waves() { return PTMI_PIXELS_WAVES; }
+int streams_split_waves() { return PTMI_SPLIT_WAVES; }
 unsigned int streams_first_block() { return kFirstBlock; }
 
-hipError_t launch_streams_primary(const RenderArgs &a, HitList hits, unsigned int *counters, hipStream_t stream)
+// regions of the start-hit list: one per 8x8 tile (padded as the tiled render kernels pad their grids), or one per 64
+// consecutive pixels for images too small for tiles, a multiple of four either way (a workgroup of the primary kernel makes four)
+unsigned int streams_regions(int width, int rows_local)
 {
-    const long long n = (long long)a.rows_local * a.width;
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(streams_primary_kernel, dim3(blocks_for(n, kPrimaryBlock)), dim3(kPrimaryBlock), 0, stream, a, hits, counters);
+    if (tiles_pay_dims(width, rows_local)) return quad_positions(width, rows_local) * 4u;
+    const unsigned long long n = (unsigned long long)width * (unsigned long long)rows_local;
+    return (unsigned int)((((n + 63ull) / 64ull) + 3ull) & ~3ull);
+}
+
+hipError_t launch_streams_primary(const RenderArgs &a, HitList hits, unsigned int *counters, int advance_missed, hipStream_t stream)
+{
+    if (hits.n_regions == 0) return hipSuccess;
+    const dim3 g(hits.n_regions / 4u), b(256);
+    if (tiles_pay(a)) hipLaunchKernelGGL((streams_primary_kernel<true>), g, b, 0, stream, a, hits, counters, advance_missed);
+    else              hipLaunchKernelGGL((streams_primary_kernel<false>), g, b, 0, stream, a, hits, counters, advance_missed);
     return hipGetLastError();
 }
 
-hipError_t launch_streams_update_seed(Planes p, long long n, int draws, hipStream_t stream)
+hipError_t launch_streams_seeds(Planes p, uint4 *snapshots, long long n, int passes, int samples_per_pass, int draws, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(streams_update_seed_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, p, n, draws);
+    hipLaunchKernelGGL(streams_seeds_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, p, snapshots, n, passes, samples_per_pass, draws);
     return hipGetLastError();
 }
 
