@@ -14,7 +14,7 @@ from . import _build
 from .world import CAMERA_DTYPE, PLANE_DTYPE, SPHERE_DTYPE, INLINE, STREAMS
 
 OPT_STREAMS_SEED_RULE, OPT_STREAM_STEP_CAP, OPT_STREAM_CAPACITY, OPT_STREAMS_FORM, OPT_STREAM_BATCH, OPT_SPP_CHUNKS = 1, 2, 3, 4, 5, 6
-SEED_KEEP_ACCUMULATOR, SEED_FROM_RESULT = 0, 1
+SEED_KEEP_ACCUMULATOR, SEED_FROM_RESULT, SEED_AUTO = 0, 1, 2
 FORM_AUTO, FORM_STREAM = 0, 1
 PTMI_OK, PTMI_EINVAL, PTMI_ENODEVICE, PTMI_EHIP, PTMI_ENOMEM, PTMI_ESTATE, PTMI_ELIMIT = 0, -1, -2, -3, -4, -5, -6
 
@@ -26,7 +26,7 @@ _f32p, _u32p, _i32p, _i64p, _vp = (C.POINTER(C.c_float), C.POINTER(C.c_uint32), 
 class Stats(C.Structure):
     _fields_ = [("live_bounces", C.c_uint64), ("nominal_bounces", C.c_uint64), ("samples", C.c_uint64),
                 ("last_render_ms", C.c_float), ("stream_iterations", C.c_uint32), ("stream_rays_dropped", C.c_uint64),
-                ("stream_rays_truncated", C.c_uint64)]
+                ("stream_rays_truncated", C.c_uint64), ("stream_rays_spilled", C.c_uint64)]
 
 
 SYMBOLS = {

@@ -75,14 +75,20 @@ struct ptmi_ctx {
     void *d_snapshots = nullptr;     // stream form, split kernel: the seed every item starts from
     size_t snapshot_bytes = 0;
     int cus = 0;                     // compute units of the device (persistent grids)
+    hipStream_t aux_stream = nullptr;   // stream form, ordered kernel: the second chain of launches runs here
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int opt_ordered_passes = 0;      // 0 = automatic (experiments: PTMI_ORDERED_PASSES in the environment)
     unsigned int *d_qcount = nullptr;
     uint64_t rays_dropped = 0;
     uint64_t rays_truncated = 0;
+    uint64_t rays_spilled = 0;       // stream form: children that found the wave's ring full and went through HBM
+    void *spill_block = nullptr;     // stream form: the waves' spill queues
+    size_t spill_capacity = 0;
     uint64_t live_host = 0;        // live rays counted on the host (wavefront path)
     unsigned long long *d_stream_counters = nullptr;   // kScWords device counters of the per-pixel Streams kernels
 
     // options of render Streams (ptmi_set_option)
-    int opt_seed_rule = PTMI_SEED_KEEP_ACCUMULATOR;
+    int opt_seed_rule = PTMI_SEED_AUTO;              // resolved per scene: effective_seed_rule()
     int opt_step_cap = kStreamStepCapDefault;
     int opt_capacity = 4;
     int opt_form = PTMI_FORM_AUTO;
@@ -107,6 +113,14 @@ int fail(ptmi_ctx *c, int code, const std::string &msg)
             return fail((c), e_ == hipErrorOutOfMemory ? PTMI_ENOMEM : PTMI_EHIP,           \
                         std::string(#call) + ": " + hipGetErrorString(e_));                \
     } while (0)
+
+// PTMI_SEED_AUTO: `combine new old` (the seed of the result) wherever the reference defines the outcome -- no ray-splitting
+// material -- and the accumulator's seed with GLASS, where several results of one step would race for it
+int effective_seed_rule(const ptmi_ctx *c)
+{
+    if (c->opt_seed_rule != PTMI_SEED_AUTO) return c->opt_seed_rule;
+    return c->has_glass ? PTMI_SEED_KEEP_ACCUMULATOR : PTMI_SEED_FROM_RESULT;
+}
 
 int effective_stripe(const ptmi_ctx *c) { return c->stripe_rows > 0 ? c->stripe_rows : (c->height > 0 ? c->height : 1); }
 
@@ -266,17 +280,58 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
     auto cursor_of = [&](int level) { return (size_t)(kLvCursor + kLvPerLevel * (level % kLvMaxLevels)) * kCounterStride; };
     ItemArgs it{};
     it.hits = hits;
-    it.n_chunks = n_regions * (region_slots / 64u);
-    it.chunk_cursor = c->d_qcount + cursor_of(0) + kCounterStride;
+    it.n_positions = n_regions / 4u;
+    it.n_chains = 1; it.chain = 0; it.passes = 1;
     it.n_px = (unsigned int)n;
     it.stats = c->d_qcount;
+    auto tickets_of = [&](int launch) { return c->d_qcount + (size_t)(kLvTickets + 8 * launch) * kCounterStride; };
     const int cus = c->cus > 0 ? c->cus : 256;
     if (ordered) {
+        // One lane renders a pixel's samples in order, so an item is a serial chain and the end of a launch is as long as its last
+        // items: with few items per lane (1080p: three) a quarter of the wave-time of ONE launch lay after the first wave had
+        // ended.  The samples are therefore cut into passes -- one launch each, a pixel's seven words travelling through the
+        // planes in between -- and the positions into two CHAINS that run on two streams: within a chain the passes follow each
+        // other in stream order (nothing else orders a pixel's samples), and while the last items of one chain's launch end, the
+        // waves of the other chain's launch take the slots they leave.
         PTMI_HIP(c, launch_streams_primary(a, hits, c->d_qcount, n_spp, c->stream));
         PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, kItersBytes, c->stream));
-        unsigned int grid = (unsigned int)(cus * 4 * streams_pixels_waves());
-        if (grid > it.n_chunks) grid = it.n_chunks;
-        PTMI_HIP(c, launch_streams_pixels(a, it, grid, c->stream));
+        // (measured, S16: 1080p / 64 spp 4.65 -> 4.53 ms with two passes, 4.59 with four -- every launch loads and stores all
+        // items once more; 4K / 64 spp, eighteen items per lane: 16.19 -> 16.33.  Passes pay where a lane sees few, long items.)
+        const unsigned int lanes = (unsigned int)(cus * 4 * streams_pixels_waves()) * 64u;
+        int passes = 1;
+        if (c->opt_ordered_passes > 0) passes = c->opt_ordered_passes;
+        else if (n < 4ull * lanes && n_spp >= 128) passes = n_spp / 64;
+        if (passes > 8) passes = 8;
+        if (passes > n_spp) passes = n_spp;
+        if (passes < 1) passes = 1;
+        const int chains = passes > 1 && it.n_positions >= 16u ? 2 : 1;
+        const unsigned int grid = (unsigned int)(cus * 4 * streams_pixels_waves());
+        if (chains > 1) {
+            if (!c->aux_stream) {
+                PTMI_HIP(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+                PTMI_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                PTMI_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            }
+            PTMI_HIP(c, hipEventRecord(c->ev_fork, c->stream));
+            PTMI_HIP(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+        }
+        const int per = n_spp / passes, extra = n_spp % passes;       // the first `extra` passes render one sample more
+        RenderArgs b = a;
+        for (int k = 0; k < passes; ++k) {
+            b.n_spp = per + (k < extra ? 1 : 0);
+            for (int ch = 0; ch < chains; ++ch) {
+                it.n_chains = chains; it.chain = ch;
+                it.chunk_cursor = tickets_of(k * chains + ch);
+                unsigned int g = grid;
+                const unsigned long long chunks = ((unsigned long long)it.n_positions * 4ull + (unsigned)chains - 1ull) / (unsigned)chains;
+                if (g > chunks) g = (unsigned int)(chunks < 1 ? 1 : chunks);
+                PTMI_HIP(c, launch_streams_pixels(b, it, g, ch == 0 ? c->stream : c->aux_stream));
+            }
+        }
+        if (chains > 1) {
+            PTMI_HIP(c, hipEventRecord(c->ev_join, c->aux_stream));
+            PTMI_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        }
         return PTMI_OK;
     }
 
@@ -295,8 +350,9 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
     }
     if (per_item > n_spp) per_item = n_spp;
     const int passes = (n_spp + per_item - 1) / per_item;
-    if ((unsigned long long)it.n_chunks * (unsigned long long)passes > 0x7fffffffull) return fail(c, PTMI_ELIMIT, "too many items for the stream form of Streams");
-    if (grid > it.n_chunks * (unsigned int)passes) grid = it.n_chunks * (unsigned int)passes;
+    const unsigned long long n_tickets = (unsigned long long)n_regions * (region_slots / 64u) * (unsigned long long)passes;
+    if (n_tickets > 0x7fffffffull) return fail(c, PTMI_ELIMIT, "too many items for the stream form of Streams");
+    if (grid > n_tickets) grid = (unsigned int)n_tickets;
     const size_t snap_bytes = (size_t)passes * n * sizeof(uint4);
     if (snap_bytes > c->snapshot_bytes) {
         PTMI_HIP(c, hipStreamSynchronize(c->stream));
@@ -319,12 +375,21 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
     }
     const size_t capacity = c->queue_capacity;
     const RayQueue q[2] = {carve_queue(c->queue_block, capacity, 0), carve_queue(c->queue_block, capacity, 1)};
+    const size_t spill_records = (size_t)grid * streams_spill_records();
+    if (spill_records > c->spill_capacity) {
+        PTMI_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->spill_block) { (void)hipFree(c->spill_block); c->spill_block = nullptr; c->spill_capacity = 0; }
+        PTMI_HIP(c, hipMalloc(&c->spill_block, (size_t)kRayQueueWords * spill_records * 4));
+        c->spill_capacity = spill_records;
+    }
     std::vector<unsigned int> base((size_t)kLvMaxLevels, 0u);   // per level (mod kLvMaxLevels): where its reserved blocks start
 
     PTMI_HIP(c, launch_streams_primary(a, hits, c->d_qcount, 0, c->stream));
     PTMI_HIP(c, launch_streams_seeds(a.planes, static_cast<uint4 *>(c->d_snapshots), (long long)n, passes, per_item, n_spp, c->stream));
     it.passes = passes; it.samples_per_pass = per_item;
+    it.chunk_cursor = tickets_of(0);
     it.seed_snapshots = static_cast<const uint4 *>(c->d_snapshots);
+    it.spill = carve_queue(c->spill_block, c->spill_capacity, 0);
     it.out = q[0];
     it.out_count = c->d_qcount + cursor_of(0);
     it.out_base = grid * first_block;
@@ -373,6 +438,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
     c->live_host += 2ull * raw[(size_t)kLvSplitPixels * kCounterStride] * (uint64_t)n_spp;
     c->rays_dropped += raw[(size_t)kLvDropped * kCounterStride];
     c->rays_truncated += raw[(size_t)kLvCut * kCounterStride];
+    c->rays_spilled += raw[(size_t)kLvSpilled * kCounterStride];
     unsigned int longest = raw[(size_t)kLvDeepest * kCounterStride];            // stream_iterations: the deepest step of this call
     if (longest == 0) longest = 1;                                              // every primary ray missed: one traceStep all the same
     PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, kItersBytes, c->stream));             // (sharded for the per-pixel kernels: shard 0 carries this form's figure)
@@ -394,7 +460,7 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
     a.stripe_rows = stripe_rows; a.n_parts = n_parts; a.part = part;
     a.bounce_limit = bounce_limit; a.n_spp = n_spp;
     a.live_counter = c->d_live; a.work_counter = c->d_work; a.stream_iterations = c->d_iters;
-    a.stream_step_cap = c->opt_step_cap; a.seed_from_result = c->opt_seed_rule == PTMI_SEED_FROM_RESULT;
+    a.stream_step_cap = c->opt_step_cap; a.seed_from_result = effective_seed_rule(c) == PTMI_SEED_FROM_RESULT;
     a.stream_counters = c->d_stream_counters;
     const bool stream_form = algorithm == PTMI_STREAMS && (c->opt_form == PTMI_FORM_STREAM || c->variant == 9);
     // Cost-ordered dispatch (ptmi_kernels.hip: lane_pixel): launches with one (camera, scene, shape, limit, algorithm)
@@ -403,7 +469,12 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
     const bool per_pixel_kernel = !stream_form;
     int next_order_state = c->order_state;
     // (the stream form orders its start-hit list the same way, under a key of its own; its items record their costs)
-    if (stream_form ? (quad_positions(width, rows_local) > 0 && !sx) : uses_quad_order(a, algorithm == PTMI_INLINE, c->variant)) {
+#ifdef PTMI_STREAM_NO_ORDER
+    const bool stream_order = false;
+#else
+    const bool stream_order = quad_positions(width, rows_local) > 0 && !sx;
+#endif
+    if (stream_form ? stream_order : uses_quad_order(a, algorithm == PTMI_INLINE, c->variant)) {
         const unsigned int n_quads = quad_positions(width, rows_local);
         if (n_quads > c->quad_capacity) {
             if (c->d_quad_cost) { PTMI_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_quad_cost); (void)hipFree(c->d_quad_order); (void)hipFree(c->d_quad_class); }
@@ -424,7 +495,7 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
         if (launches == 0) PTMI_HIP(c, hipMemsetAsync(c->d_quad_cost, 0, n_quads * sizeof(unsigned int), c->stream));
         else if ((launches & (launches - 1)) == 0 && launches < (1 << 20)) PTMI_HIP(c, launch_quad_order(c->d_quad_cost, c->d_quad_order, c->d_quad_class, n_quads, c->stream));
         if (launches > 0) a.quad_order = c->d_quad_order;
-        if (launches < (stream_form ? (1 << 12) : (1 << 20))) { a.quad_cost = c->d_quad_cost; next_order_state = launches + 1; }   // the sums stay far from 2^32
+        if (launches < (stream_form ? (1 << 11) : (1 << 20))) { a.quad_cost = c->d_quad_cost; next_order_state = launches + 1; }   // the sums stay far from 2^32
     }
     if (per_pixel_kernel) {
         // one word per tile workgroup for the sample chunks of the tiled per-pixel kernels (ptmi_kernels.hip)
@@ -506,6 +577,7 @@ int ptmi_create(ptmi_ctx **out, int device)
     ptmi_ctx *c = new (std::nothrow) ptmi_ctx;
     if (!c) return fail(nullptr, PTMI_ENOMEM, "host allocation failed");
     c->device = device;
+    if (const char *e = std::getenv("PTMI_ORDERED_PASSES")) c->opt_ordered_passes = std::atoi(e);
     auto bail = [&](hipError_t err, const char *what) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);
         ptmi_destroy(c);
@@ -548,6 +620,7 @@ void ptmi_destroy(ptmi_ctx *c)
     if (c->hit_block) (void)hipFree(c->hit_block);
     if (c->d_hit_counts) (void)hipFree(c->d_hit_counts);
     if (c->d_snapshots) (void)hipFree(c->d_snapshots);
+    if (c->spill_block) (void)hipFree(c->spill_block);
     if (c->d_qcount) (void)hipFree(c->d_qcount);
     if (c->d_quad_cost) (void)hipFree(c->d_quad_cost);
     if (c->d_quad_order) (void)hipFree(c->d_quad_order);
@@ -556,6 +629,9 @@ void ptmi_destroy(ptmi_ctx *c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_snap) (void)hipEventDestroy(c->ev_snap);
+    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -701,7 +777,7 @@ int ptmi_set_option(ptmi_ctx *c, int option, int64_t value)
     std::lock_guard<std::mutex> lock(c->mu);
     switch (option) {
     case PTMI_OPT_STREAMS_SEED_RULE:
-        if (value != PTMI_SEED_KEEP_ACCUMULATOR && value != PTMI_SEED_FROM_RESULT) return fail(c, PTMI_EINVAL, "unknown seed rule");
+        if (value != PTMI_SEED_KEEP_ACCUMULATOR && value != PTMI_SEED_FROM_RESULT && value != PTMI_SEED_AUTO) return fail(c, PTMI_EINVAL, "unknown seed rule");
         c->opt_seed_rule = (int)value; return PTMI_OK;
     case PTMI_OPT_STREAM_STEP_CAP:
         if (value < 1 || value > (1 << 30)) return fail(c, PTMI_EINVAL, "step cap must be in [1, 2^30]");
@@ -946,6 +1022,7 @@ int ptmi_get_stats(ptmi_ctx *c, ptmi_stats *out)
     out->stream_iterations = iters;
     out->stream_rays_dropped = c->rays_dropped + sc[kScDropped];
     out->stream_rays_truncated = c->rays_truncated + sc[kScTruncated];
+    out->stream_rays_spilled = c->rays_spilled;
     out->last_render_ms = 0.0f;
     if (c->timing && c->ev_valid) PTMI_HIP(c, hipEventElapsedTime(&out->last_render_ms, c->ev0, c->ev1));
     return PTMI_OK;
@@ -972,7 +1049,7 @@ int ptmi_reset_stats(ptmi_ctx *c)
     PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, kItersBytes, c->stream));
     PTMI_HIP(c, hipMemsetAsync(c->d_work, 0, 64 * sizeof(unsigned int), c->stream));
     PTMI_HIP(c, hipMemsetAsync(c->d_stream_counters, 0, kScWords * sizeof(unsigned long long), c->stream));
-    c->nominal = 0; c->samples = 0; c->rays_dropped = 0; c->rays_truncated = 0; c->live_host = 0;
+    c->nominal = 0; c->samples = 0; c->rays_dropped = 0; c->rays_truncated = 0; c->rays_spilled = 0; c->live_host = 0;
     return PTMI_OK;
 }
 

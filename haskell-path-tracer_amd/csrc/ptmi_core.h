@@ -220,6 +220,17 @@ PTMI_HD uint32_t sfc32_next(Sfc32 &s)
     s.c = ((s.c << 21) | (s.c >> 11)) + tmp;
     return tmp;
 }
+// The state sfc32_next came from: the step is a bijection of the 128-bit state (b -> b ^ (b >> 9) and c -> 9 c are invertible,
+// the rest is additions).  Used where a kernel needs the seed a ray carried BEFORE its hit's three draws and kept only the
+// one after them.
+PTMI_HD void sfc32_prev(Sfc32 &s)
+{
+    const uint32_t c = s.b * 0x38e38e39u;                    // 9^-1 mod 2^32
+    const uint32_t b = s.a ^ (s.a >> 9) ^ (s.a >> 18) ^ (s.a >> 27);
+    const uint32_t counter = s.counter - 1u;
+    const uint32_t tmp = s.c - ((c << 21) | (c >> 11));
+    s.a = tmp - b - counter; s.b = b; s.c = c; s.counter = counter;
+}
 // random @Float -> (0, 1]   (mwc-random wordToFloat)
 PTMI_HD float random_float(Sfc32 &s)
 {

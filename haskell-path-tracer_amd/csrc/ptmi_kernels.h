@@ -75,15 +75,17 @@ constexpr int kStreamStepCapDefault = 1 << 16;   // traceSteps per ray lineage; 
 // Counters of the stream form, each kCounterStride words (one cache line) apart; sums are sharded by workgroup, because one
 // word serves only ~90 atomics per microsecond and the 6 144 waves of a level end together:
 //   [kLvLive, +kLvLiveShards) children emitted | kLvCut rays cut by the step cap | kLvDropped children that found the output
-//   stream full | kLvDeepest deepest step + 1 | kLvHits start hits in the list | kLvSplitPixels pixels whose (glass) primary hit
+//   stream full | kLvDeepest deepest step + 1 | kLvSpilled children that went through HBM (spill queues, overflow stream) | kLvSplitPixels pixels whose (glass) primary hit
 //   was replaced by its children's hits | per level l, kLvPerLevel lines from kLvCursor + kLvPerLevel l:
 //     + 0: the reservation cursor of the stream level l WRITES, counted from the end of its waves' static blocks (grid * first
 //          block: LevelArgs.out_base / in_base; that sum = the item count, holes included, of the stream level l + 1 reads)
 //     + 1: level l's chunk hand-out | + 2 .. + 2 + kLvEmitShards: the children level l stored (shards)
 constexpr int kLvLiveShards = 64, kLvEmitShards = 8, kLvPerLevel = 2 + kLvEmitShards;
-constexpr int kLvLive = 0, kLvCut = kLvLiveShards, kLvDropped = kLvCut + 1, kLvDeepest = kLvCut + 2, kLvHits = kLvCut + 3, kLvSplitPixels = kLvCut + 4,
+constexpr int kLvLive = 0, kLvCut = kLvLiveShards, kLvDropped = kLvCut + 1, kLvDeepest = kLvCut + 2, kLvSpilled = kLvCut + 3, kLvSplitPixels = kLvCut + 4,
               kLvCursor = kLvCut + 5, kLvMaxLevels = 64;
-constexpr int kLvWords = (kLvCursor + kLvPerLevel * kLvMaxLevels) * kCounterStride;
+// ... and, behind the per-level lines, the ticket counters of the item kernels: eight (one per XCD queue) per launch of a call
+constexpr int kLvTickets = kLvCursor + kLvPerLevel * kLvMaxLevels, kLvMaxLaunches = 32;
+constexpr int kLvWords = (kLvTickets + 8 * kLvMaxLaunches) * kCounterStride;
 // The hits the samples of the held pixels START from, written once per render call (streams_primary_kernel), in REGIONS: one
 // region per 64-pixel tile of the image (a wave of the primary kernel: an 8x8 pixel tile, or 64 consecutive pixels of a row
 // for images too small for tiles), in the order the tiles are dispatched (most expensive quad of tiles first once costs
@@ -112,16 +114,19 @@ struct LevelArgs {
     int may_emit;                   // 0: the scene has no ray-splitting material -- nothing is ever written to `out`
 };
 // The item kernels of the stream form (streams_pixels_kernel, streams_split_kernel): persistent waves take the regions of the
-// start-hit list as chunks -- the first gridDim chunks are the waves' own, later ones come from a ticket counter.
+// start-hit list as chunks, by ticket, from eight queues (one per XCD; ChunkCursor in ptmi_kernels.hip).
 struct ItemArgs {
     HitList hits;
-    unsigned int n_chunks;          // chunks of 64 records per pass: n_regions * region_slots / 64
-    unsigned int *chunk_cursor;     // device: tickets handed out beyond the waves' own chunks (zero at launch)
+    unsigned int n_positions;       // groups of four regions (dispatch positions): hits.n_regions / 4
+    int n_chains, chain;            // this launch works on the positions p with (p / 8) mod n_chains == chain
+    int passes;                     // tickets run over the launch's chunks this many times (streams_split_kernel: sample ranges)
+    unsigned int *chunk_cursor;     // device: the launch's eight ticket counters, kCounterStride words apart, zero at launch
     // streams_split_kernel only
-    int passes, samples_per_pass;   // a pixel's samples are cut into `passes` items of this many samples (the last one shorter)
+    int samples_per_pass;           // a pixel's samples are cut into `passes` items of this many samples (the last one shorter)
     const uint4 *seed_snapshots;    // [passes][n_px]: the seed sample (pass * samples_per_pass) of a pixel starts from
     unsigned int n_px;
-    RayQueue out;                   // overflow stream: children that found the wave's ring full
+    RayQueue spill;                 // the waves' own spill queues: streams_spill_records() records each, gridDim of them
+    RayQueue out;                   // overflow stream: children that found ring and spill queue full
     unsigned int *out_count;        // device: reservation cursor of `out`, zero at launch
     unsigned int out_base;
     unsigned int *emitted;
@@ -133,6 +138,7 @@ hipError_t launch_streams_pixels(const RenderArgs &a, const ItemArgs &it, unsign
 hipError_t launch_streams_split(const RenderArgs &a, const ItemArgs &it, unsigned int grid, hipStream_t stream);
 int streams_pixels_waves();           // waves per SIMD the item kernels are built for (persistent grids)
 int streams_split_waves();
+unsigned int streams_spill_records();   // records of a wave's spill queue in HBM
 unsigned int streams_regions(int width, int rows_local);    // regions of the start-hit list
 hipError_t launch_streams_seeds(Planes p, uint4 *snapshots, long long n, int passes, int samples_per_pass, int draws, hipStream_t stream);
 hipError_t launch_streams_level(const RenderArgs &a, const LevelArgs &lv, unsigned int grid, hipStream_t stream);

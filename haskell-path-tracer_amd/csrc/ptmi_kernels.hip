@@ -1705,6 +1705,13 @@ __device__ __forceinline__ unsigned int rank_in(unsigned long long mask)
 {
     return __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
 }
+// 16 bytes past the L1 (global_load_dwordx4 ... nt): for records this wave wrote itself a few trips ago
+__device__ __forceinline__ float4 load_past_l1(const float4 *p)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+    return float4{v.x, v.y, v.z, v.w};
+}
 // Element `byte_off / 4` of a plane through a 32-bit byte offset (the stream form holds < 2^30 pixels): the access becomes
 // scalar base + 32-bit vector offset instead of a 64-bit address pair per plane.
 template <typename T> __device__ __forceinline__ T &plane_at(T *base, uint32_t byte_off)
@@ -1813,42 +1820,54 @@ __global__ void __launch_bounds__(256) streams_primary_kernel(const RenderArgs a
     }
 }
 
-// The chunk cursor of the item kernels.  A chunk is 64 slots of a region; ticket t stands for chunk t mod n_chunks of pass
-// t div n_chunks.  Wave w starts with ticket w; later tickets come from one returning atomic each (an item is tens to
-// thousands of loop trips).  Regions without records (tiles whose primary rays all miss) are skipped.
+// The chunk cursor of the item kernels.  A chunk is 64 slots of a region of the start-hit list; the regions come in groups
+// of four, one group per dispatch POSITION (the four tiles of a quad, most expensive quad first).  The positions are dealt to
+// queues: position p belongs to chain (p / 8) mod n_chains -- a launch works on one chain -- and to XCD p mod 8, so that the
+// tiles of a quad, whose pixels share cache lines of the planes, are worked on behind ONE L2 (dealt to any XCD, every line
+// of the planes was fetched four times).  A queue is a ticket counter: ticket j stands for chunk (j mod n) of pass (j div n),
+// n = the queue's chunks, passes outermost and positions in dispatch order.  A wave takes tickets -- one returning atomic
+// each; an item is tens to thousands of loop trips -- from the queue of the XCD it runs on (HW_REG_XCC_ID; which wave works
+// on which chunk changes no result) and, when that one is exhausted, from the other XCDs' queues.  Eight counters instead
+// of one: a single word serves ~90 atomics per microsecond and thousands of waves start together.  Regions without
+// records (tiles whose primary rays all miss) are skipped.
 struct ChunkCursor {
-    unsigned int ticket, taken, len, first, pass;
+    unsigned int taken, len, first, pass;    // of the chunk in hand: records handed out, records, first slot, pass
+    unsigned int home, tries;                // the wave's XCD; queues found exhausted (8: nothing is left)
 };
-__device__ __forceinline__ void open_chunk(ChunkCursor &c, const ItemArgs &it, unsigned int n_total, unsigned int G)
+__device__ __forceinline__ unsigned int xcc_id()
+{
+    return (unsigned int)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;     // HW_REG_XCC_ID, bits [3:0]
+}
+__device__ __forceinline__ bool chunks_left(const ChunkCursor &c) { return c.tries < 8u; }
+__device__ __forceinline__ void next_chunk(ChunkCursor &c, const ItemArgs &it)
 {
     const unsigned int per = it.hits.region_slots >> 6;      // chunks per region: 1 or 2
-    for (;;) {
-        c.taken = 0; c.len = 0;
-        if (c.ticket >= n_total) return;
-        c.pass = c.ticket / it.n_chunks;
-        const unsigned int k = c.ticket - c.pass * it.n_chunks, region = k / per, half = k - region * per;
+    const unsigned int nch = (unsigned int)it.n_chains, ch = (unsigned int)it.chain;
+    c.taken = 0; c.len = 0;
+    while (c.tries < 8u) {
+        const unsigned int q = (c.home + c.tries) & 7u;
+        // positions of this chain in queue q: p = (s n_chains + chain) 8 + q < n_positions
+        const unsigned int n_pos = it.n_positions > q + 8u * ch ? (it.n_positions - q - 8u * ch - 1u) / (8u * nch) + 1u : 0u;
+        const unsigned int n = n_pos * 4u * per;
+        unsigned int j = 0;
+        if ((threadIdx.x & 63) == 0) j = atomicAdd(it.chunk_cursor + (size_t)q * kCounterStride, 1u);
+        j = (unsigned int)__builtin_amdgcn_readfirstlane((int)j);
+        if (n == 0u || j / n >= (unsigned int)it.passes) { ++c.tries; continue; }
+        c.pass = j / n;
+        const unsigned int k = j - c.pass * n, s_pos = k / (4u * per), r = k - s_pos * (4u * per);
+        const unsigned int region = ((s_pos * nch + ch) * 8u + q) * 4u + r / per, half = r % per;
         const unsigned int have = it.hits.counts[region];
         c.first = region * it.hits.region_slots + half * 64u;
         c.len = have > half * 64u ? (have - half * 64u < 64u ? have - half * 64u : 64u) : 0u;
         if (c.len) return;
-        unsigned int t = 0;
-        if ((threadIdx.x & 63) == 0) t = G + atomicAdd(it.chunk_cursor, 1u);
-        c.ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
     }
 }
-__device__ __forceinline__ void next_chunk(ChunkCursor &c, const ItemArgs &it, unsigned int n_total, unsigned int G)
-{
-    unsigned int t = 0;
-    if ((threadIdx.x & 63) == 0) t = G + atomicAdd(it.chunk_cursor, 1u);
-    c.ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
-    open_chunk(c, it, n_total, G);
-}
 
-// what an item cost, for the dispatch order of later launches with the same key: loop trips the lane spent on it (or the
-// hits it shaded, one per trip), in units of 64
+// what an item cost, for the dispatch order of later launches with the same key: the loop trips the lane spent on it (or the
+// hits it shaded, one per trip)
 __device__ __forceinline__ void record_item_cost(const RenderArgs &a, unsigned int quad, unsigned int trips)
 {
-    if (a.quad_cost) atomicAdd(a.quad_cost + quad, (trips + 63u) >> 6);
+    if (a.quad_cost) atomicAdd(a.quad_cost + quad, trips);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1862,9 +1881,9 @@ __device__ __forceinline__ void record_item_cost(const RenderArgs &a, unsigned i
 template <bool LDS_SCENE>
 __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixels_kernel(const RenderArgs a, const ItemArgs it)
 {
-    // the lane's item: 0-2 position of the start hit, 3-5 axis and 6 half-angle scale of its bounce, 7-10 the seed the sample's
-    // last hit carried (PTMI_SEED_FROM_RESULT), 11 primitive, 12 quad, 13 the lane's count of shaded hits when the item began
-    __shared__ float item_const[14][kRenderBlock];
+    // the lane's item: 0-2 position of the start hit, 3-5 axis and 6 half-angle scale of its bounce, 7 primitive, 8 quad,
+    // 9 the lane's count of shaded hits when the item began
+    __shared__ float item_const[10][kRenderBlock];
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -1875,18 +1894,22 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
     const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
     const float4 *M = S + a.scene.geom_f4();
     const int lane = threadIdx.x & 63;
-    const unsigned int G = gridDim.x, n_total = it.n_chunks;
     const unsigned int step_cap = (unsigned int)a.stream_step_cap;
     const int n_spp = a.n_spp;
     float *mine = &item_const[0][threadIdx.x];
     auto put = [&](int k, float v) { mine[k * kRenderBlock] = v; };
     auto get = [&](int k) { return mine[k * kRenderBlock]; };
-    auto note_hit_seed = [&](const Sfc32 &sd) {
-        if (a.seed_from_result) { put(7, u2f(sd.a)); put(8, u2f(sd.b)); put(9, u2f(sd.c)); put(10, u2f(sd.counter)); }
-    };
+    // PTMI_SEED_FROM_RESULT (combine new old): the seed the ray of the sample's last hit carried.  (Four registers, copied at every
+    // hit; four LDS words written at every hit and four selects per sample cost 3 % more, stepping the lane's seed back over the
+    // hit's draws at the sample's end -- sfc32_prev -- 2.5 %.)
+    Sfc32 hit_seed; hit_seed.a = hit_seed.b = hit_seed.c = hit_seed.counter = 0;
 
-    ChunkCursor cur; cur.ticket = blockIdx.x;
-    open_chunk(cur, it, n_total, G);
+    ChunkCursor cur; cur.home = xcc_id(); cur.tries = 0;
+    next_chunk(cur, it);
+#ifdef PTMI_TAIL_STATS
+    const unsigned long long t_start = __builtin_readcyclecounter();
+    unsigned long long lane_trips = 0, wave_trips = 0;        // lanes with an item, summed over the trips / trips
+#endif
 
     bool busy = false, pending = false, has_ray = false, over = false;
     V3 acc = mk(0.0f, 0.0f, 0.0f), pos = acc, normal = acc, d = acc, throughput = acc;
@@ -1898,7 +1921,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
     for (;;) {
         // ---- refill: idle lanes take the next start hits of the wave's chunk (at once: an item is a pixel's whole sample chain)
         const unsigned long long idle = __ballot(!busy);
-        if (idle && cur.ticket < n_total) {                  // wave-uniform
+        if (idle && chunks_left(cur)) {                      // wave-uniform
             const unsigned int want = (unsigned int)__builtin_popcountll(idle), avail = cur.len - cur.taken;
             const unsigned int take = want < avail ? want : avail;
             const unsigned int rank = rank_in(idle);
@@ -1908,16 +1931,19 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
                 pixel4 = f2u(r3.y) << 2;
                 put(0, r0.x); put(1, r0.y); put(2, r0.z);
                 put(3, r0.w); put(4, r1.x); put(5, r1.y); put(6, r1.z);
-                put(11, r3.x); put(12, r3.w); put(13, u2f(live));
+                put(7, r3.x); put(8, r3.w); put(9, u2f(live));
                 acc = mk(plane_at(a.planes.r, pixel4), plane_at(a.planes.g, pixel4), plane_at(a.planes.b, pixel4));
                 pixel_seed.a = plane_at(a.planes.sa, pixel4); pixel_seed.b = plane_at(a.planes.sb, pixel4);
                 pixel_seed.c = plane_at(a.planes.sc, pixel4); pixel_seed.counter = plane_at(a.planes.sctr, pixel4);
                 s = -1; busy = true; over = true; pending = false; has_ray = false;
             }
             cur.taken += take;
-            if (cur.taken >= cur.len) next_chunk(cur, it, n_total, G);
+            if (cur.taken >= cur.len) next_chunk(cur, it);
         }
-        if (!__any(busy) && cur.ticket >= n_total) break;      // (no lane busy, chunks left: nothing below has a lane to run for; the next trip refills)
+        if (!__any(busy) && !chunks_left(cur)) break;      // (no lane busy, chunks left: nothing below has a lane to run for; the next trip refills)
+#ifdef PTMI_TAIL_STATS
+        lane_trips += (unsigned long long)__builtin_popcountll(__ballot(busy)); ++wave_trips;
+#endif
         float4 mb = M[2 * idx + 1];
         V3 axis = mk(0.0f, 0.0f, 0.0f); float hk = 0.0f;
         if (pending) {
@@ -1926,7 +1952,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
             if (near_zero(throughput)) {
                 const float4 ma = M[2 * idx];
                 acc = acc + (scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);
-                note_hit_seed(seed);
+                hit_seed = seed;
                 ++steps;
                 pending = false; over = true;
             } else {
@@ -1936,7 +1962,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
         if (over) {
             if (s >= 0) {                                      // a sample has been rendered
                 if (a.seed_from_result && steps > 0u) {        // combine new old: the seed the sample's last hit carried
-                    pixel_seed.a = f2u(get(7)); pixel_seed.b = f2u(get(8)); pixel_seed.c = f2u(get(9)); pixel_seed.counter = f2u(get(10));
+                    pixel_seed = hit_seed;
                 }
                 (void)random_float(pixel_seed);                // updateSeed
             }
@@ -1946,7 +1972,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
                 longest = longest > 1u ? longest : 1u;         // the primary ray's traceStep
                 seed = pixel_seed;
                 throughput = mk(1.0f, 1.0f, 1.0f);
-                pos = mk(get(0), get(1), get(2)); idx = (int)f2u(get(11));
+                pos = mk(get(0), get(1), get(2)); idx = (int)f2u(get(7));
                 mb = M[2 * idx + 1];
                 axis = mk(get(3), get(4), get(5)); hk = get(6);
                 pending = true;
@@ -1954,13 +1980,13 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
                 plane_at(a.planes.r, pixel4) = acc.x; plane_at(a.planes.g, pixel4) = acc.y; plane_at(a.planes.b, pixel4) = acc.z;
                 plane_at(a.planes.sa, pixel4) = pixel_seed.a; plane_at(a.planes.sb, pixel4) = pixel_seed.b;
                 plane_at(a.planes.sc, pixel4) = pixel_seed.c; plane_at(a.planes.sctr, pixel4) = pixel_seed.counter;
-                record_item_cost(a, f2u(get(12)), live - f2u(get(13)));       // its shaded hits stand for the loop trips it took
+                record_item_cost(a, f2u(get(8)), live - f2u(get(9)));       // its shaded hits stand for the loop trips it took
                 busy = false;
             }
         }
         if (pending) {                                         // alive (a fresh sample starts with throughput 1)
             const bool capped = steps + 1u >= step_cap;
-            note_hit_seed(seed);
+            hit_seed = seed;
             // results: colour += emittance * throughput for EVERY hit; then the new ray (shade, with the axis in hand)
             V3 next; float brdf;
             next_about_axis(mb, axis, hk, seed, next, brdf);
@@ -1986,6 +2012,17 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
             }
         }
     }
+#ifdef PTMI_TAIL_STATS
+    if (lane == 0) {     // diagnostic build: [8] first start, [10] last end, [12] sum of ends, [14] waves, [16] lanes-with-item x trips, [18] trips (all u64, s_memtime ticks)
+        unsigned long long *wc = reinterpret_cast<unsigned long long *>(a.work_counter + 8);
+        const unsigned long long t_end = __builtin_readcyclecounter();
+        atomicMax(wc + 0, ~t_start); atomicMax(wc + 1, t_end); atomicAdd(wc + 2, t_end - t_start); atomicAdd(wc + 3, 1ull);
+        atomicAdd(wc + 4, lane_trips); atomicAdd(wc + 5, wave_trips);
+        atomicMax(wc + 6, t_end - t_start);
+        const unsigned long long bin = (t_end - t_start) >> 19;               // [24, 64): waves by duration, bins of 2^19 cycles
+        atomicAdd(a.work_counter + 24 + (bin < 39ull ? (unsigned int)bin : 39u), 1u);
+    }
+#endif
     // statistics: the per-pixel kernels' sharded counters
     for (int off = 32; off > 0; off >>= 1) { const unsigned int other = __shfl_xor(longest, off, 64); longest = other > longest ? other : longest; }
     const unsigned long long live_total = wave_sum(live);
@@ -1997,23 +2034,27 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
 
 // ---------------------------------------------------------------------------------------
 // streams_split_kernel: items of (start hit, sample range), a child ring per wave.  Loop shape
-// [finish dead hits][refill items][next ray: ring, else the item's next sample][shade][expand][trace].
+// [finish dead hits][refill items][next ray: ring, else the wave's spill queue, else the item's next sample][shade][expand][trace].
+// Where the children of a wave wait, in this order: the RING in LDS (kRing records: nearly all of them, for one or two
+// trips); when the ring is full, the wave's own SPILL QUEUE in HBM (kSpill 64-byte records that only this wave writes and
+// reads: same-wave program order, no cross-wave visibility question); when that is full too, the overflow stream that
+// a later launch reads (streams_level_kernel) -- which a render call practically never needs.
 // ---------------------------------------------------------------------------------------
 #ifndef PTMI_SPLIT_WAVES
-#define PTMI_SPLIT_WAVES 5
+#define PTMI_SPLIT_WAVES 6
 #endif
 #ifndef PTMI_RING
 #define PTMI_RING 16
 #endif
 constexpr unsigned int kRing = PTMI_RING;                     // records of a wave's child ring (a power of two, <= 64)
+constexpr unsigned int kSpill = 256;                          // records of a wave's spill queue in HBM (a power of two)
 template <bool LDS_SCENE, bool TILES>
 __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_kernel(const RenderArgs a, const ItemArgs it)
 {
     // the lane's own item: 0-2 position of the start hit, 3-5 normal, 6-8 incoming direction, 9-11 throughput,
-    // 12 primitive | meta << 16, 13 pixel, 14-17 the seed its next sample starts from, 18 the wave's trip count when it began
-    __shared__ float item_rec[19][kRenderBlock];
-    __shared__ float item_acc[3][kRenderBlock];               // what the lane's own lineages have added for the item's pixel
-    __shared__ float4 ring[4][kRing];                         // children waiting for a lane (RayQueue's record layout)
+    // 12 primitive | meta << 16, 13 pixel, 14-17 the seed its next sample starts from
+    __shared__ float item_rec[18][kRenderBlock];
+    __shared__ uint32_t ring[15][kRing];                      // children waiting for a lane: RayQueue's record, word by word (15 words)
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -2024,25 +2065,26 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
     const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
     const float4 *M = S + a.scene.geom_f4();
     const int lane = threadIdx.x & 63;
-    const unsigned int G = gridDim.x, w = blockIdx.x;
-    const unsigned int n_total = it.n_chunks * (unsigned int)it.passes;
+    const unsigned int w = blockIdx.x;
     const unsigned int step_cap = (unsigned int)a.stream_step_cap;
     float *mine = &item_rec[0][threadIdx.x];
     auto put = [&](int k, float v) { mine[k * kRenderBlock] = v; };
     auto get = [&](int k) { return mine[k * kRenderBlock]; };
 
-    ChunkCursor cur; cur.ticket = w;
-    open_chunk(cur, it, n_total, G);
+    ChunkCursor cur; cur.home = xcc_id(); cur.tries = 0;
+    next_chunk(cur, it);
     unsigned int ring_head = 0, ring_n = 0;                   // wave-uniform
+    unsigned int spill_head = 0, spill_n = 0;                 // wave-uniform: the wave's spill queue, records [w kSpill, (w + 1) kSpill) of it.spill
     unsigned int blk = w * kFirstBlock, blk_end = blk + kFirstBlock;   // wave-uniform: the overflow block being filled
 
     bool busy = false, foreign = false, has_ray = false, pending = false;   // own item in hand / the ray came from the ring / a ray to trace / a hit to shade
     V3 o = mk(0, 0, 0), d = o, throughput = o, normal = o;    // o: the ray's origin, or the position of the pending hit
+    V3 own_acc = o;                                           // what the lane's own lineages have added for its item's pixel
     Sfc32 seed; seed.a = seed.b = seed.c = seed.counter = 0;
     uint32_t pixel = 0, depth = 0;                            // depth: step index of the lane's current ray
     int idx = 0, samples_left = 0;
-    unsigned int deepest = 0;
-    unsigned int live_w = 0, cut_w = 0, dropped_w = 0, stored_w = 0, trips_w = 0;   // wave-uniform statistics
+    unsigned int deepest = 0, item_trips = 0;                 // item_trips: loop trips since the lane took its item (its cost, for later launches' dispatch order)
+    unsigned int live_w = 0, cut_w = 0, dropped_w = 0, stored_w = 0, spilled_w = 0;   // wave-uniform statistics
 
     // computeResult + permute (+) (Trace.hs:179-184, :318-323); adding an exact zero changes nothing
     auto add_colour = [&](V3 c) __attribute__((always_inline)) {
@@ -2051,9 +2093,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
             if (c.y != 0.0f) atomicAdd(&plane_at(a.planes.g, pixel << 2), c.y);
             if (c.z != 0.0f) atomicAdd(&plane_at(a.planes.b, pixel << 2), c.z);
         } else {
-            if (c.x != 0.0f) item_acc[0][threadIdx.x] += c.x;
-            if (c.y != 0.0f) item_acc[1][threadIdx.x] += c.y;
-            if (c.z != 0.0f) item_acc[2][threadIdx.x] += c.z;
+            own_acc = own_acc + c;
         }
     };
 
@@ -2067,7 +2107,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
         }
         // ---- refill: lanes without an item take the next ones of the wave's chunk (whatever ray they are tracing meanwhile)
         const unsigned long long empty = __ballot(!busy);
-        if (empty && cur.ticket < n_total) {                  // wave-uniform
+        if (empty && chunks_left(cur)) {                      // wave-uniform
             const unsigned int want = (unsigned int)__builtin_popcountll(empty), avail = cur.len - cur.taken;
             const unsigned int take = want < avail ? want : avail;
             const unsigned int rank = rank_in(empty);
@@ -2081,14 +2121,14 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                 put(0, r0.x); put(1, r0.y); put(2, r0.z); put(3, r0.w); put(4, r1.x); put(5, r1.y);
                 put(6, r1.z); put(7, r1.w); put(8, r2.x); put(9, r2.y); put(10, r2.z); put(11, r2.w);
                 put(12, u2f(f2u(r3.x) | (f2u(r3.z) << 16))); put(13, r3.y);
-                put(14, u2f(s0.x)); put(15, u2f(s0.y)); put(16, u2f(s0.z)); put(17, u2f(s0.w)); put(18, u2f(trips_w));
-                item_acc[0][threadIdx.x] = 0.0f; item_acc[1][threadIdx.x] = 0.0f; item_acc[2][threadIdx.x] = 0.0f;
+                put(14, u2f(s0.x)); put(15, u2f(s0.y)); put(16, u2f(s0.z)); put(17, u2f(s0.w));
+                item_trips = 0;
                 const int first_sample = (int)cur.pass * it.samples_per_pass;
                 samples_left = a.n_spp - first_sample < it.samples_per_pass ? a.n_spp - first_sample : it.samples_per_pass;
                 busy = true;
             }
             cur.taken += take;
-            if (cur.taken >= cur.len) next_chunk(cur, it, n_total, G);
+            if (cur.taken >= cur.len) next_chunk(cur, it);
         }
         // ---- the next ray of every lane that holds neither a ray nor a hit: a child from the wave's ring first ...
         const bool free_lane = !pending && !has_ray;
@@ -2100,7 +2140,25 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
             const unsigned int rank = rank_in(free_m);
             if (free_lane && rank < take) {
                 const unsigned int slot = (ring_head + rank) & (kRing - 1u);
-                const float4 r0 = ring[0][slot], r1 = ring[1][slot], r2 = ring[2][slot], r3 = ring[3][slot];
+                o = mk(u2f(ring[0][slot]), u2f(ring[1][slot]), u2f(ring[2][slot]));
+                d = mk(u2f(ring[3][slot]), u2f(ring[4][slot]), u2f(ring[5][slot]));
+                throughput = mk(u2f(ring[6][slot]), u2f(ring[7][slot]), u2f(ring[8][slot]));
+                pixel = ring[9][slot];
+                seed.a = ring[10][slot]; seed.b = ring[11][slot]; seed.c = ring[12][slot]; seed.counter = ring[13][slot];
+                depth = ring[14][slot];
+                has_ray = true; foreign = true; took = true;
+            }
+            ring_head = (ring_head + take) & (kRing - 1u); ring_n -= take;
+        } else if (spill_n && free_m) {                       // ... or, the ring being empty, from the wave's spill queue (rare)
+            const unsigned int want = (unsigned int)__builtin_popcountll(free_m);
+            const unsigned int take = want < spill_n ? want : spill_n;
+            const unsigned int rank = rank_in(free_m);
+            // the records were written by this wave, at least a trip ago: once its stores have been acknowledged (they have: the
+            // wait is free) they are in the L2, and loads that bypass the L1 see them
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (free_lane && rank < take) {
+                const float4 *r = it.spill.record(w * kSpill + ((spill_head + rank) & (kSpill - 1u)));
+                const float4 r0 = load_past_l1(r), r1 = load_past_l1(r + 1), r2 = load_past_l1(r + 2), r3 = load_past_l1(r + 3);
                 o = mk(r0.x, r0.y, r0.z);
                 d = mk(r0.w, r1.x, r1.y);
                 throughput = mk(r1.z, r1.w, r2.x);
@@ -2109,7 +2167,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                 depth = f2u(r3.z);
                 has_ray = true; foreign = true; took = true;
             }
-            ring_head = (ring_head + take) & (kRing - 1u); ring_n -= take;
+            spill_head = (spill_head + take) & (kSpill - 1u); spill_n -= take;
         }
         // ---- ... else the next sample of its own item (its start hit and that sample's seed are in the lane's LDS column); an
         // item without samples left is over: its colour goes to the planes, one atomic per word
@@ -2133,23 +2191,23 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                 pending = true; foreign = false;              // (a start hit of a dead ray -- a reflection of weight ~0 -- waits for the next trip's first block)
             } else {
                 const uint32_t px = f2u(get(13));
-                const V3 c = mk(item_acc[0][threadIdx.x], item_acc[1][threadIdx.x], item_acc[2][threadIdx.x]);
-                if (c.x != 0.0f) atomicAdd(&plane_at(a.planes.r, px << 2), c.x);
-                if (c.y != 0.0f) atomicAdd(&plane_at(a.planes.g, px << 2), c.y);
-                if (c.z != 0.0f) atomicAdd(&plane_at(a.planes.b, px << 2), c.z);
+                if (own_acc.x != 0.0f) atomicAdd(&plane_at(a.planes.r, px << 2), own_acc.x);
+                if (own_acc.y != 0.0f) atomicAdd(&plane_at(a.planes.g, px << 2), own_acc.y);
+                if (own_acc.z != 0.0f) atomicAdd(&plane_at(a.planes.b, px << 2), own_acc.z);
+                own_acc = mk(0.0f, 0.0f, 0.0f);
                 if (TILES && a.quad_cost) {
                     const unsigned int y = px / (unsigned int)a.width, x = px - y * (unsigned int)a.width;
                     const unsigned int tile = (y >> 3) * (unsigned int)((a.width + 7) / 8) + (x >> 3);
-                    record_item_cost(a, tile >> 2, trips_w - f2u(get(18)));
+                    record_item_cost(a, tile >> 2, item_trips);
                 }
                 busy = false;
             }
         }
-        // no lane holds a ray or a hit: every lane was free, so the ring is empty (64 free lanes would have emptied it) and no lane
-        // holds an item with samples left.  (With chunks left nothing below has a lane to run for and the next trip refills: a
-        // `continue` here would be a second back edge, and cost the loop its register allocation.)
-        if (!__any(has_ray || pending) && cur.ticket >= n_total && !__any(busy)) break;
-        ++trips_w;
+        // no lane holds a ray or a hit: every lane was free, so ring and spill queue are empty (64 free lanes would have taken
+        // from them) and no lane holds an item with samples left.  (With chunks left nothing below has a lane to run for and the
+        // next trip refills: a `continue` here would be a second back edge, and cost the loop its register allocation.)
+        if (!__any(has_ray || pending) && !chunks_left(cur) && !__any(busy) && ring_n == 0 && spill_n == 0) break;
+        item_trips += busy ? 1u : 0u;
 
         // ---- shade round, for the hits of rays that are alive (a dead one just fetched waits for the next trip's first block)
         bool emits = false;
@@ -2173,7 +2231,8 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
             add_colour(contribution);
             ++depth; pending = false; has_ray = true;          // the child: next traceStep, same lane
         }
-        // ---- expand: compaction of the emitted children into the wave's ring; what the ring cannot hold goes to the overflow stream
+        // ---- expand: compaction of the emitted children into the wave's ring; what the ring cannot hold goes to the wave's spill
+        // queue, what that cannot hold to the overflow stream
         const unsigned long long kids = it.may_emit ? __ballot(emits) : 0ull;
         if (kids) {                                           // wave-uniform
             const unsigned int cnt = (unsigned int)__builtin_popcountll(kids), rank = rank_in(kids);
@@ -2182,29 +2241,40 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
             const unsigned int to_ring = cnt < room_ring ? cnt : room_ring;
             if (emits && rank < to_ring) {
                 const unsigned int slot = (ring_head + ring_n + rank) & (kRing - 1u);
-                ring[0][slot] = float4{ko.x, ko.y, ko.z, kd.x};
-                ring[1][slot] = float4{kd.y, kd.z, kt.x, kt.y};
-                ring[2][slot] = float4{kt.z, u2f(pixel), u2f(ks.a), u2f(ks.b)};
-                ring[3][slot] = float4{u2f(ks.c), u2f(ks.counter), u2f(depth), 0.0f};
+                ring[0][slot] = f2u(ko.x); ring[1][slot] = f2u(ko.y); ring[2][slot] = f2u(ko.z);
+                ring[3][slot] = f2u(kd.x); ring[4][slot] = f2u(kd.y); ring[5][slot] = f2u(kd.z);
+                ring[6][slot] = f2u(kt.x); ring[7][slot] = f2u(kt.y); ring[8][slot] = f2u(kt.z);
+                ring[9][slot] = pixel;
+                ring[10][slot] = ks.a; ring[11][slot] = ks.b; ring[12][slot] = ks.c; ring[13][slot] = ks.counter;
+                ring[14][slot] = depth;
             }
             ring_n += to_ring;
-            if (cnt > to_ring) {                              // the ring is full: the others travel through HBM
-                const unsigned int cnt2 = cnt - to_ring, rank2 = rank - to_ring;      // (rank2 is meaningful for rank >= to_ring only)
-                const bool spills = emits && rank >= to_ring;
-                const unsigned int room = blk_end - blk;
-                unsigned int slot = blk + rank2;
-                if (cnt2 > room) {                            // the block is full: one atomic reserves the next for the whole wave
-                    unsigned int fresh = 0;
-                    if (lane == 0) fresh = it.out_base + atomicAdd(it.out_count, kNextBlock);
-                    fresh = (unsigned int)__builtin_amdgcn_readfirstlane((int)fresh);
-                    if (rank2 >= room) slot = fresh + (rank2 - room);
-                    blk = fresh + (cnt2 - room); blk_end = fresh + kNextBlock;
-                } else {
-                    blk += cnt2;
+            if (cnt > to_ring) {                              // the ring is full (rare)
+                const unsigned int rest = cnt - to_ring;
+                const unsigned int room_spill = kSpill - spill_n;
+                const unsigned int to_spill = rest < room_spill ? rest : room_spill;
+                if (emits && rank >= to_ring && rank - to_ring < to_spill)
+                    queue_store(it.spill, w * kSpill + ((spill_head + spill_n + (rank - to_ring)) & (kSpill - 1u)), ko, kd, kt, pixel, ks, depth);
+                spill_n += to_spill; spilled_w += to_spill;
+                if (rest > to_spill) {                        // the wave's spill queue is full too: the overflow stream (a later launch reads it)
+                    const unsigned int cnt2 = rest - to_spill, first2 = to_ring + to_spill;
+                    const bool spills = emits && rank >= first2;
+                    const unsigned int rank2 = rank - first2;  // (meaningful where `spills`)
+                    const unsigned int room = blk_end - blk;
+                    unsigned int slot = blk + rank2;
+                    if (cnt2 > room) {                        // the block is full: one atomic reserves the next for the whole wave
+                        unsigned int fresh = 0;
+                        if (lane == 0) fresh = it.out_base + atomicAdd(it.out_count, kNextBlock);
+                        fresh = (unsigned int)__builtin_amdgcn_readfirstlane((int)fresh);
+                        if (rank2 >= room) slot = fresh + (rank2 - room);
+                        blk = fresh + (cnt2 - room); blk_end = fresh + kNextBlock;
+                    } else {
+                        blk += cnt2;
+                    }
+                    const unsigned int lost = (unsigned int)__builtin_popcountll(__ballot(spills && slot >= it.out.capacity));
+                    stored_w += cnt2 - lost; dropped_w += lost;
+                    if (spills && slot < it.out.capacity) queue_store(it.out, slot, ko, kd, kt, pixel, ks, depth);   // depth: the child's step index
                 }
-                const unsigned int lost = (unsigned int)__builtin_popcountll(__ballot(spills && slot >= it.out.capacity));
-                stored_w += cnt2 - lost; dropped_w += lost;
-                if (spills && slot < it.out.capacity) queue_store(it.out, slot, ko, kd, kt, pixel, ks, depth);   // depth: the child's step index
             }
         }
         // ---- trace round: one traceStep (Trace.hs:272-294) for every lane that holds a ray
@@ -2240,6 +2310,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
         if (deep > __hip_atomic_load(st + kLvDeepest * kCounterStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(st + kLvDeepest * kCounterStride, deep);
         if (cut_w) atomicAdd(st + kLvCut * kCounterStride, cut_w);
         if (dropped_w) atomicAdd(st + kLvDropped * kCounterStride, dropped_w);
+        if (spilled_w + stored_w) atomicAdd(st + kLvSpilled * kCounterStride, spilled_w + stored_w);
     }
 }
 
@@ -2818,6 +2889,7 @@ hipError_t launch_streams_split(const RenderArgs &a, const ItemArgs &it, unsigne
 
 int streams_pixels_waves() { return PTMI_PIXELS_WAVES; }
 int streams_split_waves() { return PTMI_SPLIT_WAVES; }
+unsigned int streams_spill_records() { return kSpill; }
 unsigned int streams_first_block() { return kFirstBlock; }
 
 // regions of the start-hit list: one per 8x8 tile (padded as the tiled render kernels pad their grids), or one per 64

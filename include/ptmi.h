@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PTMI_VERSION 200   /* 0.2.0 */
+#define PTMI_VERSION 300   /* 0.3.0: ptmi_stats.stream_rays_spilled, PTMI_SEED_AUTO (the default), group options */
 
 /* ---- error codes ------------------------------------------------------------ */
 enum {
@@ -93,6 +93,7 @@ typedef struct ptmi_stats {
     uint32_t stream_iterations;    /* Streams: the longest chain of traceSteps any ray lineage took (stream form: of the last sample) */
     uint64_t stream_rays_dropped;  /* Streams with ray splitting: children that found no room (next stream / lane stack full) */
     uint64_t stream_rays_truncated;/* Streams: rays still alive when PTMI_OPT_STREAM_STEP_CAP cut their lineage (the reference has no cap) */
+    uint64_t stream_rays_spilled;  /* Streams, stream form: children that found their wave's ring in LDS full and travelled through HBM (nothing is lost) */
 } ptmi_stats;
 
 typedef struct ptmi_ctx ptmi_ctx;
@@ -144,11 +145,17 @@ int ptmi_set_variant(ptmi_ctx *ctx, int variant);
  * scheduling knob of the per-pixel kernels that changes no result. */
 enum {
     /* Which seed a pixel carries out of `combine` (Trace.hs:179-184): the combination function keeps the seed of its
-     * FIRST argument and Accelerate's `permute` does not define which of (accumulator element, new value) that is.
-     *   PTMI_SEED_KEEP_ACCUMULATOR (default)  the pixel keeps its seed through the sample; updateSeed advances it one draw
-     *   PTMI_SEED_FROM_RESULT                 every hit replaces it by the seed its ray carried into the hit (computeResult,
-     *                                         Trace.hs:317-321); updateSeed advances the survivor.  Refused for scenes with
-     *                                         GLASS: with several rays per pixel the survivor is a race in Accelerate too. */
+     * FIRST argument, and which of (new value, accumulator element) `permute` hands it first is backend behaviour
+     * (assumption A5).  In the reference a pixel receives at most ONE result per traceStep
+     * (numNewRays is 0 or 1, Trace.hs:329-331), so either reading is deterministic there.
+     *   PTMI_SEED_FROM_RESULT       `f new old`, the order Accelerate's interpreter and LLVM code generators apply the
+     *                               function in: every hit replaces the pixel's seed by the seed its ray carried into the
+     *                               hit (computeResult, Trace.hs:317-321); updateSeed advances the survivor.  Refused for
+     *                               scenes with GLASS: several results per pixel and step race for the seed there.
+     *   PTMI_SEED_KEEP_ACCUMULATOR  `f old new`: the pixel keeps its seed through the sample; updateSeed advances it one draw.
+     *   PTMI_SEED_AUTO (default)    FROM_RESULT -- the likelier reading -- for scenes in which no primitive splits rays (every
+     *                               scene the reference can express); KEEP_ACCUMULATOR for scenes with the build-defined
+     *                               GLASS, where the reference defines nothing. */
     PTMI_OPT_STREAMS_SEED_RULE = 1,
     /* Safety cap on the traceSteps of one ray lineage (children inherit their ancestors' count).  The reference has NO
      * bound (notFinished never stops a non-empty stream, Trace.hs:166-170); the default, 65536, only guarantees
@@ -172,7 +179,7 @@ enum {
      * 0 (default) = automatic, 1 = off, k = k copies. */
     PTMI_OPT_SPP_CHUNKS = 6
 };
-enum { PTMI_SEED_KEEP_ACCUMULATOR = 0, PTMI_SEED_FROM_RESULT = 1 };
+enum { PTMI_SEED_KEEP_ACCUMULATOR = 0, PTMI_SEED_FROM_RESULT = 1, PTMI_SEED_AUTO = 2 };
 enum { PTMI_FORM_AUTO = 0, PTMI_FORM_STREAM = 1 };
 int ptmi_set_option(ptmi_ctx *ctx, int option, int64_t value);
 int ptmi_get_option(ptmi_ctx *ctx, int option, int64_t *value);

@@ -54,6 +54,13 @@ class _Opts(C.Structure):
 
 
 SEED_KEEP_ACCUMULATOR, SEED_FROM_RESULT = 0, 1        # ORA_SEED_* (assumption A5, pt_oracle.h)
+GLASS_TAG = 2
+
+
+def default_seed_rule(spheres, planes):
+    """What libptmi's PTMI_SEED_AUTO resolves to: `combine new old` (the result's seed) unless a primitive splits rays."""
+    tags = list(np.asarray(spheres)["brdf_tag"].reshape(-1)) + list(np.asarray(planes)["brdf_tag"].reshape(-1))
+    return SEED_KEEP_ACCUMULATOR if any(int(t) == GLASS_TAG for t in tags) else SEED_FROM_RESULT
 
 
 def build(force=False):
@@ -227,10 +234,11 @@ def render_inline(spheres, planes, camera, width, height, bounce_limit, n_spp, p
 
 
 def render_streams(spheres, planes, camera, width, height, max_iterations, n_spp, planes_in,
-                   rows=None, seed_rule=SEED_KEEP_ACCUMULATOR, want_truncated=False):
+                   rows=None, seed_rule=None, want_truncated=False):
+    """seed_rule None = the library's default (default_seed_rule)."""
     sc, keep = _scene(spheres, planes)
     cam = np.ascontiguousarray(camera, CAMERA_DTYPE)
-    o, keep_rows = _opts(rows, seed_rule)
+    o, keep_rows = _opts(rows, default_seed_rule(spheres, planes) if seed_rule is None else seed_rule)
     outs = _copies(planes_in, height if rows is None else len(rows), width)
     truncated = C.c_int64(0)
     live = lib().ora_render_streams_ex(C.byref(sc), _p(cam), width, height, max_iterations, n_spp,
@@ -241,11 +249,12 @@ def render_streams(spheres, planes, camera, width, height, max_iterations, n_spp
 
 
 def render_streams_wavefront(spheres, planes, camera, width, height, hard_cap, n_spp, planes_in, capacity_factor=4,
-                             rows=None, seed_rule=SEED_KEEP_ACCUMULATOR, want_truncated=False):
-    """Streams as a stream (supports the build-defined GLASS extension). -> (planes, live, dropped, steps[, truncated])"""
+                             rows=None, seed_rule=None, want_truncated=False):
+    """Streams as a stream (supports the build-defined GLASS extension). -> (planes, live, dropped, steps[, truncated])
+    seed_rule None = the library's default (default_seed_rule)."""
     sc, keep = _scene(spheres, planes)
     cam = np.ascontiguousarray(camera, CAMERA_DTYPE)
-    o, keep_rows = _opts(rows, seed_rule)
+    o, keep_rows = _opts(rows, default_seed_rule(spheres, planes) if seed_rule is None else seed_rule)
     outs = _copies(planes_in, height if rows is None else len(rows), width)
     dropped, steps, truncated = C.c_int64(0), C.c_int(0), C.c_int64(0)
     live = lib().ora_render_streams_wavefront_ex(C.byref(sc), _p(cam), width, height, hard_cap, n_spp, capacity_factor,

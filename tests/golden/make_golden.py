@@ -23,7 +23,10 @@ CASES = {
     "main_64x48_l4_s1": ("main", 64, 48, 4, 1, "inline"),
     "main_64x48_l15_s2": ("main", 64, 48, 15, 2, "inline"),
     "s16_80x45_l8_s4": ("s16", 80, 45, 8, 4, "inline"),
+    # render Streams under the library's default seed rule (PTMI_SEED_AUTO = `combine new old` without GLASS) ...
     "main_64x48_streams_s2": ("main", 64, 48, 1 << 16, 2, "streams"),
+    # ... and under the other reading of `combine` (assumption A5): the pixel keeps the accumulator's seed
+    "main_64x48_streams_keep_s2": ("main", 64, 48, 1 << 16, 2, "streams_keep"),
     # build-defined GLASS extension (no reference semantics at all): stream form, hard cap 64 steps
     "glass_64x48_wavefront_s2": ("glass", 64, 48, 64, 2, "wavefront"),
 }
@@ -40,7 +43,10 @@ def main():
         if alg == "inline":
             out, live = ora.render_inline(sp, pl, cam, w, h, limit, spp, start)
         elif alg == "streams":
+            assert ora.default_seed_rule(sp, pl) == ora.SEED_FROM_RESULT
             out, live = ora.render_streams(sp, pl, cam, w, h, limit, spp, start)
+        elif alg == "streams_keep":
+            out, live = ora.render_streams(sp, pl, cam, w, h, limit, spp, start, seed_rule=ora.SEED_KEEP_ACCUMULATOR)
         else:
             out, live, dropped, _steps = ora.render_streams_wavefront(sp, pl, cam, w, h, limit, spp, start)
             assert dropped == 0

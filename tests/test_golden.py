@@ -28,8 +28,10 @@ def test_oracle_reproduces_golden(ora, path):
     w, h, limit, spp = int(z["width"]), int(z["height"]), int(z["limit"]), int(z["spp"])
     if str(z["algorithm"]) == "inline":
         got, live = ora.render_inline(z["spheres"], z["planes"], z["camera"], w, h, limit, spp, start)
-    elif str(z["algorithm"]) == "streams":
+    elif str(z["algorithm"]) == "streams":           # the library's default seed rule
         got, live = ora.render_streams(z["spheres"], z["planes"], z["camera"], w, h, limit, spp, start)
+    elif str(z["algorithm"]) == "streams_keep":
+        got, live = ora.render_streams(z["spheres"], z["planes"], z["camera"], w, h, limit, spp, start, seed_rule=ora.SEED_KEEP_ACCUMULATOR)
     else:
         got, live, _dropped, _steps = ora.render_streams_wavefront(z["spheres"], z["planes"], z["camera"], w, h, limit, spp, start)
     assert_planes_equal(got, want, os.path.basename(path))
@@ -46,8 +48,13 @@ def test_gpu_reproduces_golden(ctx, pkg, path):
     ctx.resize(w, h)
     ctx.upload_state(*start)
     ctx.reset_stats()
-    ctx.render(z["camera"], limit, spp, alg)
-    got = ctx.download_state()
+    B = pkg.binding
+    ctx.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_KEEP_ACCUMULATOR if str(z["algorithm"]) == "streams_keep" else B.SEED_AUTO)
+    try:
+        ctx.render(z["camera"], limit, spp, alg)
+        got = ctx.download_state()
+    finally:
+        ctx.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_AUTO)
     if str(z["algorithm"]) == "wavefront":
         # GLASS: several rays of a pixel add in one launch, in undefined order (as in Accelerate's permute)
         assert_planes_equal(got[3:], want[3:] , os.path.basename(path))

@@ -45,16 +45,21 @@ def test_streams_ignores_the_iteration_limit_like_the_reference(ctx, pkg, ora):
 
 def test_streams_seed_rule_and_first_sample_colour(ctx, pkg, ora):
     """Sample 1: Streams == Inline in colour except where a path outlives the limit or ends on a hit with
-    near-zero throughput; carried seed = original advanced by ONE draw (updateSeed)."""
+    near-zero throughput; under PTMI_SEED_KEEP_ACCUMULATOR the carried seed = original advanced by ONE draw (updateSeed)."""
     sp, pl = pkg.world.main_scene()
     cam = pkg.world.initial_camera()
     w, h = 80, 60
     start = initial_planes(ora, w, h)
+    B = pkg.binding
     ctx.set_scene(sp, pl)
     ctx.resize(w, h)
     ctx.upload_state(*start)
-    ctx.render(cam, 15, 1, pkg.STREAMS)
-    stm = ctx.download_state()
+    ctx.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_KEEP_ACCUMULATOR)
+    try:
+        ctx.render(cam, 15, 1, pkg.STREAMS)
+        stm = ctx.download_state()
+    finally:
+        ctx.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_AUTO)
     ctx.upload_state(*start)
     ctx.render(cam, 64, 1, pkg.INLINE)
     inl = ctx.download_state()
@@ -76,11 +81,12 @@ def test_render1_streams(ctx, pkg, ora):
     assert_planes_equal(got, want, "render1 Streams")
 
 
+@pytest.mark.parametrize("rule", ["keep", "from_result", "auto"])
 @pytest.mark.parametrize("stream_form", [False, True])
 @pytest.mark.parametrize("scene_name,w,h,spp", [("main", 96, 64, 3), ("s16", 120, 67, 2)])
-def test_seed_from_result_rule(ctx, pkg, ora, scene_name, w, h, spp, stream_form):
-    """Assumption A5's alternative (PTMI_SEED_FROM_RESULT: permute hands `combine` the new value first) on the device,
-    both forms, against the oracle -- bit for bit, seeds included."""
+def test_both_seed_rules_in_both_forms(ctx, pkg, ora, scene_name, w, h, spp, stream_form, rule):
+    """Assumption A5's two readings of `combine` (Trace.hs:179-184) on the device, both forms, against the oracle -- bit for
+    bit, seeds included.  PTMI_SEED_AUTO (the default) is `combine new old` = PTMI_SEED_FROM_RESULT for these scenes."""
     B = pkg.binding
     scene = pkg.world.main_scene() if scene_name == "main" else pkg.world.scene16()
     cam = pkg.world.initial_camera()
@@ -89,21 +95,24 @@ def test_seed_from_result_rule(ctx, pkg, ora, scene_name, w, h, spp, stream_form
     ctx.resize(w, h)
     ctx.upload_state(*start)
     ctx.reset_stats()
-    ctx.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_FROM_RESULT)
+    assert ctx.get_option(B.OPT_STREAMS_SEED_RULE) == B.SEED_AUTO             # the default
+    value = {"keep": B.SEED_KEEP_ACCUMULATOR, "from_result": B.SEED_FROM_RESULT, "auto": B.SEED_AUTO}[rule]
+    ctx.set_option(B.OPT_STREAMS_SEED_RULE, value)
     ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM if stream_form else B.FORM_AUTO)
     try:
-        assert ctx.get_option(B.OPT_STREAMS_SEED_RULE) == B.SEED_FROM_RESULT
+        assert ctx.get_option(B.OPT_STREAMS_SEED_RULE) == value
         ctx.render(cam, 15, spp, pkg.STREAMS)
         got = ctx.download_state()
         live_gpu = ctx.stats()["live_bounces"]
     finally:
-        ctx.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_KEEP_ACCUMULATOR)
+        ctx.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_AUTO)
         ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_AUTO)
-    want, live = ora.render_streams(scene[0], scene[1], cam, w, h, CAP, spp, start, seed_rule=ora.SEED_FROM_RESULT)
-    assert_planes_equal(got, want, "seed from result, %s" % ("stream form" if stream_form else "per-pixel form"))
+    keep, live_keep = ora.render_streams(scene[0], scene[1], cam, w, h, CAP, spp, start, seed_rule=ora.SEED_KEEP_ACCUMULATOR)
+    res, live_res = ora.render_streams(scene[0], scene[1], cam, w, h, CAP, spp, start, seed_rule=ora.SEED_FROM_RESULT)
+    want, live = (keep, live_keep) if rule == "keep" else (res, live_res)
+    assert_planes_equal(got, want, "seed rule %s, %s" % (rule, "stream form" if stream_form else "per-pixel form"))
     assert live_gpu == live
-    keep, _ = ora.render_streams(scene[0], scene[1], cam, w, h, CAP, spp, start)
-    assert not np.array_equal(keep[3], want[3])              # the two rules really differ
+    assert not np.array_equal(keep[3], res[3])               # the two rules really differ
 
 
 def test_seed_from_result_is_refused_when_rays_split(ctx, pkg):
@@ -116,7 +125,9 @@ def test_seed_from_result_is_refused_when_rays_split(ctx, pkg):
             ctx.render(pkg.world.initial_camera(), 8, 1, pkg.STREAMS)
         assert e.value.code == -1
     finally:
-        ctx.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_KEEP_ACCUMULATOR)
+        ctx.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_AUTO)
+    ctx.render(pkg.world.initial_camera(), 8, 1, pkg.STREAMS)         # PTMI_SEED_AUTO: the accumulator's seed with GLASS
+    ctx.synchronize()
     with pytest.raises(pkg.PtmiError):
         ctx.set_option(99, 0)
     with pytest.raises(pkg.PtmiError):

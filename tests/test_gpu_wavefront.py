@@ -91,20 +91,23 @@ def test_inline_refuses_glass(ctx, pkg):
     ctx.synchronize()
 
 
-def test_stream_batch_option_trades_order_for_longer_launches(ctx, pkg, ora):
-    """PTMI_OPT_STREAM_BATCH > 1 without GLASS: several samples of a pixel share one stream, so the order of a pixel's
-    additions is no longer the sample order -- colours agree to rounding, the RNG planes stay exact, nothing is lost."""
+def test_stream_batch_option_trades_order_for_shorter_items(ctx, pkg, ora):
+    """PTMI_OPT_STREAM_BATCH > 0 without GLASS: a pixel's samples are cut into items of that many samples which run in
+    whatever lanes take them, so the order of a pixel's additions is no longer the sample order -- colours agree to
+    rounding, the RNG planes stay exact, nothing is lost."""
     B = pkg.binding
     scene = pkg.world.scene16()
     cam = pkg.world.initial_camera()
     w, h, spp = 120, 67, 7
     start = initial_planes(ora, w, h)
     ctx.set_option(B.OPT_STREAM_BATCH, 4)
+    ctx.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_KEEP_ACCUMULATOR)      # (under `combine new old` a pixel's samples are one serial chain: the option is ignored)
     try:
         got, st = render(ctx, pkg, scene, cam, w, h, spp, start, stream_form=True)
     finally:
         ctx.set_option(B.OPT_STREAM_BATCH, 0)
-    want, live = ora.render_streams(scene[0], scene[1], cam, w, h, CAP, spp, start)
+        ctx.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_AUTO)
+    want, live = ora.render_streams(scene[0], scene[1], cam, w, h, CAP, spp, start, seed_rule=ora.SEED_KEEP_ACCUMULATOR)
     for a, b in zip(got[3:], want[3:]):
         assert np.array_equal(a, b)
     assert st["live_bounces"] == live and st["stream_rays_dropped"] == 0 and st["stream_rays_truncated"] == 0

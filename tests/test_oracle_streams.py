@@ -29,7 +29,8 @@ def test_seed_from_result_rule(ora, pkg):
     sp, pl = pkg.world.main_scene()
     cam = pkg.world.initial_camera()
     start = initial_planes(ora, W, H)
-    keep, _ = ora.render_streams(sp, pl, cam, W, H, 1 << 16, 1, start)
+    keep, _ = ora.render_streams(sp, pl, cam, W, H, 1 << 16, 1, start, seed_rule=ora.SEED_KEEP_ACCUMULATOR)
+    assert ora.default_seed_rule(sp, pl) == ora.SEED_FROM_RESULT and ora.default_seed_rule(*pkg.world.glass_scene()) == ora.SEED_KEEP_ACCUMULATOR
     res, live = ora.render_streams(sp, pl, cam, W, H, 1 << 16, 1, start, seed_rule=ora.SEED_FROM_RESULT)
     wav = ora.render_streams_wavefront(sp, pl, cam, W, H, 1 << 16, 1, start, seed_rule=ora.SEED_FROM_RESULT)
     assert_planes_equal(wav[0], res, "from-result: stream vs per pixel")
@@ -52,9 +53,11 @@ def test_seed_from_result_rule(ora, pkg):
         explained |= hit
     assert explained.all()
     # and from the second sample on the colours differ between the rules
-    keep2, _ = ora.render_streams(sp, pl, cam, W, H, 1 << 16, 2, start)
+    keep2, _ = ora.render_streams(sp, pl, cam, W, H, 1 << 16, 2, start, seed_rule=ora.SEED_KEEP_ACCUMULATOR)
     res2, _ = ora.render_streams(sp, pl, cam, W, H, 1 << 16, 2, start, seed_rule=ora.SEED_FROM_RESULT)
     assert not np.array_equal(keep2[0], res2[0])
+    auto2, _ = ora.render_streams(sp, pl, cam, W, H, 1 << 16, 2, start)
+    assert_planes_equal(auto2, res2, "the default (no ray-splitting material) is the result's seed")
 
 
 def test_step_cap_bookkeeping(ora, pkg):
@@ -64,8 +67,9 @@ def test_step_cap_bookkeeping(ora, pkg):
     w, h = 20, 12
     start = initial_planes(ora, w, h)
     for cap in (1, 3, 64):
-        chain, live, cut = ora.render_streams(sp, pl, cam, w, h, cap, 2, start, want_truncated=True)
-        wav, live_w, dropped, steps, cut_w = ora.render_streams_wavefront(sp, pl, cam, w, h, cap, 2, start, want_truncated=True)
+        keep = ora.SEED_KEEP_ACCUMULATOR                       # the tree walk's rule (it exists for GLASS)
+        chain, live, cut = ora.render_streams(sp, pl, cam, w, h, cap, 2, start, want_truncated=True, seed_rule=keep)
+        wav, live_w, dropped, steps, cut_w = ora.render_streams_wavefront(sp, pl, cam, w, h, cap, 2, start, want_truncated=True, seed_rule=keep)
         tree, live_t, dropped_t, longest, cut_t = ora.render_streams_tree(sp, pl, cam, w, h, cap, 2, start)
         assert_planes_equal(wav, chain, "cap %d stream vs chain" % cap)
         assert_planes_equal(tree, chain, "cap %d tree vs chain" % cap)
@@ -97,4 +101,4 @@ def test_tree_order_equals_stream_order_up_to_rounding(ora, pkg):
     # without GLASS the tree walk is the chain
     sp16, _ = pkg.world.scene16()
     assert_planes_equal(ora.render_streams_tree(sp16, pl, cam, W, H, 1 << 16, 2, start)[0],
-                        ora.render_streams(sp16, pl, cam, W, H, 1 << 16, 2, start)[0], "tree without glass")
+                        ora.render_streams(sp16, pl, cam, W, H, 1 << 16, 2, start, seed_rule=ora.SEED_KEEP_ACCUMULATOR)[0], "tree without glass")

@@ -131,10 +131,10 @@ def test_streams_equals_inline_for_first_sample_mostly(ora, pkg):
     w, h = 64, 48
     start = initial_planes(ora, w, h)
     inl, _ = ora.render_inline(sp, pl, cam, w, h, 64, 1, start)
-    stm, _ = ora.render_streams(sp, pl, cam, w, h, 1 << 16, 1, start)
+    stm, _ = ora.render_streams(sp, pl, cam, w, h, 1 << 16, 1, start, seed_rule=ora.SEED_KEEP_ACCUMULATOR)
     same = np.mean((inl[0] == stm[0]) & (inl[1] == stm[1]) & (inl[2] == stm[2]))
     assert same > 0.98
-    # updateSeed: the ORIGINAL seed advanced by exactly one draw
+    # updateSeed under the keep-accumulator reading of `combine`: the ORIGINAL seed advanced by exactly one draw
     _, _, end = ora.sfc32_stream([p[0, 0] for p in start[3:]], 1)
     assert tuple(int(p[0, 0]) for p in stm[3:]) == tuple(end)
 

@@ -21,11 +21,14 @@ WORKLOADS = {
     "c2": ("s16", "inline", "auto"), "streams": ("s16", "streams", "auto"), "s16_stream": ("s16", "streams", "stream"),
     "glass_tree": ("glass", "streams", "auto"), "glass_stream": ("glass", "streams", "stream"),
     "s16_stream_b16": ("s16", "streams", "stream16"), "glass_stream_b8": ("glass", "streams", "stream8"),
-    "glass_stream_b32": ("glass", "streams", "stream32"),
+    "glass_stream_b32": ("glass", "streams", "stream32"), "glass_stream_b16": ("glass", "streams", "stream16"),
+    "glass_stream_b64": ("glass", "streams", "stream64"), "glass_stream_b4": ("glass", "streams", "stream4"),
 }
 
 
 def one(lib, names, width=1920, height=1080, spp=64, repeats=7):
+    if os.environ.get("PTMI_AB_SHAPE"):                    # e.g. 3840x2160x64
+        width, height, spp = (int(v) for v in os.environ["PTMI_AB_SHAPE"].split("x"))
     pkg = graft.load_package()
     if lib != "default":
         pkg.binding._lib = None
@@ -57,6 +60,12 @@ def one(lib, names, width=1920, height=1080, spp=64, repeats=7):
                 c.synchronize()
                 times.append((time.perf_counter() - t0) * 1e3)
             out[name] = round(min(times), 3)
+            if form.startswith("stream"):
+                c.reset_stats()
+                c.render(cam, 8, spp, algorithm)
+                st = c.stats()
+                if st["stream_rays_spilled"] or st["stream_rays_dropped"]:
+                    out[name + "_spilled/dropped"] = [st["stream_rays_spilled"], st["stream_rays_dropped"]]
     return out
 
 
@@ -72,7 +81,7 @@ def main():
         print(json.dumps(one(sys.argv[2], sys.argv[3].split(","))))
         return
     args = sys.argv[2:] if len(sys.argv) >= 2 and sys.argv[1] == "run" else sys.argv[1:]
-    names = [n for n in WORKLOADS if n != "s16_stream_b16"]
+    names = ["c2", "streams", "s16_stream", "glass_tree", "glass_stream"]
     if args and args[0] == "--workloads":
         names = args[1].split(",")
         args = args[2:]

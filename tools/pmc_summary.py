@@ -48,11 +48,13 @@ def main():
             rec["valu_wave_instr_per_call"] = round(cc["SQ_INSTS_VALU"] / calls[k])
             if "SQ_THREAD_CYCLES_VALU" in cc:
                 rec["active_lanes_per_valu_instr"] = round(cc["SQ_THREAD_CYCLES_VALU"] / cc["SQ_INSTS_VALU"], 2)
-            n_simd = 1024.0
+            n_simd, n_xcd = 1024.0, 8.0
             if "GRBM_GUI_ACTIVE" in cc and ns[k]:
-                clock_ghz = cc["GRBM_GUI_ACTIVE"] / ns[k]
-                rec["clock_ghz_from_GRBM_GUI_ACTIVE"] = round(clock_ghz, 3)
-                rec["simd_cycles_per_valu_instr"] = round(n_simd * cc["GRBM_GUI_ACTIVE"] / cc["SQ_INSTS_VALU"], 3)
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs (each counts its own busy cycles): one XCD's share is the launch's
+                # duration in shader clocks
+                cycles = cc["GRBM_GUI_ACTIVE"] / n_xcd
+                rec["clock_ghz_from_GRBM_GUI_ACTIVE"] = round(cycles / ns[k], 3)
+                rec["simd_cycles_per_valu_instr"] = round(n_simd * cycles / cc["SQ_INSTS_VALU"], 3)
         if "SQ_WAIT_INST_ANY" in cc and "SQ_WAVE_CYCLES" in cc:
             rec["wave_cycles_waiting_share"] = round(cc["SQ_WAIT_INST_ANY"] / cc["SQ_WAVE_CYCLES"], 3)
         if "FETCH_SIZE" in cc:

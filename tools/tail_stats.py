@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""tail_stats.py [s16|glass] -- how much of a stream-form launch its end costs (diagnostic build -DPTMI_TAIL_STATS of the
+pixels kernel): every persistent wave stamps its start and end (s_memtime), counts its loop trips and the lanes that held an
+item in each.  Prints what share of the wave-time of the launch lies after waves have ended (the drain), and the mean
+number of lanes with an item per trip."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+
+def main():
+    pkg = graft.load_package()
+    lib = os.path.join(ROOT, "build", "ab", "tailstats.so")
+    if not os.path.exists(lib):
+        os.makedirs(os.path.dirname(lib), exist_ok=True)
+        pkg._build.build_lib(out=lib, extra_flags=["-DPTMI_TAIL_STATS"])
+    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        return
+    pkg.binding._lib = None
+    pkg.binding.load_library(lib)
+    B = pkg.binding
+    cam = pkg.world.initial_camera()
+    sp, pl = pkg.world.scene16()
+    out = {}
+    for spp in (64,):
+        with pkg.Context(0) as c:
+            c.set_scene(sp, pl)
+            c.resize(1920, 1080)
+            c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+            c.init_output(0x5EED1234)
+            for _ in range(40):
+                c.render(cam, 8, spp, pkg.STREAMS)
+            c.synchronize()
+            c.reset_stats()
+            c.set_timing(True)
+            c.render(cam, 8, spp, pkg.STREAMS)
+            ms = c.stats()["last_render_ms"]
+            w = c.debug_counters()
+            u64 = lambda i: int(w[i]) | (int(w[i + 1]) << 32)    # noqa: E731
+            first, last, total, waves, lane_trips, trips, longest = (~u64(8)) & (2 ** 64 - 1), u64(10), u64(12), u64(14), u64(16), u64(18), u64(20)
+            span = last - first
+            out["spp_%d" % spp] = {"render_ms": round(ms, 3), "waves": waves, "span_ticks": span, "mean_wave_ticks": round(total / max(waves, 1)),
+                                   "longest_wave_ticks": longest, "drain_share_of_wave_time": round(1.0 - total / (waves * span), 4) if waves and span else None,
+                                   "lanes_with_an_item_per_trip": round(lane_trips / max(trips, 1), 2), "trips_per_wave": round(trips / max(waves, 1), 1),
+                                   "waves_by_duration_bins_of_2^19_cycles": [int(x) for x in w[24:64]]}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
