@@ -71,7 +71,14 @@ struct ptmi_ctx {
     void *hit_block = nullptr;       // stream form: the start hits of the pixels, in regions (HitList)
     size_t hit_capacity = 0;
     unsigned int *d_hit_counts = nullptr;   // ... records per region
+    unsigned long long *d_hit_missed = nullptr;   // ... and the pixels of every region that have none
     unsigned int hit_regions = 0;
+    // The start-hit list is a function of (camera, scene, shape, partition, dispatch order) only -- every sample of a pixel
+    // shoots the same primary ray, in every call -- so it is kept until one of them changes.
+    struct HitKey { ptmi_camera cam; uint64_t scene_version, order_generation; int dims[8]; unsigned int region_slots; int cap_allows_split; const void *planes_r; } hit_key{};
+    bool hit_list_valid = false;
+    uint64_t order_generation = 0;          // bumped whenever the dispatch order (d_quad_order, or its use) changes
+    uint64_t hit_split_pixels = 0;          // pixels whose glass primary hit the list replaced by its children's hits
     void *d_snapshots = nullptr;     // stream form, split kernel: the seed every item starts from
     size_t snapshot_bytes = 0;
     int cus = 0;                     // compute units of the device (persistent grids)
@@ -250,7 +257,7 @@ RayQueue carve_queue(void *block, size_t capacity, int which)
 //   * GLASS (or PTMI_OPT_STREAM_BATCH > 0): streams_split_kernel -- items of (start hit, sample range), children through the
 //     waves' LDS rings.  The predicate `null state` (Trace.hs:166-170) is the overflow stream's length: read back ONCE, after
 //     the launch; only if children really travelled through HBM does the host play `awhile`, one launch per overflow level.
-int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
+int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_camera &camera)
 {
     const size_t n = (size_t)a.rows_local * a.width;
     if (n == 0 || n_spp <= 0) return PTMI_OK;
@@ -264,20 +271,34 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
         PTMI_HIP(c, hipStreamSynchronize(c->stream));
         if (c->hit_block) { (void)hipFree(c->hit_block); c->hit_block = nullptr; c->hit_capacity = 0; }
         if (c->d_hit_counts) { (void)hipFree(c->d_hit_counts); c->d_hit_counts = nullptr; c->hit_regions = 0; }
+        if (c->d_hit_missed) { (void)hipFree(c->d_hit_missed); c->d_hit_missed = nullptr; }
+        c->hit_list_valid = false;
         PTMI_HIP(c, hipMalloc(&c->hit_block, (size_t)kHitListWords * hit_slots * 4));
         c->hit_capacity = hit_slots;
         PTMI_HIP(c, hipMalloc(&c->d_hit_counts, (size_t)n_regions * sizeof(unsigned int)));
+        PTMI_HIP(c, hipMalloc(&c->d_hit_missed, (size_t)n_regions * sizeof(unsigned long long)));
         c->hit_regions = n_regions;
     }
     if (!c->d_qcount) PTMI_HIP(c, hipMalloc(&c->d_qcount, (size_t)kLvWords * sizeof(unsigned int)));
     HitList hits;
     hits.base = static_cast<uint32_t *>(c->hit_block);
     hits.counts = c->d_hit_counts;
+    hits.missed = c->d_hit_missed;
     hits.region_slots = region_slots;
     hits.n_regions = n_regions;
     // the statistics accumulate on the device over the whole call; cursors start from zero
     PTMI_HIP(c, hipMemsetAsync(c->d_qcount, 0, (size_t)kLvWords * sizeof(unsigned int), c->stream));
     auto cursor_of = [&](int level) { return (size_t)(kLvCursor + kLvPerLevel * (level % kLvMaxLevels)) * kCounterStride; };
+    ptmi_ctx::HitKey key{};
+    key.cam = camera; key.scene_version = c->scene_version; key.order_generation = a.quad_order ? c->order_generation : 0;
+    const int key_dims[8] = {a.width, a.height, a.rows_local, a.stripe_rows, a.n_parts, a.part, a.quad_order ? 1 : 0, 0};
+    std::memcpy(key.dims, key_dims, sizeof key_dims);
+    key.region_slots = region_slots; key.cap_allows_split = a.stream_step_cap >= 3 ? 1 : 0; key.planes_r = nullptr;
+    const bool list_kept = c->hit_list_valid && std::memcmp(&key, &c->hit_key, sizeof key) == 0;
+    if (!list_kept) {
+        PTMI_HIP(c, launch_streams_primary(a, hits, c->d_qcount, c->stream));
+        c->hit_key = key; c->hit_list_valid = true;
+    }
     ItemArgs it{};
     it.hits = hits;
     it.n_positions = n_regions / 4u;
@@ -293,7 +314,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
         // planes in between -- and the positions into two CHAINS that run on two streams: within a chain the passes follow each
         // other in stream order (nothing else orders a pixel's samples), and while the last items of one chain's launch end, the
         // waves of the other chain's launch take the slots they leave.
-        PTMI_HIP(c, launch_streams_primary(a, hits, c->d_qcount, n_spp, c->stream));
+        PTMI_HIP(c, launch_streams_advance_missed(a, hits, n_spp, c->stream));
         PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, kItersBytes, c->stream));
         // (measured, S16: 1080p / 64 spp 4.65 -> 4.53 ms with two passes, 4.59 with four -- every launch loads and stores all
         // items once more; 4K / 64 spp, eighteen items per lane: 16.19 -> 16.33.  Passes pay where a lane sees few, long items.)
@@ -384,7 +405,6 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
     }
     std::vector<unsigned int> base((size_t)kLvMaxLevels, 0u);   // per level (mod kLvMaxLevels): where its reserved blocks start
 
-    PTMI_HIP(c, launch_streams_primary(a, hits, c->d_qcount, 0, c->stream));
     PTMI_HIP(c, launch_streams_seeds(a.planes, static_cast<uint4 *>(c->d_snapshots), (long long)n, passes, per_item, n_spp, c->stream));
     it.passes = passes; it.samples_per_pass = per_item;
     it.chunk_cursor = tickets_of(0);
@@ -404,12 +424,16 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
         for (int k = 0; k < kLvEmitShards; ++k) total += raw[cursor_of(level) + (size_t)(2 + k) * kCounterStride];
         return total;
     };
-    auto read_counters = [&]() -> int {
-        PTMI_HIP(c, hipMemcpyAsync(raw.data(), c->d_qcount, (size_t)kLvWords * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    auto read_counters = [&](int levels) -> int {           // the statistics and the lines of the first `levels` levels
+        int lines = kLvCursor + kLvPerLevel * levels;
+        if (lines > kLvTickets) lines = kLvTickets;
+        PTMI_HIP(c, hipMemcpyAsync(raw.data(), c->d_qcount, (size_t)lines * kCounterStride * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
         PTMI_HIP(c, hipStreamSynchronize(c->stream));
         return PTMI_OK;
     };
-    if (int rc = read_counters()) return rc;
+    // stream_iterations lives in the per-pixel kernels' sharded counter: shard 0 carries this form's figure, copied on the device
+    PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, kItersBytes, c->stream));
+    if (int rc = read_counters(1)) return rc;
     // `null state` (Trace.hs:166-170): the loop goes on while the last level left children in its overflow stream (a level
     // cuts the rays the step cap forbids as it reads them, and counts them)
     for (int level = 0; c->has_glass && emitted_of(level) > 0u;) {
@@ -431,19 +455,19 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp)
         // the counter words of this level: long idle when they come round again
         PTMI_HIP(c, hipMemsetAsync(lv.out_count, 0, (size_t)kLvPerLevel * kCounterStride * sizeof(unsigned int), c->stream));
         PTMI_HIP(c, launch_streams_level(a, lv, lgrid, c->stream));
-        if (int rc = read_counters()) return rc;
+        if (int rc = read_counters(level + 1)) return rc;
     }
     for (int k = 0; k < kLvLiveShards; ++k) c->live_host += raw[(size_t)(kLvLive + k) * kCounterStride];
     // the two children of every glass primary hit whose split is cached in the start list: counted here, per sample
-    c->live_host += 2ull * raw[(size_t)kLvSplitPixels * kCounterStride] * (uint64_t)n_spp;
+    if (!list_kept) c->hit_split_pixels = raw[(size_t)kLvSplitPixels * kCounterStride];
+    c->live_host += 2ull * c->hit_split_pixels * (uint64_t)n_spp;
     c->rays_dropped += raw[(size_t)kLvDropped * kCounterStride];
     c->rays_truncated += raw[(size_t)kLvCut * kCounterStride];
     c->rays_spilled += raw[(size_t)kLvSpilled * kCounterStride];
     unsigned int longest = raw[(size_t)kLvDeepest * kCounterStride];            // stream_iterations: the deepest step of this call
+    if (c->hit_split_pixels && longest < 2) longest = 2;                        // the children of the cached glass primary hits: traceStep 2
     if (longest == 0) longest = 1;                                              // every primary ray missed: one traceStep all the same
-    PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, kItersBytes, c->stream));             // (sharded for the per-pixel kernels: shard 0 carries this form's figure)
-    PTMI_HIP(c, hipMemcpyAsync(c->d_iters, &longest, sizeof longest, hipMemcpyHostToDevice, c->stream));
-    PTMI_HIP(c, hipStreamSynchronize(c->stream));
+    PTMI_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->d_iters), (int)longest, 1, c->stream));
     return PTMI_OK;
 }
 
@@ -478,7 +502,7 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
         const unsigned int n_quads = quad_positions(width, rows_local);
         if (n_quads > c->quad_capacity) {
             if (c->d_quad_cost) { PTMI_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_quad_cost); (void)hipFree(c->d_quad_order); (void)hipFree(c->d_quad_class); }
-            c->d_quad_cost = c->d_quad_order = c->d_quad_class = nullptr; c->quad_capacity = 0; c->order_state = 0;
+            c->d_quad_cost = c->d_quad_order = c->d_quad_class = nullptr; c->quad_capacity = 0; c->order_state = 0; ++c->order_generation;
             PTMI_HIP(c, hipMalloc(&c->d_quad_cost, n_quads * sizeof(unsigned int)));
             PTMI_HIP(c, hipMalloc(&c->d_quad_order, n_quads * sizeof(unsigned int)));
             PTMI_HIP(c, hipMalloc(&c->d_quad_class, n_quads * sizeof(unsigned int)));
@@ -488,12 +512,15 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
         key.cam = *camera; key.scene_version = c->scene_version;
         const int dims[8] = {width, height, rows_local, stripe_rows, n_parts, part, bounce_limit, stream_form ? 2 : algorithm};
         std::memcpy(key.dims, dims, sizeof dims);
-        if (std::memcmp(&key, &c->order_key, sizeof key) != 0) { c->order_key = key; c->order_state = 0; }
+        if (std::memcmp(&key, &c->order_key, sizeof key) != 0) { c->order_key = key; c->order_state = 0; ++c->order_generation; }
         // order_state counts the launches made with this key.  Every launch adds its costs (a 1-spp launch says little
         // on its own: the compat entry renders one sample per call); the order is rebuilt before launch 1, 2, 4, 8, ...
         const int launches = c->order_state;
         if (launches == 0) PTMI_HIP(c, hipMemsetAsync(c->d_quad_cost, 0, n_quads * sizeof(unsigned int), c->stream));
-        else if ((launches & (launches - 1)) == 0 && launches < (1 << 20)) PTMI_HIP(c, launch_quad_order(c->d_quad_cost, c->d_quad_order, c->d_quad_class, n_quads, c->stream));
+        else if ((launches & (launches - 1)) == 0 && launches < (1 << 20)) {
+            PTMI_HIP(c, launch_quad_order(c->d_quad_cost, c->d_quad_order, c->d_quad_class, n_quads, c->stream));
+            ++c->order_generation;
+        }
         if (launches > 0) a.quad_order = c->d_quad_order;
         if (launches < (stream_form ? (1 << 11) : (1 << 20))) { a.quad_cost = c->d_quad_cost; next_order_state = launches + 1; }   // the sums stay far from 2^32
     }
@@ -512,7 +539,7 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
     if (algorithm == PTMI_INLINE) {
         PTMI_HIP(c, launch_render_inline(a, c->variant, c->stream));
     } else if (stream_form) {                              // rays travel through streams in HBM (PTMI_OPT_STREAMS_FORM; variant 9)
-        if (int rc = render_streams_wavefront(c, a, n_spp)) return rc;
+        if (int rc = render_streams_wavefront(c, a, n_spp, *camera)) return rc;
     } else if (c->has_glass) {                             // rays may split: the per-pixel tree walk
         PTMI_HIP(c, launch_render_streams_tree(a, c->variant, c->stream));
     } else {
@@ -619,6 +646,7 @@ void ptmi_destroy(ptmi_ctx *c)
     if (c->queue_block) (void)hipFree(c->queue_block);
     if (c->hit_block) (void)hipFree(c->hit_block);
     if (c->d_hit_counts) (void)hipFree(c->d_hit_counts);
+    if (c->d_hit_missed) (void)hipFree(c->d_hit_missed);
     if (c->d_snapshots) (void)hipFree(c->d_snapshots);
     if (c->spill_block) (void)hipFree(c->spill_block);
     if (c->d_qcount) (void)hipFree(c->d_qcount);

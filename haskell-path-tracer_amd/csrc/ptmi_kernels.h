@@ -97,6 +97,7 @@ constexpr int kLvWords = (kLvTickets + 8 * kLvMaxLaunches) * kCounterStride;
 struct HitList {             // records of 16 words: [position xyz, normal x] [normal yz, direction xy] [direction z, throughput xyz] [primitive, local pixel index, meta, quad]
     uint32_t *base;
     unsigned int *counts;    // records per region
+    unsigned long long *missed;   // per region: the lanes (pixels of the tile) that have no start hit
     unsigned int region_slots;   // 64, or 128 when a primary hit can split
     unsigned int n_regions;
     PTMI_HD float4 *record(unsigned int i) const { return reinterpret_cast<float4 *>(base) + (size_t)i * 4; }
@@ -142,8 +143,9 @@ unsigned int streams_spill_records();   // records of a wave's spill queue in HB
 unsigned int streams_regions(int width, int rows_local);    // regions of the start-hit list
 hipError_t launch_streams_seeds(Planes p, uint4 *snapshots, long long n, int passes, int samples_per_pass, int draws, hipStream_t stream);
 hipError_t launch_streams_level(const RenderArgs &a, const LevelArgs &lv, unsigned int grid, hipStream_t stream);
-// advance_missed: updateSeeds a pixel without start hits receives here (the ordered item kernel advances the others itself)
-hipError_t launch_streams_primary(const RenderArgs &a, HitList hits, unsigned int *counters, int advance_missed, hipStream_t stream);
+hipError_t launch_streams_primary(const RenderArgs &a, HitList hits, unsigned int *counters, hipStream_t stream);
+// updateSeeds for the pixels without start hits (the ordered item kernel advances the others itself)
+hipError_t launch_streams_advance_missed(const RenderArgs &a, HitList hits, int draws, hipStream_t stream);
 unsigned int streams_first_block();   // output slots every wave of a level owns from the start
 
 hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t stream);

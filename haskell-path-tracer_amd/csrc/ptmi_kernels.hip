@@ -1726,28 +1726,35 @@ template <typename T> __device__ __forceinline__ T &plane_at(T *base, uint32_t b
 // step cap cannot cut the children (>= 3) and the glass hit itself emits nothing (its emittance would have to be added
 // once per sample).  advance_missed: a pixel without start hits gets its updateSeeds here (streams_pixels_kernel does
 // the others' itself).  `counters`: the stream form's counter block (kLvSplitPixels, kLvDeepest).
+// which pixel a lane of the primary kernel (and of the kernel that advances the missed pixels' seeds) looks at
 template <bool TILES>
-__global__ void __launch_bounds__(256) streams_primary_kernel(const RenderArgs a, const HitList out, unsigned int *counters, int advance_missed)
+__device__ __forceinline__ bool primary_pixel(const RenderArgs &a, unsigned int &quad, unsigned int &region, long long &pixel)
 {
-    const int ns = a.scene.n_spheres, np = a.scene.n_planes;
-    const float4 *S = a.scene.packed;                        // one evaluation per pixel and call: scalar loads will do
-    const float4 *M = S + a.scene.geom_f4();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned int position = blockIdx.x;
-    const unsigned int quad = (TILES && a.quad_order) ? a.quad_order[position] : position;
-    const unsigned int region = position * 4u + (unsigned int)wave;
-    long long pixel; bool valid;
+    quad = (TILES && a.quad_order) ? a.quad_order[position] : position;
+    region = position * 4u + (unsigned int)wave;
     if (TILES) {
         const unsigned int tile = quad * 4u + (unsigned int)wave;
         const int tiles_x = (a.width + 7) / 8;
         const int tx = (int)(tile % (unsigned)tiles_x), ty = (int)(tile / (unsigned)tiles_x);
         const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
         pixel = (long long)y * a.width + x;
-        valid = x < a.width && y < a.rows_local;
-    } else {
-        pixel = (long long)region * 64 + lane;
-        valid = pixel < (long long)a.rows_local * a.width;
+        return x < a.width && y < a.rows_local;
     }
+    pixel = (long long)region * 64 + lane;
+    return pixel < (long long)a.rows_local * a.width;
+}
+
+template <bool TILES>
+__global__ void __launch_bounds__(256) streams_primary_kernel(const RenderArgs a, const HitList out, unsigned int *counters)
+{
+    const int ns = a.scene.n_spheres, np = a.scene.n_planes;
+    const float4 *S = a.scene.packed;                        // one evaluation per pixel and call: scalar loads will do
+    const float4 *M = S + a.scene.geom_f4();
+    const int lane = threadIdx.x & 63;
+    unsigned int quad, region; long long pixel;
+    const bool valid = primary_pixel<TILES>(a, quad, region, pixel);
     int n_rec = 0;                                            // records this pixel contributes: 0, 1 or 2
     V3 pos[2], nor[2], dir[2], thr[2];
     int prim[2] = {0, 0};
@@ -1790,16 +1797,13 @@ __global__ void __launch_bounds__(256) streams_primary_kernel(const RenderArgs a
                 n_rec = 1;
             }
         }
-        if (advance_missed > 0 && n_rec == 0) {               // updateSeed is all a sample does to this pixel
-            Sfc32 sd; sd.a = a.planes.sa[pixel]; sd.b = a.planes.sb[pixel]; sd.c = a.planes.sc[pixel]; sd.counter = a.planes.sctr[pixel];
-            for (int j = 0; j < advance_missed; ++j) (void)random_float(sd);
-            a.planes.sa[pixel] = sd.a; a.planes.sb[pixel] = sd.b; a.planes.sc[pixel] = sd.c; a.planes.sctr[pixel] = sd.counter;
-        }
     }
     const unsigned long long m0 = __ballot(n_rec > 0), m1 = __ballot(n_rec > 1), ms = __ballot(split);
+    const unsigned long long missed = __ballot(valid && n_rec == 0);      // updateSeed is all a sample does to these pixels
     const unsigned int c0 = (unsigned int)__builtin_popcountll(m0), c1 = (unsigned int)__builtin_popcountll(m1);
     if (lane == 0) {
         out.counts[region] = c0 + c1;
+        out.missed[region] = missed;
         if (ms) {
             atomicAdd(counters + kLvSplitPixels * kCounterStride, (unsigned int)__builtin_popcountll(ms));
             if (2u > __hip_atomic_load(counters + kLvDeepest * kCounterStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
@@ -1818,6 +1822,21 @@ __global__ void __launch_bounds__(256) streams_primary_kernel(const RenderArgs a
             r[3] = float4{u2f((uint32_t)(e == 0 ? prim[0] : prim[1])), u2f((uint32_t)pixel), u2f(e == 0 ? meta[0] : meta[1]), u2f(quad)};
         }
     }
+}
+
+// updateSeed (Trace.hs:190-191) for the pixels WITHOUT start hits (their primary ray misses, or both children of their glass
+// primary hit do): `draws` draws each.  The pixels with start hits are streams_pixels_kernel's.  Same pixel mapping as the
+// primary kernel, whose missed[] masks (one per region) say which lanes have work.
+template <bool TILES>
+__global__ void __launch_bounds__(256) streams_advance_missed_kernel(const RenderArgs a, const HitList hits, int draws)
+{
+    unsigned int quad, region; long long pixel;
+    const bool valid = primary_pixel<TILES>(a, quad, region, pixel);
+    const unsigned long long missed = hits.missed[region];
+    if (!valid || !((missed >> (threadIdx.x & 63)) & 1ull)) return;
+    Sfc32 sd; sd.a = a.planes.sa[pixel]; sd.b = a.planes.sb[pixel]; sd.c = a.planes.sc[pixel]; sd.counter = a.planes.sctr[pixel];
+    for (int j = 0; j < draws; ++j) (void)random_float(sd);
+    a.planes.sa[pixel] = sd.a; a.planes.sb[pixel] = sd.b; a.planes.sc[pixel] = sd.c; a.planes.sctr[pixel] = sd.counter;
 }
 
 // The chunk cursor of the item kernels.  A chunk is 64 slots of a region of the start-hit list; the regions come in groups
@@ -2048,6 +2067,10 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
 #endif
 constexpr unsigned int kRing = PTMI_RING;                     // records of a wave's child ring (a power of two, <= 64)
 constexpr unsigned int kSpill = 256;                          // records of a wave's spill queue in HBM (a power of two)
+#ifndef PTMI_ITEM_BATCH
+#define PTMI_ITEM_BATCH 1
+#endif
+constexpr unsigned int kItemBatch = PTMI_ITEM_BATCH;          // lanes without an item a wave waits for before it runs the refill block (its loads stall the whole wave)
 template <bool LDS_SCENE, bool TILES>
 __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_kernel(const RenderArgs a, const ItemArgs it)
 {
@@ -2097,7 +2120,16 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
         }
     };
 
+#ifdef PTMI_SPLIT_STATS
+    unsigned int st_trips = 0, st_dead = 0, st_free = 0, st_ring = 0, st_start = 0, st_end = 0, st_refill = 0, st_shade = 0, st_glass = 0, st_trace = 0, st_busy = 0;
+    const unsigned long long t_start = __builtin_readcyclecounter();
+#endif
     for (;;) {
+#ifdef PTMI_SPLIT_STATS
+        ++st_trips;
+        st_dead += (unsigned int)__builtin_popcountll(__ballot(pending && near_zero(throughput)));
+        st_busy += (unsigned int)__builtin_popcountll(__ballot(busy));
+#endif
         // ---- a hit whose ray arrived with near-zero throughput (numNewRays = 0, Trace.hs:329-331) adds its emittance and nothing
         // else of it survives: the lineage ends here
         if (pending && near_zero(throughput)) {
@@ -2107,7 +2139,10 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
         }
         // ---- refill: lanes without an item take the next ones of the wave's chunk (whatever ray they are tracing meanwhile)
         const unsigned long long empty = __ballot(!busy);
-        if (empty && chunks_left(cur)) {                      // wave-uniform
+        if ((unsigned int)__builtin_popcountll(empty) >= kItemBatch && chunks_left(cur)) {     // wave-uniform
+#ifdef PTMI_SPLIT_STATS
+            ++st_refill;
+#endif
             const unsigned int want = (unsigned int)__builtin_popcountll(empty), avail = cur.len - cur.taken;
             const unsigned int take = want < avail ? want : avail;
             const unsigned int rank = rank_in(empty);
@@ -2134,6 +2169,12 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
         const bool free_lane = !pending && !has_ray;
         const unsigned long long free_m = __ballot(free_lane);
         bool took = false;
+#ifdef PTMI_SPLIT_STATS
+        st_free += (unsigned int)__builtin_popcountll(free_m);
+        st_ring += ring_n < (unsigned int)__builtin_popcountll(free_m) ? ring_n : (unsigned int)__builtin_popcountll(free_m);
+        st_start += (unsigned int)__builtin_popcountll(__ballot(free_lane && busy && samples_left > 0));
+        st_end += (unsigned int)__builtin_popcountll(__ballot(free_lane && busy && samples_left <= 0));
+#endif
         if (ring_n && free_m) {                               // wave-uniform
             const unsigned int want = (unsigned int)__builtin_popcountll(free_m);
             const unsigned int take = want < ring_n ? want : ring_n;
@@ -2214,6 +2255,10 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
         V3 ko = o, kd = o, kt = o; Sfc32 ks = seed;
         const bool alive = pending && !near_zero(throughput);
         live_w += (unsigned int)__builtin_popcountll(__ballot(alive));        // one child per shaded hit ...
+#ifdef PTMI_SPLIT_STATS
+        st_shade += (unsigned int)__builtin_popcountll(__ballot(alive));
+        st_glass += (unsigned int)__builtin_popcountll(__ballot(alive && f2u(M[2 * idx + 1].x) == 2u));
+#endif
         if (alive) {
             const float4 ma = M[2 * idx], mb = M[2 * idx + 1];
             V3 contribution;
@@ -2279,6 +2324,9 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
         }
         // ---- trace round: one traceStep (Trace.hs:272-294) for every lane that holds a ray
         cut_w += (unsigned int)__builtin_popcountll(__ballot(has_ray && depth >= step_cap));
+#ifdef PTMI_SPLIT_STATS
+        st_trace += (unsigned int)__builtin_popcountll(__ballot(has_ray));
+#endif
         if (has_ray) {
             if (depth >= step_cap) {                          // the safety cap (the reference has none): the ray exists, but is never traced
                 has_ray = false;
@@ -2294,6 +2342,20 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
             }
         }
     }
+#ifdef PTMI_SPLIT_STATS
+    if (lane == 0 && a.work_counter) {      // diagnostic build: per-round lane participation, summed over the waves; wave durations
+        unsigned int *wc = a.work_counter;
+        atomicAdd(wc + 1, st_trips); atomicAdd(wc + 2, st_dead); atomicAdd(wc + 3, st_free); atomicAdd(wc + 4, st_ring);
+        atomicAdd(wc + 5, st_start); atomicAdd(wc + 6, st_end); atomicAdd(wc + 7, st_refill); atomicAdd(wc + 8, st_shade);
+        atomicAdd(wc + 9, st_glass); atomicAdd(wc + 10, st_trace); atomicAdd(wc + 11, st_busy);
+        const unsigned long long dur = __builtin_readcyclecounter() - t_start;
+        atomicAdd(reinterpret_cast<unsigned long long *>(wc + 12), dur);
+        atomicMax(reinterpret_cast<unsigned long long *>(wc + 14), dur);
+        atomicAdd(wc + 16, 1u);
+        const unsigned long long bin = dur >> 20;
+        atomicAdd(wc + 24 + (bin < 39ull ? (unsigned int)bin : 39u), 1u);
+    }
+#endif
     // what is left of this wave's last overflow block: holes
     if (it.may_emit) {
         const unsigned int end = blk_end < it.out.capacity ? blk_end : it.out.capacity;
@@ -2901,12 +2963,21 @@ unsigned int streams_regions(int width, int rows_local)
     return (unsigned int)((((n + 63ull) / 64ull) + 3ull) & ~3ull);
 }
 
-hipError_t launch_streams_primary(const RenderArgs &a, HitList hits, unsigned int *counters, int advance_missed, hipStream_t stream)
+hipError_t launch_streams_primary(const RenderArgs &a, HitList hits, unsigned int *counters, hipStream_t stream)
 {
     if (hits.n_regions == 0) return hipSuccess;
     const dim3 g(hits.n_regions / 4u), b(256);
-    if (tiles_pay(a)) hipLaunchKernelGGL((streams_primary_kernel<true>), g, b, 0, stream, a, hits, counters, advance_missed);
-    else              hipLaunchKernelGGL((streams_primary_kernel<false>), g, b, 0, stream, a, hits, counters, advance_missed);
+    if (tiles_pay(a)) hipLaunchKernelGGL((streams_primary_kernel<true>), g, b, 0, stream, a, hits, counters);
+    else              hipLaunchKernelGGL((streams_primary_kernel<false>), g, b, 0, stream, a, hits, counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_streams_advance_missed(const RenderArgs &a, HitList hits, int draws, hipStream_t stream)
+{
+    if (hits.n_regions == 0 || draws <= 0) return hipSuccess;
+    const dim3 g(hits.n_regions / 4u), b(256);
+    if (tiles_pay(a)) hipLaunchKernelGGL((streams_advance_missed_kernel<true>), g, b, 0, stream, a, hits, draws);
+    else              hipLaunchKernelGGL((streams_advance_missed_kernel<false>), g, b, 0, stream, a, hits, draws);
     return hipGetLastError();
 }
 

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""split_stats.py -- where the lanes of streams_split_kernel go (diagnostic build -DPTMI_SPLIT_STATS): lane participation in
+every block of the loop, per wave-trip, on the glass scene at 1080p / 64 spp; and how the waves' durations spread."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+
+def main():
+    pkg = graft.load_package()
+    lib = os.path.join(ROOT, "build", "ab", "splitstats.so")
+    if not os.path.exists(lib):
+        os.makedirs(os.path.dirname(lib), exist_ok=True)
+        pkg._build.build_lib(out=lib, extra_flags=["-DPTMI_SPLIT_STATS"])
+    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        return
+    pkg.binding._lib = None
+    pkg.binding.load_library(lib)
+    B = pkg.binding
+    cam = pkg.world.initial_camera()
+    sp, pl = pkg.world.glass_scene()
+    out = {}
+    for w, h, spp, parts in ((1920, 1080, 64, 1), (3840, 2160, 512, 8)):
+        with pkg.Context(0) as c:
+            c.set_scene(sp, pl)
+            if parts > 1:
+                c.set_partition(10, parts, 0)
+            c.resize(w, h)
+            c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+            c.init_output(0x5EED1234)
+            for _ in range(6):
+                c.render(cam, 8, spp, pkg.STREAMS)
+            c.synchronize()
+            c.reset_stats()
+            c.set_timing(True)
+            c.render(cam, 8, spp, pkg.STREAMS)
+            st = c.stats()
+            wc = [int(x) for x in c.debug_counters()]
+            trips = max(wc[1], 1)
+            waves = max(wc[16], 1)
+            total = wc[12] | (wc[13] << 32)
+            longest = wc[14] | (wc[15] << 32)
+            px = c.local_rows * w
+            out["%dx%d_%dspp_part_of_%d" % (w, h, spp, parts)] = {
+                "render_ms": round(st["last_render_ms"], 3), "wave_trips": wc[1], "wave_trips_per_pixel_sample": round(wc[1] / (px * spp), 3),
+                "per_trip": {"lanes_with_an_item": round(wc[11] / trips, 2), "dead_hits": round(wc[2] / trips, 2), "free_lanes": round(wc[3] / trips, 2),
+                             "taken_from_ring": round(wc[4] / trips, 2), "samples_started": round(wc[5] / trips, 2), "items_ended": round(wc[6] / trips, 3),
+                             "refill_blocks": round(wc[7] / trips, 3), "shades": round(wc[8] / trips, 2), "of_them_glass": round(wc[9] / trips, 2),
+                             "traces": round(wc[10] / trips, 2)},
+                "waves": waves, "mean_wave_cycles": round(total / waves), "longest_wave_cycles": longest,
+                "mean_over_longest": round(total / waves / max(longest, 1), 4), "spilled": st["stream_rays_spilled"], "live": st["live_bounces"],
+                "waves_by_duration_bins_of_2^20_cycles": wc[24:64]}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
