@@ -114,29 +114,94 @@ def load_traffic():
     return t.get("hbm_bytes_per_launch") if t else None
 
 
-def valu_accounting(kernel_ms):
+def valu_accounting(pkg, kernel_ms):
     """The kernel's real bound.  The instruction mix and the cycle count are properties of the code and the workload, not
-    of the run (two boxes of the pool at 2.28 and 2.36 GHz spent the same cycles): profiles/r02_valu_roofline.json holds,
+    of the run (two boxes of the pool at 2.28 and 2.36 GHz spent the same cycles): profiles/rNN_valu_roofline.json holds,
     for the C2 launch, the VALU wave-instructions per launch by category (PMC), the issue cycles their class costs assign
-    to that mix (a lower bound), the SIMD cycles the launch took (GRBM_GUI_ACTIVE) and the active-lane fraction.
-    frac = issue cycles needed / SIMD cycles taken, both from that profile; implied_clock_ghz = the shader clock this
-    run's launch time implies for the same cycle count -- outside 2.1-2.5 GHz the profile no longer describes the binary."""
-    d = load_json("r02_valu_roofline.json")
+    to that mix (a lower bound), the SIMD cycles the launch took (GRBM_GUI_ACTIVE / 8 XCDs) and the active-lane fraction.
+    frac = issue cycles needed / SIMD cycles taken, both from that profile; `stale` says whether the kernel sources have
+    changed since the profile was taken (source_hash); implied_clock_ghz = the shader clock this run's launch time implies
+    for the same cycle count -- outside 2.1-2.5 GHz the profile no longer describes the binary."""
+    d, name = None, None
+    for tag in ("r03", "r02"):
+        d = load_json("%s_valu_roofline.json" % tag)
+        if d:
+            name = "profiles/%s_valu_roofline.json" % tag
+            break
     if not d:
         return None
     try:
         measured = float(d["measured_cycles_in_profile"])
         implied = measured / (d["n_simds"] * kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
+        now = pkg._build.source_hash()
         return {"min_issue_cycles": round(d["min_issue_cycles"]), "measured_cycles": round(measured),
                 "frac": round(d["min_issue_cycles"] / measured, 4),
+                "frac_with_v_fma_f32_at_2_cycles": d.get("frac_with_v_fma_f32_at_2_cycles"),
+                "frac_with_v_fma_f32_as_measured": d.get("frac_with_v_fma_f32_as_measured"),
                 "frac_priced_with_measured_opcode_costs": round(d["priced_with_measured_rates"]["frac"], 4),
                 "active_lane_frac": round(d["active_lane_frac"], 4),
                 "valu_wave_instr_per_launch": round(d["valu_wave_instr_per_launch"]),
                 "avg_issue_cycles_per_instr": round(d["avg_issue_cycles_per_instr"], 3),
                 "implied_clock_ghz": round(implied, 3) if implied else None,
-                "profile_clock_ghz": d["clock_ghz"], "source": "profiles/r02_valu_roofline.json"}
+                "profile_clock_ghz": d["clock_ghz"], "source": name,
+                "profile_source_hash": d.get("source_hash"), "source_hash_now": now,
+                "stale": d.get("source_hash") != now}
     except Exception:
         return None
+
+
+def also_measurements(pkg, torch):
+    """The other BASELINE.json configs and the Streams forms, on this GPU, after the headline: 3 timed steps each behind a
+    short warm-up (clock ramp, recorded dispatch order), resident state, one context each on a stream of its own.
+    kernel_ms: HIP events around the launches on the launch stream (ptmi_set_timing)."""
+    B = pkg.binding
+    cam = pkg.world.initial_camera()
+    scenes = {"s16": pkg.world.scene16(), "main": pkg.world.main_scene(), "glass": pkg.world.glass_scene()}
+    out = []
+
+    def run(name, scene, width, height, spp, limit, algorithm, part_of=0, stripe=10, stream_form=False, warm=3, steps=3, note=None):
+        sp, pl = scenes[scene]
+        with pkg.Context(0) as c:
+            c.set_scene(sp, pl)
+            if part_of > 1:
+                c.set_partition(stripe, part_of, 0)
+            c.resize(width, height)
+            if stream_form:
+                c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+            c.init_output(SEED0)
+            c.set_timing(True)
+            for _ in range(warm):
+                c.render(cam, limit, spp, algorithm)
+            c.synchronize()
+            wall, dev = [], []
+            for _ in range(steps):
+                t0 = time.perf_counter()
+                c.render(cam, limit, spp, algorithm)
+                c.synchronize()
+                wall.append((time.perf_counter() - t0) * 1e3)
+                dev.append(c.stats()["last_render_ms"])
+            rows = c.local_rows
+        ms, kms = sum(wall) / len(wall), sum(dev) / len(dev)
+        rec = {"workload": name, "ms_per_step": round(ms, 4), "kernel_ms": round(kms, 4), "steps": steps,
+               "algorithmic_GBps": round(rows * width * spp * BYTES_PER_PIXEL_SAMPLE / (kms * 1e-3) / 1e9, 1) if kms > 0 else None}
+        if algorithm == pkg.INLINE:
+            rec["Msamples_per_s"] = round(rows * width * spp * limit / (ms * 1e-3) / 1e6, 1)
+        if note:
+            rec["note"] = note
+        out.append(rec)
+
+    run("C0: 800x600, mainScene, limit 15, render Inline, 1 spp per call (the reference's own configuration; compileFor's closure)", "main", 800, 600, 1, 15, pkg.INLINE, warm=40, steps=20)
+    run("C0 at 30 spp per call (the reference's batch size, app/Main.hs:209-211)", "main", 800, 600, 30, 15, pkg.INLINE, warm=20, steps=10)
+    run("C3: 3840x2160, 256 spp, limit 8, S16, render Inline", "s16", 3840, 2160, 256, BOUNCE_LIMIT, pkg.INLINE)
+    run("C4: 3840x2160, 1024 spp, limit 8, S16, render Inline, the whole image on one GPU", "s16", 3840, 2160, 1024, BOUNCE_LIMIT, pkg.INLINE, warm=2)
+    run("C4, one part of 8 (10-row stripes): what one rank of the 8-GPU job renders", "s16", 3840, 2160, 1024, BOUNCE_LIMIT, pkg.INLINE, part_of=8)
+    run("C5, one part of 8: glass scene, 3840x2160, 512 spp, render Streams, per-pixel tree walk (the default with GLASS)", "glass", 3840, 2160, 512, BOUNCE_LIMIT, pkg.STREAMS, part_of=8)
+    run("C5, one part of 8, stream ('wavefront') form: start-hit regions, child rings (BASELINE configs[4]'s path)", "glass", 3840, 2160, 512, BOUNCE_LIMIT, pkg.STREAMS, part_of=8, stream_form=True)
+    run("C2 through render Streams, per-pixel chain", "s16", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, warm=6)
+    run("C2 through render Streams, stream form", "s16", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, stream_form=True, warm=6)
+    run("glass scene, 1920x1080, 64 spp, render Streams, tree walk", "glass", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, warm=6)
+    run("glass scene, 1920x1080, 64 spp, render Streams, stream form", "glass", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, stream_form=True, warm=6)
+    return out
 
 
 def pick_stripe(height, world):
@@ -156,6 +221,7 @@ def main():
                     help="auto: C2 on one GPU, strong scaling on C4 when --gpus > 1")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (DESIGN.md); 0 = default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the `also` block (the other BASELINE configs after the headline, ~4 s)")
     ap.add_argument("--no-n1-reference", action="store_true", help="strong scaling: skip the one-GPU timing of the same image on rank 0")
     ap.add_argument("--stripe-rows", type=int, default=0, help="0 = a stripe that deals every rank the same number of rows")
     ap.add_argument("--width", type=int, default=0, help="experiments only: the headline numbers are the default workloads")
@@ -331,14 +397,23 @@ def main():
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         is_c2 = named and scaling == "weak" and world == 1
         traffic = load_traffic() if is_c2 else None
+        shape = (width, height, spp, args.scene, args.algorithm)
+        if shape == (3840, 2160, 256, "s16", "inline"):
+            config_name = "C3"                                            # BASELINE.json configs[2]
+        elif shape == (3840, 2160, 512, "glass", "streams"):
+            config_name = "C5 (%s)" % ("stream form" if args.streams_form == "stream" else "per-pixel tree walk")   # configs[4]
+        else:
+            config_name = "experiment"
+        if n_parts != world:
+            config_name += ", one part of %d" % n_parts
         if scaling == "strong":
             workload = "%s: ONE %dx%d image at %d spp, row-striped over %d GPU(s) (strong scaling)" % (
-                base["name"] if named else "experiment", width, height, spp, world)
+                base["name"] if named else config_name, width, height, spp, world)
         else:
-            workload = ("C2" if world == 1 else "C2 per GPU (1920x1080 pixels each, weak scaling by %s)" % args.weak) if named else "experiment"
+            workload = ("C2" if world == 1 else "C2 per GPU (1920x1080 pixels each, weak scaling by %s)" % args.weak) if named else config_name
             workload += ": %dx%d image, %d spp per step" % (width, height, spp)
         kernel_name = "render_inline_kernel" if args.algorithm == "inline" else \
-            ("streams_level_kernel (stream form)" if args.streams_form == "stream" else
+            (("streams_split_kernel (stream form)" if args.scene == "glass" else "streams_pixels_kernel (stream form)") if args.streams_form == "stream" else
              ("render_streams_tree_kernel" if args.scene == "glass" else "render_streams_kernel"))
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -349,7 +424,7 @@ def main():
                     "physical_GBps": round(traffic / (kernel_ms * 1e-3) / 1e9, 2) if traffic and kernel_ms > 0 else None,
                     "physical_frac": round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and kernel_ms > 0 else None,
                     "real_bound": "valu",
-                    "valu": valu_accounting(kernel_ms) if is_c2 else None}
+                    "valu": valu_accounting(pkg, kernel_ms) if is_c2 else None}
         out = {
             "metric": METRIC,
             "value": round(value, 1), "unit": "Msamples/s",
@@ -375,6 +450,10 @@ def main():
                                             "note": "the whole image on rank 0's GPU alone, best of 3, outside the timed region"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, spheres, planes, cam, width, height)
+        if is_c2 and not args.no_also and not args.variant:
+            t_also = time.perf_counter()
+            out["also"] = also_measurements(pkg, torch)
+            out["also_seconds"] = round(time.perf_counter() - t_also, 2)
         print(json.dumps(out), flush=True)
 
     ctx.close()

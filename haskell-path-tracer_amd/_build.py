@@ -11,6 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libptmi.so")
+ABLATIONS_LIB = os.path.join(HERE, "libptmi_ablations.so")   # the same library with the ablation kernels of DESIGN.md 5.2 (tests, measurements)
 SOURCES = ["ptmi_api.cpp", "ptmi_stage.cpp", "ptmi_group.cpp", "ptmi_kernels.hip"]
 HEADERS = ["ptmi_core.h", "ptmi_kernels.h", "ptmi_stage.h", os.path.join("..", "..", "include", "ptmi.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
@@ -24,12 +25,37 @@ def hipcc_path():
     raise RuntimeError("hipcc not found; libptmi.so cannot be built")
 
 
+def source_hash():
+    """sha256 over the kernel sources, the headers and the build flags: what a profile of the binary is a profile OF
+    (profiles/*_valu_roofline.json carries it; bench.py says `stale` when the sources have moved on)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_ablations_lib(force=False):
+    """libptmi_ablations.so = libptmi.so + the ablation kernels (-DPTMI_ABLATIONS): what ptmi_set_variant's other values need."""
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    if not force and os.path.exists(ABLATIONS_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(ABLATIONS_LIB) for d in deps):
+        return ABLATIONS_LIB
+    import fcntl
+    with open(ABLATIONS_LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        tmp = "%s.tmp.%d" % (ABLATIONS_LIB, os.getpid())
+        build_lib(out=tmp, extra_flags=["-DPTMI_ABLATIONS"])
+        os.replace(tmp, ABLATIONS_LIB)
+    return ABLATIONS_LIB
 
 
 def build_lib(force=False, verbose=False, extra_flags=(), out=None):

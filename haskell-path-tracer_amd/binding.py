@@ -92,20 +92,25 @@ class PtmiError(RuntimeError):
 _lib = None
 
 
-def load_library(path=None):
-    """dlopen libptmi.so (building nothing: see _build.build_lib) and type every symbol."""
-    global _lib
-    if _lib is not None and path is None:
-        return _lib
-    path = path or _build.LIB
+def open_library(path):
+    """dlopen one libptmi build and type every symbol (a second build -- the ablation library, a diagnostic build -- can be
+    open beside the default one: Context(library=...))."""
     if not os.path.exists(path):
         raise PtmiError(PTMI_ESTATE, "libptmi.so not built (%s); run __graft_entry__.build()" % path)
     lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export it
         fn.restype, fn.argtypes = res, args
-    _lib = lib
     return lib
+
+
+def load_library(path=None):
+    """The default library of the process: libptmi.so (building nothing: see _build.build_lib), or `path` from then on."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    _lib = open_library(path or _build.LIB)
+    return _lib
 
 
 def _ptr(a):
@@ -122,8 +127,8 @@ def _host(a, dtype, n=None, name="array"):
 class Context:
     """One ptmi_ctx.  Methods map 1:1 onto include/ptmi.h."""
 
-    def __init__(self, device=0):
-        self._lib = load_library()
+    def __init__(self, device=0, library=None):
+        self._lib = library if library is not None else load_library()
         h = _vp()
         rc = self._lib.ptmi_create(C.byref(h), int(device))
         if rc != PTMI_OK:

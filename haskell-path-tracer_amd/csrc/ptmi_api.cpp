@@ -82,6 +82,8 @@ struct ptmi_ctx {
     void *d_snapshots = nullptr;     // stream form, split kernel: the seed every item starts from
     size_t snapshot_bytes = 0;
     int cus = 0;                     // compute units of the device (persistent grids)
+    void *tree_stack = nullptr;      // tree walk: the lanes' first waiting children (RenderArgs.tree_stack)
+    size_t tree_stack_bytes = 0;
     hipStream_t aux_stream = nullptr;   // stream form, ordered kernel: the second chain of launches runs here
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int opt_ordered_passes = 0;      // 0 = automatic (experiments: PTMI_ORDERED_PASSES in the environment)
@@ -541,6 +543,16 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
     } else if (stream_form) {                              // rays travel through streams in HBM (PTMI_OPT_STREAMS_FORM; variant 9)
         if (int rc = render_streams_wavefront(c, a, n_spp, *camera)) return rc;
     } else if (c->has_glass) {                             // rays may split: the per-pixel tree walk
+        // the first waiting children of every lane as 64-byte records in global memory (ptmi_kernels.hip); without the block
+        // (the device could not give it) every entry lives in scratch memory, as slow writes but the same results
+        const size_t want = (size_t)tree_workgroups(width, rows_local) * kTreeFastLevels * 64 * 64;
+        if (want > c->tree_stack_bytes) {
+            PTMI_HIP(c, hipStreamSynchronize(c->stream));
+            if (c->tree_stack) { (void)hipFree(c->tree_stack); c->tree_stack = nullptr; c->tree_stack_bytes = 0; }
+            if (hipMalloc(&c->tree_stack, want) == hipSuccess) c->tree_stack_bytes = want;
+            else { (void)hipGetLastError(); c->tree_stack = nullptr; }
+        }
+        a.tree_stack = want <= c->tree_stack_bytes ? static_cast<float4 *>(c->tree_stack) : nullptr;
         PTMI_HIP(c, launch_render_streams_tree(a, c->variant, c->stream));
     } else {
         PTMI_HIP(c, launch_render_streams(a, c->variant, c->stream));
@@ -649,6 +661,7 @@ void ptmi_destroy(ptmi_ctx *c)
     if (c->d_hit_missed) (void)hipFree(c->d_hit_missed);
     if (c->d_snapshots) (void)hipFree(c->d_snapshots);
     if (c->spill_block) (void)hipFree(c->spill_block);
+    if (c->tree_stack) (void)hipFree(c->tree_stack);
     if (c->d_qcount) (void)hipFree(c->d_qcount);
     if (c->d_quad_cost) (void)hipFree(c->d_quad_cost);
     if (c->d_quad_order) (void)hipFree(c->d_quad_order);
@@ -795,6 +808,7 @@ int ptmi_set_variant(ptmi_ctx *c, int variant)
     if (!c) return PTMI_EINVAL;
     std::lock_guard<std::mutex> lock(c->mu);
     if (variant < 0 || variant > 18) return fail(c, PTMI_EINVAL, "unknown variant");
+    if (!variant_available(variant)) return fail(c, PTMI_EINVAL, "this variant is an ablation kernel: build libptmi with -DPTMI_ABLATIONS");
     c->variant = variant;
     return PTMI_OK;
 }

@@ -52,9 +52,16 @@ struct RenderArgs {
     int stream_step_cap;                  // traceSteps per ray lineage before the safety cap cuts it (the reference has none)
     int seed_from_result;                 // PTMI_SEED_FROM_RESULT: a hit's ray seed replaces the pixel's (assumption A5)
     unsigned long long *stream_counters;  // device: [kScTruncated] rays cut by the cap, [kScDropped] children that found no room
+    // tree walk: the first kTreeFastLevels waiting children of every lane, [tile workgroup][level][lane] records of four float4
+    // (tree_stack_tiles workgroups); NULL = everything in scratch
+    float4 *tree_stack;
 };
 enum { kScTruncated = 0, kScDropped = 1, kScWords = 4 };
 constexpr int kTreeStackDepth = 16;        // per-pixel tree walk: pending children a lane can hold (render_streams_tree_kernel)
+#ifndef PTMI_TREE_FAST_LEVELS
+#define PTMI_TREE_FAST_LEVELS 4
+#endif
+constexpr int kTreeFastLevels = PTMI_TREE_FAST_LEVELS;   // ... of which the first few are 64-byte records in global memory (RenderArgs.tree_stack), the rest scratch
 
 // Ray stream of the stream form of Streams: `capacity` records (type RayState, Trace.hs:46) of 16 words = one 64-byte line:
 //   [origin xyz, direction x] [direction yz, throughput xy] [throughput z, local pixel index, seed a, seed b]
@@ -149,8 +156,10 @@ hipError_t launch_streams_advance_missed(const RenderArgs &a, HitList hits, int 
 unsigned int streams_first_block();   // output slots every wave of a level owns from the start
 
 hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t stream);
+bool variant_available(int variant);     // ablation variants exist only in builds with -DPTMI_ABLATIONS
 hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t stream);
 hipError_t launch_render_streams_tree(const RenderArgs &a, int variant, hipStream_t stream);   // scenes with GLASS: per-pixel tree walk
+unsigned int tree_workgroups(int width, int rows_local);   // workgroups per copy of its grid (RenderArgs.tree_stack holds kTreeFastLevels x 64 records of 64 B for each)
 unsigned int quad_positions(int width, int rows_local);                    // entries of quad_order / quad_cost (0 = tiles not used)
 hipError_t launch_quad_order(const unsigned int *cost, unsigned int *order, unsigned int *cls, unsigned int n, hipStream_t stream);
 bool uses_quad_order(const RenderArgs &a, int algorithm_inline, int variant);

@@ -348,6 +348,11 @@ __device__ __forceinline__ int global_row(int local_row, int stripe_rows, int n_
     return ((local_row / stripe_rows) * n_parts + part) * stripe_rows + local_row % stripe_rows;
 }
 
+// How many lanes below this one are set in `mask`: v_mbcnt_lo/hi, no per-lane 64-bit mask to keep in registers.
+__device__ __forceinline__ unsigned int rank_in(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+}
 __device__ __forceinline__ unsigned long long wave_sum(unsigned int v)
 {
     unsigned long long s = v;
@@ -824,6 +829,7 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? PTMI_INLINE_WA
     }
 }
 
+#ifdef PTMI_ABLATIONS     // the two ablation kernels of render Inline: only in builds with -DPTMI_ABLATIONS
 // ---------------------------------------------------------------------------------------
 // render Inline, pooled second shade round.  Same loop [shade A][shade B][trace C] and the same arithmetic as
 // kCached, but the B round -- lanes whose sample ended in A and whose next sample starts from the cached
@@ -1175,6 +1181,8 @@ __global__ void __launch_bounds__(kRenderBlock) render_inline_persistent_kernel(
 #endif
 }
 
+#endif  // PTMI_ABLATIONS
+
 // ---------------------------------------------------------------------------------------
 // render Streams (Trace.hs:141-191, 272-331).  The reference keeps one ray per pixel in a stream
 // that `expand` compacts after every step (numNewRays is 0 or 1, Trace.hs:329-331) and scatters the
@@ -1492,7 +1500,12 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
             // memory.  (Before the start record existed, every sample of a glass pixel pushed a child and the first entry
             // lived in LDS: 23 GB -> 1.4 GB of scratch writes per launch.  With the primary split cached, pushes are rare,
             // and an LDS entry beside the start record would cost a wave of occupancy: 10.2 ms instead of 9.1.)
-            uint32_t stack_w[kTreeStackDepth][14];
+            // The lane's waiting children, a stack.  Its first kTreeFastLevels entries are 64-byte records in a global-memory block
+            // laid out [tile][level][lane] -- a push is four 16-byte stores to ONE line, a pop four loads -- and only deeper
+            // entries live in scratch memory, where a push is fourteen lane-strided dwords, each a partial line: with the
+            // whole stack in scratch the kernel wrote 4 GB per 1080p / 64-spp launch (70 times the planes).
+            uint32_t stack_w[kTreeStackDepth - kTreeFastLevels][14];
+            float4 *fast = a.tree_stack ? a.tree_stack + ((size_t)wg * kTreeFastLevels * kRenderBlock + threadIdx.x) * 4 : nullptr;
             int sp = 0, entry_i = 0;
             int s = 0, idx = h0.idx;
             unsigned int steps = 0, deepest = 0;                 // deepest: traceSteps of the sample's longest lineage
@@ -1532,7 +1545,15 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                 if (sp > 0) {                                     // the most recent waiting child
                     --sp;
                     uint32_t e[14];
-                    for (int q = 0; q < 14; ++q) e[q] = stack_w[sp][q];
+                    if (fast && sp < kTreeFastLevels) {
+                        const float4 *r = fast + (size_t)sp * kRenderBlock * 4;
+                        const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+                        e[0] = f2u(r0.x); e[1] = f2u(r0.y); e[2] = f2u(r0.z); e[3] = f2u(r0.w); e[4] = f2u(r1.x); e[5] = f2u(r1.y); e[6] = f2u(r1.z);
+                        e[7] = f2u(r1.w); e[8] = f2u(r2.x); e[9] = f2u(r2.y); e[10] = f2u(r2.z); e[11] = f2u(r2.w); e[12] = f2u(r3.x); e[13] = f2u(r3.y);
+                    } else {
+                        const int q0 = fast ? sp - kTreeFastLevels : sp;
+                        for (int q = 0; q < 14; ++q) e[q] = stack_w[q0 < kTreeStackDepth - kTreeFastLevels ? q0 : 0][q];
+                    }
                     pos = mk(u2f(e[0]), u2f(e[1]), u2f(e[2]));
                     d = mk(u2f(e[3]), u2f(e[4]), u2f(e[5]));
                     throughput = mk(u2f(e[6]), u2f(e[7]), u2f(e[8]));
@@ -1585,9 +1606,18 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                         else {
                             // while the cached reflection's subtree is walked, the cached refraction "waits": one slot less
                             if (sp < kTreeStackDepth - ((prefix && entry_i == 1 && first_is_reflection) ? 1 : 0)) {
-                                const uint32_t e[14] = {f2u(ko[1].x), f2u(ko[1].y), f2u(ko[1].z), f2u(kd[1].x), f2u(kd[1].y), f2u(kd[1].z),
-                                                        f2u(kt[1].x), f2u(kt[1].y), f2u(kt[1].z), ks[1].a, ks[1].b, ks[1].c, ks[1].counter, steps};
-                                for (int q = 0; q < 14; ++q) stack_w[sp][q] = e[q];
+                                if (fast && sp < kTreeFastLevels) {
+                                    float4 *r = fast + (size_t)sp * kRenderBlock * 4;
+                                    r[0] = float4{ko[1].x, ko[1].y, ko[1].z, kd[1].x};
+                                    r[1] = float4{kd[1].y, kd[1].z, kt[1].x, kt[1].y};
+                                    r[2] = float4{kt[1].z, u2f(ks[1].a), u2f(ks[1].b), u2f(ks[1].c)};
+                                    r[3] = float4{u2f(ks[1].counter), u2f(steps), 0.0f, 0.0f};
+                                } else {
+                                    const uint32_t e[14] = {f2u(ko[1].x), f2u(ko[1].y), f2u(ko[1].z), f2u(kd[1].x), f2u(kd[1].y), f2u(kd[1].z),
+                                                            f2u(kt[1].x), f2u(kt[1].y), f2u(kt[1].z), ks[1].a, ks[1].b, ks[1].c, ks[1].counter, steps};
+                                    const int q0 = fast ? sp - kTreeFastLevels : sp;
+                                    for (int q = 0; q < 14; ++q) stack_w[q0 < kTreeStackDepth - kTreeFastLevels ? q0 : 0][q] = e[q];
+                                }
                                 ++sp;
                             } else {
                                 ++dropped;
@@ -1700,11 +1730,6 @@ constexpr unsigned int kFirstBlock = 64, kNextBlock = 256;   // output slots a w
 #endif
 constexpr unsigned int kRefillBatch = PTMI_REFILL_BATCH;     // overflow levels: idle lanes a wave waits for before it runs the refill block
 
-// How many lanes below this one are set in `mask`: v_mbcnt_lo/hi, no per-lane 64-bit mask to keep in registers.
-__device__ __forceinline__ unsigned int rank_in(unsigned long long mask)
-{
-    return __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
-}
 // 16 bytes past the L1 (global_load_dwordx4 ... nt): for records this wave wrote itself a few trips ago
 __device__ __forceinline__ float4 load_past_l1(const float4 *p)
 {
@@ -2775,49 +2800,30 @@ static hipError_t choose_sample_chunks(RenderArgs &b, unsigned int per_copy, int
     return hipMemsetAsync(b.chunk_done, 0, (size_t)per_copy * sizeof(unsigned int), stream);
 }
 
+// Which render Inline kernel a variant is (ptmi_set_variant):
+//   0 auto | 4 cached, a wave = 64 consecutive pixels of a row (LDS scene) | 5 the same with the scene through scalar loads
+//   13 = 4 with 8x8 pixel tiles per wave | 17 = 5 with 8x8 tiles -- these are what auto chooses from.
+// Only in builds with -DPTMI_ABLATIONS (ptmi_set_variant refuses them otherwise):
+//   1 / 6 persistent hand-out (LDS / scalar-load scene) | 2 lock step | 3 regenerate | 7 / 8 capped occupancy
+//   10-12 pooled second shade round | 14-16 other tile shapes | 18 round 1's loop
 hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t stream)
 {
     const long long n_local = (long long)a.rows_local * a.width;
     if (n_local <= 0) return hipSuccess;
     const dim3 grid(blocks_for(n_local, kRenderBlock)), block(kRenderBlock);
     const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
-    // variants: 0 auto | 1 persistent (LDS scene) | 2 lock step | 3 regenerate | 4 cached, static row mapping (LDS scene)
-    //           5 cached, static, scene through scalar loads | 6 persistent, scene through scalar loads
-    //           10-12 pooled second shade round | 13 = 4 with 8x8 pixel tiles per wave | 14-16 other tile shapes
-    //           17 = 5 with 8x8 tiles
-    if (a.bounce_limit <= 0 || a.n_spp <= 0) variant = 2;   // degenerate counts: the plain loop handles them
     const bool big_scene = lds > kMaxSceneLds;               // every route reads such a scene through scalar loads, not LDS
-    if (variant == 0) {
-        // static mapping wins at every size measured (DESIGN.md 5.3); a scene so big that staging it per wave would cost more occupancy than scalar loads cost speed is
+    const bool degenerate = a.bounce_limit <= 0 || a.n_spp <= 0;   // the cached kernel handles both (iterate 0; no sample at all)
+    if (variant == 0 || degenerate) {
+        // static mapping wins at every size measured (DESIGN.md 5.2); a scene so big that staging it per wave would cost more occupancy than scalar loads cost speed is
         // read through scalar loads; 8x8 tiles once the image is big enough for whole tiles to dominate
         const bool tiles = tiles_pay(a);
-        variant = lds <= kMaxSceneLds ? (tiles ? 13 : 4) : (tiles ? 17 : 5);
+        variant = !big_scene ? (tiles ? 13 : 4) : (tiles ? 17 : 5);
     }
-    if (big_scene) {                                         // the LDS forms of the ablation variants would not fit or would cap occupancy
+    if (big_scene) {                                         // the LDS forms would not fit or would cap occupancy
         if (variant == 1) variant = 6;
         else if (variant == 4 || variant == 7 || variant == 8) variant = 5;
         else if (variant >= 13 && variant <= 16) variant = 17;
-    }
-    if (variant == 1 || variant == 6) {
-        // persistent grid; more workgroups than fit would only start late and find the queue empty: cap at 8 per CU
-        static int max_blocks = 0;
-        if (!max_blocks) {
-            int dev = 0, cus = 0;
-            hipError_t e = hipGetDevice(&dev);
-            if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            if (e != hipSuccess) return e;
-            max_blocks = (cus > 0 ? cus : 256) * 8 * (256 / kRenderBlock);
-        }
-        const unsigned int blocks = grid.x < (unsigned int)max_blocks ? grid.x : (unsigned int)max_blocks;
-        hipError_t e = hipMemsetAsync(a.work_counter, 0, sizeof(unsigned int), stream);
-        if (e != hipSuccess) return e;
-        if (variant == 1) hipLaunchKernelGGL((render_inline_persistent_kernel<true>), dim3(blocks), block, lds, stream, a);
-        else              hipLaunchKernelGGL((render_inline_persistent_kernel<false>), dim3(blocks), block, 0, stream, a);
-        return hipGetLastError();
-    }
-    if (variant == 18) {                                      // round 1's loop (no frozen-shade shortcut), 8x8 tiles, LDS scene
-        hipLaunchKernelGGL((render_inline_kernel<true, kCachedR1, 8>), dim3(tile_grid(a, 8)), block, lds, stream, a);
-        return hipGetLastError();
     }
     if (variant == 17 || variant == 13) {
         RenderArgs b = a;
@@ -2826,6 +2832,27 @@ hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t st
         const dim3 cgrid(per_copy * (unsigned int)b.spp_chunks);
         if (variant == 17) hipLaunchKernelGGL((render_inline_kernel<false, kCached, 8>), cgrid, block, 0, stream, b);
         else               hipLaunchKernelGGL((render_inline_kernel<true, kCached, 8>), cgrid, block, lds, stream, b);
+        return hipGetLastError();
+    }
+    if (variant == 5) { hipLaunchKernelGGL((render_inline_kernel<false, kCached>), grid, block, 0, stream, a); return hipGetLastError(); }
+    if (variant == 4) { hipLaunchKernelGGL((render_inline_kernel<true, kCached>), grid, block, lds, stream, a); return hipGetLastError(); }
+#ifdef PTMI_ABLATIONS
+    if (variant == 1 || variant == 6) {
+        // persistent grid; more workgroups than fit would only start late and find the queue empty: cap at 8 per CU
+        int dev = 0, cus = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        const int max_blocks = (cus > 0 ? cus : 256) * 8 * (256 / kRenderBlock);
+        const unsigned int blocks = grid.x < (unsigned int)max_blocks ? grid.x : (unsigned int)max_blocks;
+        e = hipMemsetAsync(a.work_counter, 0, sizeof(unsigned int), stream);
+        if (e != hipSuccess) return e;
+        if (variant == 1) hipLaunchKernelGGL((render_inline_persistent_kernel<true>), dim3(blocks), block, lds, stream, a);
+        else              hipLaunchKernelGGL((render_inline_persistent_kernel<false>), dim3(blocks), block, 0, stream, a);
+        return hipGetLastError();
+    }
+    if (variant == 18) {                                      // round 1's loop (no frozen-shade shortcut), 8x8 tiles, LDS scene
+        hipLaunchKernelGGL((render_inline_kernel<true, kCachedR1, 8>), dim3(tile_grid(a, 8)), block, lds, stream, a);
         return hipGetLastError();
     }
     if (variant >= 14 && variant <= 16) {                     // other pixel tiles per wave: 16x4 / 4x16 / 32x2 (8x8 is handled above)
@@ -2853,16 +2880,26 @@ hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t st
     switch (variant) {
     case 2:  if (big_scene) hipLaunchKernelGGL((render_inline_kernel<false, kLockstep>), grid, block, 0, stream, a);
              else           hipLaunchKernelGGL((render_inline_kernel<true, kLockstep>), grid, block, lds, stream, a);
-             break;
+             return hipGetLastError();
     case 3:  if (big_scene) hipLaunchKernelGGL((render_inline_kernel<false, kRegenerate>), grid, block, 0, stream, a);
              else           hipLaunchKernelGGL((render_inline_kernel<true, kRegenerate>), grid, block, lds, stream, a);
-             break;
-    case 5:  hipLaunchKernelGGL((render_inline_kernel<false, kCached>), grid, block, 0, stream, a); break;
-    case 7:  hipLaunchKernelGGL((render_inline_kernel<true, kCached>), grid, block, 33 * 1024, stream, a); break;   // 4 waves/SIMD
-    case 8:  hipLaunchKernelGGL((render_inline_kernel<true, kCached>), grid, block, 41 * 1024, stream, a); break;   // 3 waves/SIMD
-    default: hipLaunchKernelGGL((render_inline_kernel<true, kCached>), grid, block, lds, stream, a); break;
+             return hipGetLastError();
+    case 7:  hipLaunchKernelGGL((render_inline_kernel<true, kCached>), grid, block, 33 * 1024, stream, a); return hipGetLastError();   // 4 waves/SIMD
+    case 8:  hipLaunchKernelGGL((render_inline_kernel<true, kCached>), grid, block, 41 * 1024, stream, a); return hipGetLastError();   // 3 waves/SIMD
+    default: break;
     }
-    return hipGetLastError();
+#endif
+    return hipErrorInvalidValue;                             // ptmi_set_variant admits only what the build holds
+}
+
+bool variant_available(int variant)
+{
+    if (variant == 0 || variant == 4 || variant == 5 || variant == 9 || variant == 13 || variant == 17) return true;
+#ifdef PTMI_ABLATIONS
+    return variant >= 0 && variant <= 18;
+#else
+    return false;
+#endif
 }
 
 hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t stream)
@@ -2887,6 +2924,13 @@ hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t s
         else              hipLaunchKernelGGL((render_streams_kernel<true>), grid, block, lds, stream, a);
     }
     return hipGetLastError();
+}
+
+// workgroups (per copy of the grid) of the tree walk = records' worth of RenderArgs.tree_stack: x kTreeFastLevels x 64 lanes x 64 B
+unsigned int tree_workgroups(int width, int rows_local)
+{
+    if (tiles_pay_dims(width, rows_local)) return quad_positions(width, rows_local) * 4u;
+    return (unsigned int)(((long long)width * rows_local + kRenderBlock - 1) / kRenderBlock);
 }
 
 hipError_t launch_render_streams_tree(const RenderArgs &a, int variant, hipStream_t stream)

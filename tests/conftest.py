@@ -30,6 +30,21 @@ def ora():
 
 
 @pytest.fixture(scope="session")
+def ablations(pkg):
+    """libptmi_ablations.so: libptmi built with -DPTMI_ABLATIONS (the slower loop shapes of DESIGN.md 5.2, kept as evidence;
+    the product library does not contain them)."""
+    return pkg.binding.open_library(pkg._build.build_ablations_lib())
+
+
+@pytest.fixture(scope="session")
+def actx(pkg, ablations):
+    """One device context of the ablation library (tests that walk through ptmi_set_variant's ablation values)."""
+    c = pkg.Context(0, library=ablations)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="session")
 def ctx(pkg):
     """One device context for the GPU tests; fails loudly when the HIP library or GPU is missing."""
     c = pkg.Context(0)

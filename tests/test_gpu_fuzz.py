@@ -44,31 +44,35 @@ def random_case(pkg, r):
     return spheres, planes, cam, width, height, int(r.choice([1, 2, 4, 8, 15])), int(r.integers(1, 4))
 
 
-def test_random_scenes_inline_and_streams(ctx, pkg, ora):
+def test_random_scenes_inline_and_streams(ctx, actx, pkg, ora):
     r = np.random.default_rng(SEED)
     checked = 0
     for case in range(N_CASES):
         spheres, planes, cam, w, h, limit, spp = random_case(pkg, r)
         start = initial_planes(ora, w, h, seed0=int(r.integers(0, 2 ** 63)))
         variant = INLINE_VARIANTS[case % len(INLINE_VARIANTS)]     # half the cases on the default kernel, the rest spread over the others
-        ctx.set_scene(spheres, planes)
-        ctx.resize(w, h)
-        ctx.upload_state(*start)
-        ctx.reset_stats()
-        ctx.set_variant(variant)
+        ic = ctx if variant in (0, 4, 5, 13, 17) else actx         # the other loop shapes live in the ablation library
+        ic.set_scene(spheres, planes)
+        ic.resize(w, h)
+        ic.upload_state(*start)
+        ic.reset_stats()
+        ic.set_variant(variant)
         if case % 4 == 0 and spp >= 2:                             # two launches: the second runs in the cost order the first recorded
-            ctx.render(cam, limit, 1, pkg.INLINE)
-            ctx.render(cam, limit, spp - 1, pkg.INLINE)
+            ic.render(cam, limit, 1, pkg.INLINE)
+            ic.render(cam, limit, spp - 1, pkg.INLINE)
         else:
-            ctx.render(cam, limit, spp, pkg.INLINE)
-        ctx.set_variant(0)
-        got = ctx.download_state()
-        live_gpu = ctx.stats()["live_bounces"]
+            ic.render(cam, limit, spp, pkg.INLINE)
+        ic.set_variant(0)
+        got = ic.download_state()
+        live_gpu = ic.stats()["live_bounces"]
         with np.errstate(all="ignore"):
             want, live = ora.render_inline(spheres, planes, cam, w, h, limit, spp, start)
         assert_planes_equal(got, want, "fuzz case %d inline, variant %d (%dx%d, %d+%d prims, limit %d, spp %d)" % (case, variant, w, h, len(spheres), len(planes), limit, spp))
         assert live_gpu == live
         if case % 3 == 0:
+            if ic is not ctx:
+                ctx.set_scene(spheres, planes)
+                ctx.resize(w, h)
             ctx.upload_state(*start)
             stream_form = case % 2 == 1                            # the stream ("wavefront") form or the per-pixel form
             ctx.set_variant(9 if stream_form else 0)

@@ -44,7 +44,7 @@ def test_render_inline_matches_oracle(ctx, pkg, ora, w, h, limit, spp, scene_nam
 
 
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, 15, 16, 17, 18])
-def test_every_kernel_variant_matches_oracle(pkg, ora, variant):
+def test_every_kernel_variant_matches_oracle(pkg, ora, ablations, variant):
     """All loop shapes (persistent hand-out, lock step, regenerate, cached/static, LDS or scalar-load scene,
     second shade round pooled over 2 / 4 / 8 waves, 8x8 / 16x4 / 4x16 / 32x2 pixel tiles per wave,
     round 1's [shade][shade][trace] loop without the frozen-shade shortcut)
@@ -54,11 +54,20 @@ def test_every_kernel_variant_matches_oracle(pkg, ora, variant):
     w, h, limit, spp = 150, 90, 8, 5
     start = initial_planes(ora, w, h)
     want, live = ora.render_inline(scene[0], scene[1], cam, w, h, limit, spp, start)
-    with pkg.Context(0) as c:
+    with pkg.Context(0, library=ablations) as c:            # the ablation kernels live in libptmi_ablations.so only
         c.set_variant(variant)
         got, stats = run_gpu(c, pkg, scene, cam, w, h, limit, spp, start)
     assert_planes_equal(got, want, "variant %d" % variant)
     assert stats["live_bounces"] == live
+    with pkg.Context(0) as c:                               # the product library: what `auto` chooses from, nothing else
+        if variant in (4, 5, 13, 17):
+            c.set_variant(variant)
+            got, stats = run_gpu(c, pkg, scene, cam, w, h, limit, spp, start)
+            assert_planes_equal(got, want, "variant %d, product library" % variant)
+        else:
+            with pytest.raises(pkg.PtmiError) as e:
+                c.set_variant(variant)
+            assert e.value.code == -1
 
 
 def test_non_finite_inputs_take_the_literal_fold(ctx, pkg, ora):

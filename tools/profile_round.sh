@@ -16,7 +16,7 @@ python3 bench.py --scaling strong --steps 3 --warmup 1 --no-cpu-baseline > "$OUT
 python3 bench.py --scene glass --algorithm streams --width 3840 --height 2160 --spp 512 --part-of 8 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c5_part.json" 2>> "$OUT/bench.log"; echo "bench C5 part rc=$?"
 python3 bench.py --scene glass --algorithm streams --streams-form stream --width 3840 --height 2160 --spp 512 --part-of 8 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c5_part_stream.json" 2>> "$OUT/bench.log"; echo "bench C5 part, stream form rc=$?"
 # the kernel trace of the driver's own command (default steps): its mean for render_inline_kernel must agree with roofline.kernel_ms
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_default" --output-format csv -- python3 bench.py --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats_default.log"; echo "stats rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_default" --output-format csv -- python3 bench.py --no-cpu-baseline --no-also > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats_default.log"; echo "stats rc=$?"
 
 # 2. kernel trace + PMC passes, per workload: the headline kernel and the Streams kernels
 #    (tools/pmc_kernels.sh writes gpurun_out/pmc_<name>/; the same bench command under every pass)
