@@ -221,6 +221,8 @@ def main():
                     help="auto: C2 on one GPU, strong scaling on C4 when --gpus > 1")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (DESIGN.md); 0 = default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-image", action="store_true",
+                    help="N > 1: after the timed steps rank 0 renders the same samples in ONE context and compares the gathered image bit for bit")
     ap.add_argument("--no-also", action="store_true", help="skip the `also` block (the other BASELINE configs after the headline, ~4 s)")
     ap.add_argument("--no-n1-reference", action="store_true", help="strong scaling: skip the one-GPU timing of the same image on rank 0")
     ap.add_argument("--stripe-rows", type=int, default=0, help="0 = a stripe that deals every rank the same number of rows")
@@ -385,6 +387,24 @@ def main():
                 torch.cuda.synchronize()
                 times.append((time.perf_counter() - t1) * 1e3)
             n1_ms = min(times)
+    image_equal = None
+    if args.check_image and world > 1:
+        # the image rank 0 holds after the last gather against the same samples rendered by ONE context: stripes, seeds from the
+        # global pixel index, gather and reassembly change no bit
+        final = gather.overlapped(color)
+        gather.wait()
+        torch.cuda.synchronize()
+        if rank == 0:
+            with pkg.Context(local_rank) as whole:
+                whole.set_scene(spheres, planes)
+                whole.resize(width, height)
+                whole.init_output(SEED0)
+                for _ in range(args.warmup + args.steps):
+                    whole.render(cam, BOUNCE_LIMIT, spp, algorithm)
+                want = whole.download_color()
+            got = final.cpu().numpy()
+            import numpy as np
+            image_equal = all(np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)) for k in range(3))
     if world > 1:
         dist.barrier()
 
@@ -444,6 +464,8 @@ def main():
             "live_Mbounces_per_s": round(live_total / elapsed / 1e6, 1),
             "roofline": roofline,
         }
+        if image_equal is not None:
+            out["gathered_image_equals_one_context"] = bool(image_equal)
         if n1_ms is not None:
             out["one_gpu_same_workload"] = {"ms_per_step": round(n1_ms, 3),
                                             "value": round(nominal_per_step / (n1_ms * 1e-3) / 1e6, 1),

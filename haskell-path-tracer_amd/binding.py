@@ -55,6 +55,7 @@ SYMBOLS = {
     "ptmi_download_color": (C.c_int, [_vp] + [_vp] * 3),
     "ptmi_render": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
     "ptmi_synchronize": (C.c_int, [_vp]),
+    "ptmi_render_blocks": (C.c_int, [_vp, C.c_int]),
     "ptmi_render1": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp] + [_vp] * 14),
     "ptmi_present": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "ptmi_snapshot_color": (C.c_int, [_vp, _vp, _vp]),
@@ -69,6 +70,8 @@ SYMBOLS = {
     "ptmi_group_init_output": (C.c_int, [_vp, C.c_uint64]),
     "ptmi_group_reseed": (C.c_int, [_vp, C.c_uint64]),
     "ptmi_group_render": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
+    "ptmi_group_set_option": (C.c_int, [_vp, C.c_int, C.c_int64]),
+    "ptmi_group_set_variant": (C.c_int, [_vp, C.c_int]),
     "ptmi_group_synchronize": (C.c_int, [_vp]),
     "ptmi_group_download_color": (C.c_int, [_vp, _vp, _vp, _vp]),
     "ptmi_group_gather_color": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
@@ -269,6 +272,12 @@ class Context:
     def synchronize(self):
         self._check(self._lib.ptmi_synchronize(self._h))
 
+    def render_blocks(self, algorithm=INLINE):
+        rc = self._lib.ptmi_render_blocks(self._h, int(algorithm))
+        if rc < 0:
+            self._check(rc)
+        return rc == 1
+
     def render1(self, camera, bounce_limit, width, height, planes_in, algorithm=INLINE, screen=None):
         """compileFor's closure (app/Main.hs:188-191): 7 host planes in -> 7 new host planes out."""
         cam = np.ascontiguousarray(camera, dtype=CAMERA_DTYPE)
@@ -331,8 +340,8 @@ class Context:
 class Group:
     """One ptmi_group: the GPUs of a node behind one host process (include/ptmi.h, "groups")."""
 
-    def __init__(self, devices, stripe_rows=0):
-        self._lib = load_library()
+    def __init__(self, devices, stripe_rows=0, library=None):
+        self._lib = library if library is not None else load_library()
         devs = np.ascontiguousarray(devices, dtype=np.int32)
         h = _vp()
         rc = self._lib.ptmi_group_create(C.byref(h), devs.ctypes.data_as(_i32p), devs.size, int(stripe_rows))
@@ -392,6 +401,12 @@ class Group:
     def render(self, camera, bounce_limit, n_spp, algorithm=INLINE):
         cam = np.ascontiguousarray(camera, dtype=CAMERA_DTYPE)
         self._check(self._lib.ptmi_group_render(self._h, _ptr(cam), algorithm, bounce_limit, n_spp))
+
+    def set_option(self, option, value):
+        self._check(self._lib.ptmi_group_set_option(self._h, int(option), C.c_int64(int(value))))
+
+    def set_variant(self, variant):
+        self._check(self._lib.ptmi_group_set_variant(self._h, int(variant)))
 
     def synchronize(self):
         self._check(self._lib.ptmi_group_synchronize(self._h))

@@ -485,6 +485,7 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
     a.width = width; a.height = height; a.rows_local = rows_local;
     a.stripe_rows = stripe_rows; a.n_parts = n_parts; a.part = part;
     a.bounce_limit = bounce_limit; a.n_spp = n_spp;
+    a.cus = c->cus;
     a.live_counter = c->d_live; a.work_counter = c->d_work; a.stream_iterations = c->d_iters;
     a.stream_step_cap = c->opt_step_cap; a.seed_from_result = effective_seed_rule(c) == PTMI_SEED_FROM_RESULT;
     a.stream_counters = c->d_stream_counters;
@@ -531,7 +532,7 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
         const unsigned int need = ((unsigned int)(((width + 7) / 8) * ((rows_local + 7) / 8)) + 31u) & ~31u;
         if (need > c->chunk_capacity) {
             if (c->d_chunk_done) { PTMI_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_chunk_done); c->d_chunk_done = nullptr; c->chunk_capacity = 0; }
-            PTMI_HIP(c, hipMalloc(&c->d_chunk_done, (size_t)need * sizeof(unsigned int)));
+            PTMI_HIP(c, hipMalloc(&c->d_chunk_done, ((size_t)need + 32) * sizeof(unsigned int)));     // + the ticket counter's line
             c->chunk_capacity = need;
         }
         a.chunk_done = c->d_chunk_done; a.chunk_capacity = c->chunk_capacity;
@@ -944,6 +945,18 @@ int ptmi_render(ptmi_ctx *c, const ptmi_camera *camera, int algorithm, int bounc
     PTMI_HIP(c, hipSetDevice(c->device));
     return launch_render(c, active(c), camera, algorithm, bounce_limit, n_spp, c->width, c->height,
                          c->rows_local, effective_stripe(c), c->n_parts, c->part, nullptr, nullptr);
+}
+
+/* 1 when ptmi_render with this algorithm returns only after device work it waits for (the stream form with a ray-splitting
+ * scene or unordered items reads its overflow counters back), 0 when it only enqueues.  ptmi_group_render gives such members a
+ * host thread each. */
+int ptmi_render_blocks(ptmi_ctx *c, int algorithm)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    const bool stream_form = algorithm == PTMI_STREAMS && (c->opt_form == PTMI_FORM_STREAM || c->variant == 9);
+    const bool ordered = !c->has_glass && (c->opt_batch == 0 || effective_seed_rule(c) == PTMI_SEED_FROM_RESULT);
+    return stream_form && !ordered ? 1 : 0;
 }
 
 int ptmi_synchronize(ptmi_ctx *c)

@@ -222,9 +222,10 @@ int ptmi_group_render(ptmi_group *g, const ptmi_camera *camera, int algorithm, i
     const size_t n = g->members.size();
     // The per-pixel kernels are launched asynchronously: every device is busy before the first call returns.  The stream
     // form of Streams reads stream lengths back while it runs (the host plays `awhile`), so its members get a thread each.
-    int64_t form = PTMI_FORM_AUTO;
-    if (algorithm == PTMI_STREAMS && n > 1) (void)ptmi_get_option(g->members[0], PTMI_OPT_STREAMS_FORM, &form);
-    if (form == PTMI_FORM_STREAM) {
+    bool blocking = false;                                   // (any member: options and variants can be set per member too)
+    if (algorithm == PTMI_STREAMS && n > 1)
+        for (size_t i = 0; i < n; ++i) blocking |= ptmi_render_blocks(g->members[i], algorithm) == 1;
+    if (blocking) {
         std::vector<int> rcs(n, PTMI_OK);
         std::vector<std::thread> threads;
         for (size_t i = 0; i < n; ++i)
@@ -235,6 +236,24 @@ int ptmi_group_render(ptmi_group *g, const ptmi_camera *camera, int algorithm, i
     }
     for (size_t i = 0; i < n; ++i)
         if (int rc = ptmi_render(g->members[i], camera, algorithm, bounce_limit, n_spp)) return member_fail(g, (int)i, rc);
+    return PTMI_OK;
+}
+
+int ptmi_group_set_option(ptmi_group *g, int option, int64_t value)
+{
+    if (!g) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(g->mu);
+    for (size_t i = 0; i < g->members.size(); ++i)
+        if (int rc = ptmi_set_option(g->members[i], option, value)) return member_fail(g, (int)i, rc);
+    return PTMI_OK;
+}
+
+int ptmi_group_set_variant(ptmi_group *g, int variant)
+{
+    if (!g) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(g->mu);
+    for (size_t i = 0; i < g->members.size(); ++i)
+        if (int rc = ptmi_set_variant(g->members[i], variant)) return member_fail(g, (int)i, rc);
     return PTMI_OK;
 }
 
@@ -297,6 +316,11 @@ int ptmi_group_gather_color(ptmi_group *g, int root, float *r_dev, float *g_dev,
     if (g->width <= 0) return gfail(g, PTMI_ESTATE, "ptmi_group_resize has not been called");
     if (!r_dev || !g_dev || !b_dev) return gfail(g, PTMI_EINVAL, "a plane pointer is NULL");
     const size_t w = (size_t)g->width;
+    struct DeviceGuard {                                     // the caller's current HIP device is the caller's: put it back
+        int dev = -1;
+        DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+        ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+    } restore_device;
     const bool force_rccl = [] { const char *e = getenv("PTMI_GROUP_FORCE_RCCL"); return e && e[0] == '1'; }();
     const bool use_rccl = n > 1 || force_rccl;
     if (use_rccl && g->comms.empty()) {
@@ -337,13 +361,20 @@ int ptmi_group_gather_color(ptmi_group *g, int root, float *r_dev, float *g_dev,
     float *recv = g->recv_block;
     if (use_rccl) {
         GROUP_NCCL(g, g_rccl.GroupStart());
-        for (int i = 0; i < n; ++i) {
+        ncclResult_t inside = ncclSuccess;                   // an error between GroupStart and GroupEnd must not leave the group open
+        const char *what = "";
+        for (int i = 0; i < n && inside == ncclSuccess; ++i) {
             if (i == root && !force_rccl) continue;
             if (floats[(size_t)i] == 0) continue;
-            GROUP_NCCL(g, g_rccl.Send(g->send_snap[(size_t)i], floats[(size_t)i], ncclFloat32, root, g->comms[(size_t)i], g->comm_streams[(size_t)i]));
-            GROUP_NCCL(g, g_rccl.Recv(recv + offset[(size_t)i], floats[(size_t)i], ncclFloat32, i, g->comms[(size_t)root], g->comm_streams[(size_t)root]));
+            inside = g_rccl.Send(g->send_snap[(size_t)i], floats[(size_t)i], ncclFloat32, root, g->comms[(size_t)i], g->comm_streams[(size_t)i]);
+            what = "ncclSend";
+            if (inside != ncclSuccess) break;
+            inside = g_rccl.Recv(recv + offset[(size_t)i], floats[(size_t)i], ncclFloat32, i, g->comms[(size_t)root], g->comm_streams[(size_t)root]);
+            what = "ncclRecv";
         }
-        GROUP_NCCL(g, g_rccl.GroupEnd());
+        const ncclResult_t ended = g_rccl.GroupEnd();
+        if (inside != ncclSuccess) return gfail(g, PTMI_EHIP, std::string(what) + ": " + g_rccl.GetErrorString(inside));
+        if (ended != ncclSuccess) return gfail(g, PTMI_EHIP, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ended));
     }
     GROUP_HIP(g, hipSetDevice(g->devices[(size_t)root]));
     if (!(use_rccl && force_rccl) && floats[(size_t)root])

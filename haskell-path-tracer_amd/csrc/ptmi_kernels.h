@@ -44,7 +44,9 @@ struct RenderArgs {
     const unsigned int *quad_order;
     unsigned int *quad_cost;
     // Sample chunks of the tiled render Inline kernel (see render_inline_kernel): spp_chunks = 0 lets the launcher choose,
-    // 1 switches them off, k >= 2 forces k copies; chunk_done: one word per tile workgroup (capacity words), device memory.
+    // 1 switches them off, k >= 2 forces k copies; chunk_done: one word per tile workgroup (capacity words) and, behind them,
+    // the ticket counter of the launch (chunk_done[chunk_capacity]), device memory.
+    int cus;                              // compute units of the context's device
     int spp_chunks;
     unsigned int *chunk_done;
     unsigned int chunk_capacity;

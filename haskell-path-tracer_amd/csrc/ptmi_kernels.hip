@@ -416,6 +416,13 @@ __device__ __forceinline__ void enter_sample_chunk(const RenderArgs &a, unsigned
 {
     wg = blockIdx.x; chunk = 0; n_spp_chunk = a.n_spp;
     if (TILE_W > 0 && a.spp_chunks > 1) {
+        // The workgroup's place in the chain of copies is a TICKET, not blockIdx: HIP promises nothing about the order in which
+        // workgroups are dispatched, and a consumer that waited for a producer not yet dispatched -- with every slot held by
+        // waiting consumers -- would hang the launch.  The producer of a ticket's tile holds the ticket per_copy lower: it was
+        // taken by a workgroup that is running or has finished.
+        unsigned int t = 0;
+        if ((threadIdx.x & 63) == 0) t = atomicAdd(a.chunk_done + a.chunk_capacity, 1u);
+        wg = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
         const unsigned int per_copy = gridDim.x / (unsigned int)a.spp_chunks;
         chunk = (int)(wg / per_copy);
         wg -= (unsigned int)chunk * per_copy;
@@ -423,8 +430,10 @@ __device__ __forceinline__ void enter_sample_chunk(const RenderArgs &a, unsigned
         n_spp_chunk = a.n_spp - chunk * per;
         n_spp_chunk = n_spp_chunk < 0 ? 0 : (n_spp_chunk > per ? per : n_spp_chunk);
         if (chunk > 0) {
-            while (__hip_atomic_load(a.chunk_done + wg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)chunk)
+            // one relaxed poll, then ONE acquire (polling with acquire loads invalidates the L1 every time round)
+            while (__hip_atomic_load(a.chunk_done + wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)chunk)
                 __builtin_amdgcn_s_sleep(16);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
     }
 }
@@ -434,7 +443,8 @@ __device__ __forceinline__ void leave_sample_chunk(const RenderArgs &a, unsigned
 {
     if (TILE_W > 0 && a.spp_chunks > 1 && chunk + 1 < a.spp_chunks) {     // publish: the next copy of this tile may start
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if ((threadIdx.x & 63) == 0) __hip_atomic_store(a.chunk_done + wg, (unsigned int)(chunk + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the write-back has completed before the flag leaves (the compiler may drop its own wait)
+        if ((threadIdx.x & 63) == 0) __hip_atomic_store(a.chunk_done + wg, (unsigned int)(chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -470,9 +480,10 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCached ? PTMI_INLINE_WA
     // many waves as the image has tiles, each as long as n_spp; with few tiles and many samples -- one of 8 parts of a
     // 4K image at 1024 spp: 16 200 waves for 6 144 slots -- the last round of waves runs on a partly empty chip and
     // costs 15 %.  The grid is therefore spp_chunks copies of the tile grid: copy c of a tile renders samples
-    // [c S, (c+1) S) of its pixels, after copy c-1 has stored the planes and published done[tile] = c.  Workgroups are
-    // dispatched in index order and copy c-1 has the lower index, so the producer is always resident or finished when the
-    // consumer waits (in practice it finished a whole round earlier: the wait falls through).  The planes travel through
+    // [c S, (c+1) S) of its pixels, after copy c-1 has stored the planes and published done[tile] = c.  A workgroup's place
+    // in that chain is a ticket it draws when it starts (enter_sample_chunk), so the producer of what it waits for has
+    // started before it, whatever order the hardware dispatches workgroups in (in practice the producer finished a whole
+    // round earlier: the wait falls through).  The planes travel through
     // memory between copies: release / acquire at agent scope (L2 write-back, L1 invalidate); copies of one tile run on
     // the same XCD (the grid of a copy is a multiple of 32).  Results do not depend on the chunking (sample-split invariance).
     unsigned int wg; int chunk, n_spp_chunk;
@@ -2782,14 +2793,7 @@ static hipError_t choose_sample_chunks(RenderArgs &b, unsigned int per_copy, int
     const int wanted = b.spp_chunks;                           // 0 = automatic, 1 = off, k = forced
     b.spp_chunks = 1;
     if (!b.chunk_done || b.chunk_capacity < per_copy || wanted == 1 || b.screen_x) return hipSuccess;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e != hipSuccess) return e;
-        if (cus <= 0) cus = 256;
-    }
+    const int cus = b.cus > 0 ? b.cus : 256;                   // of the context's device (ptmi_create)
     const unsigned long long slots = (unsigned long long)cus * 4ull * (unsigned long long)waves_per_simd;
     int k = wanted > 1 ? wanted : (int)((16ull * slots + per_copy - 1) / per_copy);    // aim at >= 16 rounds of waves
     if (wanted <= 0 && k > b.n_spp / 64) k = b.n_spp / 64;
@@ -2797,7 +2801,8 @@ static hipError_t choose_sample_chunks(RenderArgs &b, unsigned int per_copy, int
     if (k > 64) k = 64;
     if (k < 2) return hipSuccess;
     b.spp_chunks = k;
-    return hipMemsetAsync(b.chunk_done, 0, (size_t)per_copy * sizeof(unsigned int), stream);
+    if (hipError_t e = hipMemsetAsync(b.chunk_done, 0, (size_t)per_copy * sizeof(unsigned int), stream)) return e;
+    return hipMemsetAsync(b.chunk_done + b.chunk_capacity, 0, sizeof(unsigned int), stream);      // the ticket counter
 }
 
 // Which render Inline kernel a variant is (ptmi_set_variant):

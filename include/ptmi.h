@@ -211,6 +211,9 @@ int ptmi_download_color(ptmi_ctx *ctx, float *r, float *g, float *b);   /* what 
 int ptmi_render(ptmi_ctx *ctx, const ptmi_camera *camera, int algorithm,
                 int bounce_limit, int n_spp);
 int ptmi_synchronize(ptmi_ctx *ctx);
+/* 1 if ptmi_render with `algorithm` would wait for device work before it returns under the context's present scene and options
+ * (the stream form of Streams with GLASS, or with PTMI_OPT_STREAM_BATCH, reads its overflow counters back), 0 if it only enqueues. */
+int ptmi_render_blocks(ptmi_ctx *ctx, int algorithm);
 
 /* Compatibility form = exactly one call of the closure built by compileFor: host planes in,
  * host planes out, one sample.  screen_x / screen_y are the two Int planes of the
@@ -263,6 +266,9 @@ int ptmi_group_set_scene(ptmi_group *group, const ptmi_sphere *spheres, int n_sp
 int ptmi_group_resize(ptmi_group *group, int width, int height);
 int ptmi_group_init_output(ptmi_group *group, uint64_t seed0);
 int ptmi_group_reseed(ptmi_group *group, uint64_t seed0);
+/* ptmi_set_option / ptmi_set_variant on every member (ptmi_group_member gives access to a single one). */
+int ptmi_group_set_option(ptmi_group *group, int option, int64_t value);
+int ptmi_group_set_variant(ptmi_group *group, int variant);
 /* ptmi_render on every member; asynchronous: all devices are busy before the call returns. */
 int ptmi_group_render(ptmi_group *group, const ptmi_camera *camera, int algorithm, int bounce_limit, int n_spp);
 int ptmi_group_synchronize(ptmi_group *group);
@@ -270,7 +276,9 @@ int ptmi_group_synchronize(ptmi_group *group);
  * copy path, all members at once, and the stripes are stitched in place.  Synchronous. */
 int ptmi_group_download_color(ptmi_group *group, float *r, float *g, float *b);
 /* The whole image's colour planes into DEVICE planes [height][width] on member `root`'s device: RCCL grouped
- * ncclSend / ncclRecv over xGMI (every peer has its own link to the root), then a stitch kernel.  Synchronous. */
+ * ncclSend / ncclRecv over xGMI (every peer has its own link to the root), then a stitch kernel.  Synchronous.  The
+ * caller's current HIP device is left as it was.  (Exercised with one physical device only so far -- a member's planes
+ * travelling through ncclSend / ncclRecv to itself; more than one device has not been available to this build.) */
 int ptmi_group_gather_color(ptmi_group *group, int root, float *r_device, float *g_device, float *b_device);
 int ptmi_group_get_stats(ptmi_group *group, ptmi_stats *sum);  /* sums (maxima for the time and step fields) over the members */
 /* The partition's arithmetic, usable without a device: rows part `part` holds, and the image row of one of them. */

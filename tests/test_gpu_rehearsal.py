@@ -1,0 +1,38 @@
+"""The N-rank path of bench.py end to end on the one GPU of the test box: `python -m torch.distributed.run --nproc-per-node 3
+bench.py --gpus 3 --scaling strong` under PTMI_BENCH_REHEARSAL=1 (all ranks share cuda:0 and talk over gloo), as a fresh child
+process, at a reduced sample count.  Rank 0's gathered image must equal the image ONE context renders, bit for bit: row stripes,
+seeds from the global pixel index, the overlapped gather and the reassembly change nothing.  (Three ranks: a GPU box admits six
+processes on its card, and the test runner and the launcher's agent are two of them; the 8-part shape itself -- 10-row stripes, 270 rows per part -- is
+rehearsed in one process by tests/test_group.py and over gloo, without the card, by tests/test_parallel.py.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_bench_strong_scaling_rehearsal_gathers_the_one_context_image():
+    env = dict(os.environ, PTMI_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "3", "--scaling", "strong", "--spp", "6",
+           "--steps", "2", "--warmup", "1", "--check-image", "--no-n1-reference"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 3 and out["scaling"] == "strong"
+    assert out["config"]["width"] == 3840 and out["config"]["height"] == 2160
+    assert out["gathered_image_equals_one_context"] is True

@@ -190,3 +190,27 @@ def test_sample_chunks_of_the_streams_kernels(pkg, ora, scene_name):
         want, live_ref = ora.render_streams_tree(scene[0], scene[1], cam, w, h, CAP, spp, start)[:2]
     assert_planes_equal(got, want, "streams in 4 sample chunks (%s)" % scene_name)
     assert live == live_ref
+
+
+@pytest.mark.parametrize("stream_form", [False, True])
+def test_stream_iterations_is_per_launch(ctx, pkg, ora, stream_form):
+    """ptmi_stats.stream_iterations is the deepest traceStep of the LAST launch (sharded maxima, all shards cleared per launch):
+    a deep launch (the mirror box: hundreds of steps) followed by a shallow one must report the shallow figure."""
+    B = pkg.binding
+    cam = pkg.world.initial_camera()
+    w, h = 72, 40
+    start = initial_planes(ora, w, h)
+    ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM if stream_form else B.FORM_AUTO)
+    try:
+        ctx.set_scene(*pkg.world.mirror_box())
+        ctx.resize(w, h)
+        ctx.upload_state(*start)
+        ctx.render(cam, 15, 1, pkg.STREAMS)
+        deep = ctx.stats()["stream_iterations"]
+        ctx.set_scene(*pkg.world.main_scene())
+        ctx.upload_state(*start)
+        ctx.render(cam, 15, 1, pkg.STREAMS)
+        shallow = ctx.stats()["stream_iterations"]
+    finally:
+        ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_AUTO)
+    assert deep > 200 and 1 <= shallow < 64

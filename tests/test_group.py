@@ -87,10 +87,14 @@ def test_group_device_gather_one_member(pkg, monkeypatch, force_rccl):
 
 
 @pytest.mark.gpu
-def test_group_renders_the_stream_form_on_all_members(pkg):
-    """render Streams in its stream form reads stream lengths back while it runs, so ptmi_group_render gives every member a
-    host thread; the stitched colours equal the ungrouped per-pixel Streams image bit for bit (no ray-splitting material)."""
-    sp, pl = pkg.world.scene16()
+@pytest.mark.parametrize("scene_name", ["s16", "glass"])
+def test_group_renders_the_stream_form_on_all_members(pkg, ora, scene_name):
+    """render Streams in its stream form on every member of a group (ptmi_group_set_option).  Without a ray-splitting material a
+    member only enqueues and the stitched colours equal the ungrouped per-pixel Streams image bit for bit; with GLASS every call
+    reads its overflow counters back (ptmi_render_blocks), so ptmi_group_render gives the members a host thread each, and the
+    stitched colours equal the ungrouped stream-form image within the tolerance of the undefined addition order."""
+    B = pkg.binding
+    sp, pl = pkg.world.scene16() if scene_name == "s16" else pkg.world.glass_scene()
     cam = pkg.world.initial_camera()
     w, h = 211, 97
     with pkg.Context(0) as c:
@@ -100,14 +104,52 @@ def test_group_renders_the_stream_form_on_all_members(pkg):
         c.render(cam, 8, 3, pkg.STREAMS)
         want = c.download_color()
         live = c.stats()["live_bounces"]
+        assert not c.render_blocks(pkg.STREAMS)
+        c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+        assert c.render_blocks(pkg.STREAMS) == (scene_name == "glass") and not c.render_blocks(pkg.INLINE)
     with pkg.Group([0, 0, 0], 4) as g:
         g.set_scene(sp, pl)
         g.resize(w, h)
         g.init_output(11)
-        for i in range(g.size):
-            g.member(i).set_option(pkg.binding.OPT_STREAMS_FORM, pkg.binding.FORM_STREAM)
+        g.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+        assert all(g.member(i).get_option(B.OPT_STREAMS_FORM) == B.FORM_STREAM for i in range(g.size))
         g.render(cam, 8, 3, pkg.STREAMS)
         g.synchronize()
         got = g.download_color()
-        assert g.stats()["live_bounces"] == live
-    assert_planes_equal(got, want, "group of 3, stream form")
+        st = g.stats()
+        assert st["live_bounces"] == live and st["stream_rays_dropped"] == 0
+        with pytest.raises(pkg.PtmiError):
+            g.set_option(99, 0)
+        g.set_variant(0)
+    if scene_name == "s16":
+        assert_planes_equal(got, want, "group of 3, stream form")
+    else:
+        for a, b in zip(got, want):
+            assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_group_of_8_in_the_8_gpu_shape(pkg):
+    """The shape of the 8-GPU job in ONE process: a 3840x2160 image, 10-row stripes over a group of 8 members (270 rows each;
+    here they share the one device of the test box).  ptmi_group_download_color equals the whole image of one context bit for
+    bit, and so do the members' live-bounce counts in sum."""
+    sp, pl = pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    w, h, spp = 3840, 2160, 2
+    with pkg.Context(0) as c:
+        c.set_scene(sp, pl)
+        c.resize(w, h)
+        c.init_output(0x5EED1234)
+        c.render(cam, 8, spp)
+        want = c.download_color()
+        live = c.stats()["live_bounces"]
+    with pkg.Group([0] * 8, 10) as g:
+        g.set_scene(sp, pl)
+        g.resize(w, h)
+        assert [g.member(i).local_rows for i in range(8)] == [270] * 8
+        g.init_output(0x5EED1234)
+        g.render(cam, 8, spp)
+        got = g.download_color()
+        st = g.stats()
+    assert_planes_equal(got, want, "group of 8, 10-row stripes, 4K")
+    assert st["live_bounces"] == live and st["samples"] == w * h * spp

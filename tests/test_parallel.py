@@ -67,6 +67,14 @@ def test_gather_color_over_gloo(tmp_path, world, height, stripe):
     assert torch.load(out) is True
 
 
+def test_gather_color_in_the_8_gpu_shape(tmp_path):
+    """The shape `bench.py --gpus 8` has: a 3840x2160 image in 10-row stripes over 8 ranks, 270 rows and 12.4 MB of colour
+    per rank, eight gather buffers on the root -- over gloo, on the CPU."""
+    out = str(tmp_path / "ok8.pt")
+    mp.spawn(_worker, args=(8, _free_port(), 2160, 3840, 10, out), nprocs=8, join=True)
+    assert torch.load(out) is True
+
+
 def test_gather_color_single_rank_is_a_row_scatter():
     SP, gather_color = _partition_cls()
     part = SP(10, 1, 0, 4)
