@@ -58,12 +58,28 @@ def build_ablations_lib(force=False):
     return ABLATIONS_LIB
 
 
+def _contracted_object(obj, extra_flags=(), verbose=False):
+    """ptmi_kernels.hip once more, render Inline only, with a * b + c contracted into FMAs (-ffp-contract=fast) and every name
+    in namespace ptmi_contracted: the measurement object behind PTMI_OPT_ARITHMETIC (never the default arithmetic)."""
+    flags = [f for f in FLAGS if f not in ("-ffp-contract=off", "-shared", "-pthread", "-ldl")]
+    cmd = [hipcc_path()] + flags + list(extra_flags) + ["-ffp-contract=fast", "-DPTMI_CONTRACTED_BUILD", "-Dptmi=ptmi_contracted", "-c",
+                                                          os.path.join(CSRC, "ptmi_kernels.hip"), "-o", obj]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    return obj
+
+
 def build_lib(force=False, verbose=False, extra_flags=(), out=None):
     """Compile the shared library if sources are newer than it. Returns its path.
     `out` + `extra_flags` build a differently-flagged copy elsewhere (diagnostic builds)."""
     if out is not None:
-        cmd = [hipcc_path()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
+        obj = _contracted_object(out + ".contracted.o", extra_flags)
+        cmd = [hipcc_path()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-Wl," + obj, "-o", out]
         res = subprocess.run(cmd, capture_output=True, text=True)
+        os.remove(obj)
         if res.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
         return out
@@ -75,10 +91,12 @@ def build_lib(force=False, verbose=False, extra_flags=(), out=None):
         fcntl.flock(lock, fcntl.LOCK_EX)
         if force or is_stale():
             tmp = "%s.tmp.%d" % (LIB, os.getpid())
-            cmd = [hipcc_path()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+            obj = _contracted_object(tmp + ".contracted.o", extra_flags, verbose)
+            cmd = [hipcc_path()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-Wl," + obj, "-o", tmp]
             if verbose:
                 print(" ".join(cmd))
             res = subprocess.run(cmd, capture_output=True, text=True)
+            os.remove(obj)
             if res.returncode != 0:
                 raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
             os.replace(tmp, LIB)

@@ -19,6 +19,9 @@
 
 using namespace ptmi;
 
+// render Inline with contracted arithmetic: the second object made from ptmi_kernels.hip (see its last lines)
+extern "C" int ptmi_contracted_launch_inline(const void *args, int variant, void *stream);
+
 struct ptmi_ctx {
     std::mutex mu;
     int device = 0;
@@ -103,6 +106,7 @@ struct ptmi_ctx {
     int opt_form = PTMI_FORM_AUTO;
     int opt_batch = 0;
     int opt_spp_chunks = 0;                    // 0 = automatic
+    int opt_arithmetic = PTMI_ARITH_EXACT;
 };
 
 namespace {
@@ -539,7 +543,9 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
         a.spp_chunks = sx ? 1 : c->opt_spp_chunks;
     }
     if (c->timing) { PTMI_HIP(c, hipEventRecord(c->ev0, c->stream)); }
-    if (algorithm == PTMI_INLINE) {
+    if (algorithm == PTMI_INLINE && c->opt_arithmetic == PTMI_ARITH_CONTRACTED) {
+        PTMI_HIP(c, (hipError_t)ptmi_contracted_launch_inline(&a, c->variant == 9 ? 0 : c->variant, c->stream));
+    } else if (algorithm == PTMI_INLINE) {
         PTMI_HIP(c, launch_render_inline(a, c->variant, c->stream));
     } else if (stream_form) {                              // rays travel through streams in HBM (PTMI_OPT_STREAMS_FORM; variant 9)
         if (int rc = render_streams_wavefront(c, a, n_spp, *camera)) return rc;
@@ -837,6 +843,9 @@ int ptmi_set_option(ptmi_ctx *c, int option, int64_t value)
     case PTMI_OPT_SPP_CHUNKS:
         if (value < 0 || value > 64) return fail(c, PTMI_EINVAL, "sample chunks must be in [0, 64]");
         c->opt_spp_chunks = (int)value; return PTMI_OK;
+    case PTMI_OPT_ARITHMETIC:
+        if (value != PTMI_ARITH_EXACT && value != PTMI_ARITH_CONTRACTED) return fail(c, PTMI_EINVAL, "unknown arithmetic mode");
+        c->opt_arithmetic = (int)value; return PTMI_OK;
     default: return fail(c, PTMI_EINVAL, "unknown option");
     }
 }
@@ -853,6 +862,7 @@ int ptmi_get_option(ptmi_ctx *c, int option, int64_t *value)
     case PTMI_OPT_STREAMS_FORM:      *value = c->opt_form; return PTMI_OK;
     case PTMI_OPT_STREAM_BATCH:      *value = c->opt_batch; return PTMI_OK;
     case PTMI_OPT_SPP_CHUNKS: *value = c->opt_spp_chunks; return PTMI_OK;
+    case PTMI_OPT_ARITHMETIC: *value = c->opt_arithmetic; return PTMI_OK;
     default: return fail(c, PTMI_EINVAL, "unknown option");
     }
 }

@@ -1194,6 +1194,7 @@ __global__ void __launch_bounds__(kRenderBlock) render_inline_persistent_kernel(
 
 #endif  // PTMI_ABLATIONS
 
+#ifndef PTMI_CONTRACTED_BUILD   // (the contracted-arithmetic object holds render Inline only: see the end of the file)
 // ---------------------------------------------------------------------------------------
 // render Streams (Trace.hs:141-191, 272-331).  The reference keeps one ray per pixel in a stream
 // that `expand` compacts after every step (numNewRays is 0 or 1, Trace.hs:329-331) and scatters the
@@ -2102,7 +2103,10 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
 #define PTMI_RING 16
 #endif
 constexpr unsigned int kRing = PTMI_RING;                     // records of a wave's child ring (a power of two, <= 64)
-constexpr unsigned int kSpill = 256;                          // records of a wave's spill queue in HBM (a power of two)
+#ifndef PTMI_SPILL
+#define PTMI_SPILL 256
+#endif
+constexpr unsigned int kSpill = PTMI_SPILL;                   // records of a wave's spill queue in HBM (a power of two)
 #ifndef PTMI_ITEM_BATCH
 #define PTMI_ITEM_BATCH 1
 #endif
@@ -2388,8 +2392,9 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
         atomicAdd(reinterpret_cast<unsigned long long *>(wc + 12), dur);
         atomicMax(reinterpret_cast<unsigned long long *>(wc + 14), dur);
         atomicAdd(wc + 16, 1u);
-        const unsigned long long bin = dur >> 20;
-        atomicAdd(wc + 24 + (bin < 39ull ? (unsigned int)bin : 39u), 1u);
+        const unsigned int x = cur.home;                              // per XCD: [24+x] waves, [32+x] sum of durations >> 12, [40+x] longest >> 12, [48+x] trips
+        atomicAdd(wc + 24 + x, 1u); atomicAdd(wc + 32 + x, (unsigned int)(dur >> 12)); atomicMax(wc + 40 + x, (unsigned int)(dur >> 12));
+        atomicAdd(wc + 48 + x, st_trips);
     }
 #endif
     // what is left of this wave's last overflow block: holes
@@ -2727,6 +2732,8 @@ __global__ void __launch_bounds__(kBlock) eval_sincos_kernel(const float *x, int
     s[i] = sn; c[i] = cs;
 }
 
+#endif  // PTMI_CONTRACTED_BUILD
+
 inline unsigned int blocks_for(long long n, int block = kBlock) { return (unsigned int)((n + block - 1) / block); }
 
 }  // namespace
@@ -2749,6 +2756,7 @@ bool uses_quad_order(const RenderArgs &a, int algorithm_inline, int variant)
     return algorithm_inline ? (a.bounce_limit > 0 && a.n_spp > 0) : true;
 }
 
+#ifndef PTMI_CONTRACTED_BUILD
 namespace {
 // Quads by decreasing recorded cost, in 256 cost classes (order inside a class does not matter): one workgroup,
 // LDS histogram, scan, scatter.  n is a few thousand to a few ten thousand.  Every cost is read ONCE and its class
@@ -2785,6 +2793,8 @@ hipError_t launch_quad_order(const unsigned int *cost, unsigned int *order, unsi
     hipLaunchKernelGGL(quad_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, cls, n);
     return hipGetLastError();
 }
+
+#endif  // PTMI_CONTRACTED_BUILD
 
 // Sample chunks (render_inline_kernel): only when the launch has few rounds of waves and every copy keeps >= 64 samples
 // (every copy re-evaluates the primary hit and moves the planes once more).  Sets b.spp_chunks (>= 1) and clears the flags.
@@ -2897,6 +2907,7 @@ hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t st
     return hipErrorInvalidValue;                             // ptmi_set_variant admits only what the build holds
 }
 
+#ifndef PTMI_CONTRACTED_BUILD
 bool variant_available(int variant)
 {
     if (variant == 0 || variant == 4 || variant == 5 || variant == 9 || variant == 13 || variant == 17) return true;
@@ -3096,4 +3107,19 @@ hipError_t launch_eval_sincos(const float *x, int n, float *s, float *c, hipStre
     return hipGetLastError();
 }
 
+#endif  // PTMI_CONTRACTED_BUILD
+
 }  // namespace ptmi
+
+#ifdef PTMI_CONTRACTED_BUILD
+// THE CONTRACTED-ARITHMETIC OBJECT.  This file is compiled a second time with -ffp-contract=fast and -Dptmi=ptmi_contracted
+// (every name above then lives in namespace ptmi_contracted, render Inline only): the same kernel with a * b + c contracted
+// into fused multiply-adds wherever the source writes it -- dot products, cross products, the rotation, the quaternion.  It is
+// NOT the reference's arithmetic as this repository reads it (every operation rounded on its own); it
+// exists to MEASURE how much of the kernel's time that reading costs (PTMI_OPT_ARITHMETIC, never the default, never the
+// headline).  One C entry, because the two objects' RenderArgs are distinct types of identical layout.
+extern "C" int ptmi_contracted_launch_inline(const void *args, int variant, void *stream)
+{
+    return (int)ptmi::launch_render_inline(*static_cast<const ptmi::RenderArgs *>(args), variant, static_cast<hipStream_t>(stream));
+}
+#endif

@@ -142,7 +142,7 @@ int ptmi_set_timing(ptmi_ctx *ctx, int enabled);
 int ptmi_set_variant(ptmi_ctx *ctx, int variant);
 
 /* Options.  1-5 concern `render Streams` (src/Scene/Trace.hs:141-191) and never change `render Inline`; 6 is a
- * scheduling knob of the per-pixel kernels that changes no result. */
+ * scheduling knob of the per-pixel kernels that changes no result; 7 is a labelled measurement mode of `render Inline`. */
 enum {
     /* Which seed a pixel carries out of `combine` (Trace.hs:179-184): the combination function keeps the seed of its
      * FIRST argument, and which of (new value, accumulator element) `permute` hands it first is backend behaviour
@@ -177,8 +177,15 @@ enum {
      * many samples (one part of a multi-GPU image) is cut into this many chained copies of the tile grid, each rendering
      * a slice of the samples, so that the end of the launch does not run on a partly empty chip.
      * 0 (default) = automatic, 1 = off, k = k copies. */
-    PTMI_OPT_SPP_CHUNKS = 6
+    PTMI_OPT_SPP_CHUNKS = 6,
+    /* A MEASUREMENT mode of `render Inline`, never the default: PTMI_ARITH_CONTRACTED runs the same kernel compiled with
+     * a * b + c contracted into fused multiply-adds (dot and cross products, the rotation, the quaternion) -- what a compiler
+     * with -ffp-contract=fast, or Accelerate's fast-math LLVM backends, may do to the reference's source.  Its planes are NOT
+     * the oracle's (the RNG planes still are: integer arithmetic); DESIGN.md reports how far they are and what the literal
+     * reading -- every operation rounded on its own, PTMI_ARITH_EXACT -- costs.  Variants and Streams ignore it. */
+    PTMI_OPT_ARITHMETIC = 7
 };
+enum { PTMI_ARITH_EXACT = 0, PTMI_ARITH_CONTRACTED = 1 };
 enum { PTMI_SEED_KEEP_ACCUMULATOR = 0, PTMI_SEED_FROM_RESULT = 1, PTMI_SEED_AUTO = 2 };
 enum { PTMI_FORM_AUTO = 0, PTMI_FORM_STREAM = 1 };
 int ptmi_set_option(ptmi_ctx *ctx, int option, int64_t value);

@@ -340,3 +340,37 @@ def test_staged_host_transfers_equal_plain_copies(pkg, ora, monkeypatch):
         assert_planes_equal(two, want2, "render1 with screen planes, threads=%s" % threads)
         assert_planes_equal(three, want3, "resident after upload, threads=%s" % threads)
         assert np.array_equal(rgb, results["0"][3]) and np.array_equal(rgba, results["0"][4])
+
+
+def test_contracted_arithmetic_is_a_labelled_mode_and_never_the_default(pkg, ora):
+    """PTMI_OPT_ARITHMETIC: the default is the literal arithmetic (bit-identical to the oracle); PTMI_ARITH_CONTRACTED -- the same
+    kernel with a * b + c fused, a measurement mode -- stays close (most pixels within north_star's 1e-4 after one sample) but is
+    NOT the oracle's result; switching back restores it bit for bit."""
+    B = pkg.binding
+    sp, pl = pkg.world.main_scene()
+    cam = pkg.world.initial_camera()
+    w, h = 320, 200
+    start = initial_planes(ora, w, h)
+    want, _ = ora.render_inline(sp, pl, cam, w, h, 15, 1, start)
+    with pkg.Context(0) as c:
+        assert c.get_option(B.OPT_ARITHMETIC) == B.ARITH_EXACT
+        c.set_scene(sp, pl)
+        c.resize(w, h)
+        c.upload_state(*start)
+        c.render(cam, 15, 1)
+        assert_planes_equal(c.download_state(), want, "default arithmetic")
+        c.set_option(B.OPT_ARITHMETIC, B.ARITH_CONTRACTED)
+        c.upload_state(*start)
+        c.render(cam, 15, 1)
+        got = c.download_state()
+        close = np.ones((h, w), bool)
+        for k in range(3):
+            close &= np.abs(got[k] - want[k]) <= 1e-4 * np.abs(want[k])
+        assert 0.99 < close.mean()
+        assert any(not np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)) for k in range(3))     # it really is other arithmetic
+        c.set_option(B.OPT_ARITHMETIC, B.ARITH_EXACT)
+        c.upload_state(*start)
+        c.render(cam, 15, 1)
+        assert_planes_equal(c.download_state(), want, "back to the default arithmetic")
+        with pytest.raises(pkg.PtmiError):
+            c.set_option(B.OPT_ARITHMETIC, 2)

@@ -219,6 +219,7 @@ def test_random_glass_scenes_tree_walk_and_stream_form(ctx, pkg, ora):
             if case % 4 == 0 and n_glass:
                 ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
                 ctx.set_option(B.OPT_STREAM_CAPACITY, 64)
+                ctx.set_option(B.OPT_STREAM_BATCH, int(r.choice([0, 0, 1, 2, 5])))    # samples per item: several passes over the start hits
                 ctx.upload_state(*start)
                 ctx.reset_stats()
                 ctx.render(cam, limit, spp, pkg.STREAMS)
@@ -232,6 +233,7 @@ def test_random_glass_scenes_tree_walk_and_stream_form(ctx, pkg, ora):
                         what, float(np.max(ratio)), int(np.argmax(ratio)), a.reshape(-1)[np.argmax(ratio)], b.reshape(-1)[np.argmax(ratio)])
         finally:
             ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_AUTO)
+            ctx.set_option(B.OPT_STREAM_BATCH, 0)
             ctx.set_option(B.OPT_STREAM_CAPACITY, 4)
             ctx.set_option(B.OPT_STREAM_STEP_CAP, 1 << 16)
             ctx.set_option(B.OPT_SPP_CHUNKS, 0)

@@ -152,6 +152,40 @@ def test_sphere_normals_equal_oracle_when_every_lane_hits(ctx, pkg, ora):
             assert np.array_equal(nrm[i, 3:].view(np.uint32), nor.view(np.uint32)), (radius, i, nrm[i, 3:], nor)
 
 
+def test_sqrt_rn_around_its_2_to_the_minus_96_boundary(ctx, pkg, ora):
+    """sqrt_rn (v_sqrt_f32 + two FMA residuals) is exact for x = 0 or x >= 2^-96; below that the whole wave takes the compiler's
+    scaled square root.  Spheres with radii around 2^-48 met head-on from 2^-40 ... 2^-45 away (d2 = 0 exactly, so the argument
+    of the square root is rad^2, on both sides of 2^-96, and t = tca - sqrt(rad^2) shows its every bit): whole waves on the fast
+    path, whole waves on the scaled path, and waves that mix both.  Bit for bit against the oracle's sqrtf."""
+    r = np.random.default_rng(96)
+    boundary = 2.0 ** -48                                    # rad^2 == 2^-96
+
+    def batch(radii):
+        n = radii.size
+        k = (2.0 ** -r.integers(40, 46, n)).astype(F)
+        c = np.zeros((n, 3), F); c[:, 2] = k
+        o = np.zeros((n, 3), F)
+        d = np.tile(np.array([0.0, 0.0, 1.0], F), (n, 1))
+        sph = np.array([rp.make_sphere(pkg.world.SPHERE_DTYPE, p, q) for p, q in zip(c, radii.astype(F))])
+        just, t, _ = ctx.eval_distance_to_sphere(sph, np.concatenate([o, d], 1))
+        for i in range(n):
+            want = ora.distance_to_sphere(o[i], d[i], sph[i])
+            assert bool(just[i]) == (want is not None), i
+            if want is not None:
+                assert np.float32(t[i]).view(np.uint32) == np.float32(want).view(np.uint32), (i, float(radii[i]), float(t[i]), float(want))
+        return int(just.sum())
+
+    n = 2048
+    above = np.exp(r.uniform(np.log(boundary * 1.001), np.log(boundary * 4), n))     # (rad < 2^-45 <= the distance: every ray hits)
+    below = np.exp(r.uniform(np.log(boundary / 4096), np.log(boundary * 0.999), n))
+    assert batch(above) == n                                 # every lane on the fast path
+    assert batch(below) == n                                 # every lane below 2^-96: the scaled path
+    mixed = np.where(r.random(n) < 0.5, above, below)        # both in one wave: the wave takes the scaled path
+    assert batch(mixed) == n
+    edge = boundary * (1.0 + r.integers(-3, 4, n) * 2.0 ** -23)     # the neighbours of 2^-48 themselves
+    assert batch(edge) == n
+
+
 def test_device_sincos_equals_oracle_and_libm(ctx, ora):
     """The device's sin/cos (binary64 evaluation of glibc's algorithm) == oracle == host libm, bitwise."""
     r = np.random.default_rng(5)

@@ -3,6 +3,8 @@ for permute (+).  Without GLASS it must equal the per-pixel chain kernel and the
 adder per colour word per launch).  With the build-defined GLASS extension (no reference semantics; spec in
 oracle/pt_oracle.c glass_children) several rays of a pixel add in one launch in undefined order -- as in
 Accelerate's permute -- so colours are compared within north_star's 1e-4 relative; seeds stay exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -113,3 +115,35 @@ def test_stream_batch_option_trades_order_for_shorter_items(ctx, pkg, ora):
     assert st["live_bounces"] == live and st["stream_rays_dropped"] == 0 and st["stream_rays_truncated"] == 0
     for a, b in zip(got[:3], want[:3]):
         assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) <= REL_TOL
+
+
+def test_overflow_levels_with_tiny_rings(pkg, ora, tmp_path_factory):
+    """The rare path of the stream form: a child that finds its wave's ring AND its wave's spill queue full travels through the
+    overflow stream and is traced by a later launch (streams_level_kernel), level after level.  With the product's sizes (16 ring
+    records, 256 spill records per wave) that practically never happens, so this test builds the library with a ring of 2 and a
+    spill queue of 4 records: same rays, same counts, same seeds, colours within the tolerance of the undefined addition order."""
+    B = pkg.binding
+    out = os.path.join(str(tmp_path_factory.mktemp("tinyrings")), "libptmi_tinyrings.so")
+    lib = B.open_library(pkg._build.build_lib(out=out, extra_flags=["-DPTMI_RING=2", "-DPTMI_SPILL=4"]))
+    scene = pkg.world.glass_scene()
+    cam = pkg.world.initial_camera()
+    w, h, spp = 160, 96, 4
+    start = initial_planes(ora, w, h)
+    want, live, dropped, steps = ora.render_streams_wavefront(scene[0], scene[1], cam, w, h, CAP, spp, start, capacity_factor=16)
+    assert dropped == 0
+    for batch in (0, 1):
+        with pkg.Context(0, library=lib) as c:
+            c.set_scene(*scene)
+            c.resize(w, h)
+            c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+            c.set_option(B.OPT_STREAM_CAPACITY, 16)
+            c.set_option(B.OPT_STREAM_BATCH, batch)
+            c.upload_state(*start)
+            c.render(cam, 15, spp, pkg.STREAMS)
+            got, st = c.download_state(), c.stats()
+        for a, b in zip(got[3:], want[3:]):
+            assert np.array_equal(a, b)
+        assert st["live_bounces"] == live and st["stream_rays_dropped"] == 0 and st["stream_iterations"] == steps
+        assert st["stream_rays_spilled"] > live // 50            # the tiny ring and spill queue really overflowed
+        for a, b in zip(got[:3], want[:3]):
+            assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) <= REL_TOL

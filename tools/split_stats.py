@@ -53,7 +53,8 @@ def main():
                              "traces": round(wc[10] / trips, 2)},
                 "waves": waves, "mean_wave_cycles": round(total / waves), "longest_wave_cycles": longest,
                 "mean_over_longest": round(total / waves / max(longest, 1), 4), "spilled": st["stream_rays_spilled"], "live": st["live_bounces"],
-                "waves_by_duration_bins_of_2^20_cycles": wc[24:64]}
+                "per_xcd": {"waves": wc[24:32], "mean_wave_kcycles": [round(wc[32 + x] * 4.096 / max(wc[24 + x], 1)) for x in range(8)],
+                            "longest_wave_kcycles": [round(wc[40 + x] * 4.096) for x in range(8)], "trips_per_wave": [round(wc[48 + x] / max(wc[24 + x], 1)) for x in range(8)]}}
     print(json.dumps(out))
 
 
