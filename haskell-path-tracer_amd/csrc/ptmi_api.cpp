@@ -87,8 +87,8 @@ struct ptmi_ctx {
     int cus = 0;                     // compute units of the device (persistent grids)
     void *tree_stack = nullptr;      // tree walk: the lanes' first waiting children (RenderArgs.tree_stack)
     size_t tree_stack_bytes = 0;
-    hipStream_t aux_stream = nullptr;   // stream form, ordered kernel: the second chain of launches runs here
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    unsigned int *d_region_done = nullptr;   // stream form, ordered passes: items published per region
+    unsigned int region_done_words = 0;
     int opt_ordered_passes = 0;      // 0 = automatic (experiments: PTMI_ORDERED_PASSES in the environment)
     unsigned int *d_qcount = nullptr;
     uint64_t rays_dropped = 0;
@@ -308,57 +308,47 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
     ItemArgs it{};
     it.hits = hits;
     it.n_positions = n_regions / 4u;
-    it.n_chains = 1; it.chain = 0; it.passes = 1;
+    it.passes = 1;
     it.n_px = (unsigned int)n;
     it.stats = c->d_qcount;
     auto tickets_of = [&](int launch) { return c->d_qcount + (size_t)(kLvTickets + 8 * launch) * kCounterStride; };
     const int cus = c->cus > 0 ? c->cus : 256;
     if (ordered) {
         // One lane renders a pixel's samples in order, so an item is a serial chain and the end of a launch is as long as its last
-        // items: with few items per lane (1080p: three) a quarter of the wave-time of ONE launch lay after the first wave had
-        // ended.  The samples are therefore cut into passes -- one launch each, a pixel's seven words travelling through the
-        // planes in between -- and the positions into two CHAINS that run on two streams: within a chain the passes follow each
-        // other in stream order (nothing else orders a pixel's samples), and while the last items of one chain's launch end, the
-        // waves of the other chain's launch take the slots they leave.
+        // items: with three items per lane (1080p) a quarter of the wave-time of the launch lay after the first wave had ended.
+        // The samples are therefore cut into ordered passes INSIDE the one launch (streams_pixels_kernel): a pixel's next pass is
+        // handed out once its previous one has been published.
         PTMI_HIP(c, launch_streams_advance_missed(a, hits, n_spp, c->stream));
         PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, kItersBytes, c->stream));
-        // (measured, S16: 1080p / 64 spp 4.65 -> 4.53 ms with two passes, 4.59 with four -- every launch loads and stores all
-        // items once more; 4K / 64 spp, eighteen items per lane: 16.19 -> 16.33.  Passes pay where a lane sees few, long items.)
-        const unsigned int lanes = (unsigned int)(cus * 4 * streams_pixels_waves()) * 64u;
+        const unsigned int grid_full = (unsigned int)(cus * 4 * streams_pixels_waves());
+        const unsigned long long lanes = 64ull * grid_full;
         int passes = 1;
         if (c->opt_ordered_passes > 0) passes = c->opt_ordered_passes;
-        else if (n < 4ull * lanes && n_spp >= 128) passes = n_spp / 64;
+        else if (c->opt_batch > 0) passes = (n_spp + c->opt_batch - 1) / c->opt_batch;     // PTMI_OPT_STREAM_BATCH: samples per item
+        else if (n < 8ull * lanes) passes = n_spp / 128;       // few, LONG items per lane: shorten them to 128 samples (short passes cannot pay:
+                                                               // the kernel's comment; one of 8 parts of a 4K image at 1024 spp: 44.0 / 42.3 / 40.4 / 37.8 ms with 1 / 2 / 4 / 8 passes)
         if (passes > 8) passes = 8;
-        if (passes > n_spp) passes = n_spp;
+        const int most = n_spp / streams_publish_every();      // a pass holds at least that many samples (the kernel's publish interval)
+        if (passes > most) passes = most;
         if (passes < 1) passes = 1;
-        const int chains = passes > 1 && it.n_positions >= 16u ? 2 : 1;
-        const unsigned int grid = (unsigned int)(cus * 4 * streams_pixels_waves());
-        if (chains > 1) {
-            if (!c->aux_stream) {
-                PTMI_HIP(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-                PTMI_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-                PTMI_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        it.passes = passes;
+        it.publish_every = 1;
+        while (it.publish_every * 2 <= n_spp / passes && it.publish_every < 256) it.publish_every *= 2;
+        it.chunk_cursor = tickets_of(0);
+        if (passes > 1) {
+            if (n_regions > c->region_done_words) {
+                PTMI_HIP(c, hipStreamSynchronize(c->stream));
+                if (c->d_region_done) { (void)hipFree(c->d_region_done); c->d_region_done = nullptr; c->region_done_words = 0; }
+                PTMI_HIP(c, hipMalloc(&c->d_region_done, (size_t)n_regions * sizeof(unsigned int)));
+                c->region_done_words = n_regions;
             }
-            PTMI_HIP(c, hipEventRecord(c->ev_fork, c->stream));
-            PTMI_HIP(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+            PTMI_HIP(c, hipMemsetAsync(c->d_region_done, 0, (size_t)n_regions * sizeof(unsigned int), c->stream));
+            it.region_done = c->d_region_done;
         }
-        const int per = n_spp / passes, extra = n_spp % passes;       // the first `extra` passes render one sample more
-        RenderArgs b = a;
-        for (int k = 0; k < passes; ++k) {
-            b.n_spp = per + (k < extra ? 1 : 0);
-            for (int ch = 0; ch < chains; ++ch) {
-                it.n_chains = chains; it.chain = ch;
-                it.chunk_cursor = tickets_of(k * chains + ch);
-                unsigned int g = grid;
-                const unsigned long long chunks = ((unsigned long long)it.n_positions * 4ull + (unsigned)chains - 1ull) / (unsigned)chains;
-                if (g > chunks) g = (unsigned int)(chunks < 1 ? 1 : chunks);
-                PTMI_HIP(c, launch_streams_pixels(b, it, g, ch == 0 ? c->stream : c->aux_stream));
-            }
-        }
-        if (chains > 1) {
-            PTMI_HIP(c, hipEventRecord(c->ev_join, c->aux_stream));
-            PTMI_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-        }
+        unsigned int grid = grid_full;
+        const unsigned long long tickets = (unsigned long long)n_regions * (unsigned long long)passes;
+        if (grid > tickets) grid = (unsigned int)(tickets < 1 ? 1 : tickets);
+        PTMI_HIP(c, launch_streams_pixels(a, it, grid, c->stream));
         return PTMI_OK;
     }
 
@@ -677,9 +667,7 @@ void ptmi_destroy(ptmi_ctx *c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_snap) (void)hipEventDestroy(c->ev_snap);
-    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->d_region_done) (void)hipFree(c->d_region_done);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }

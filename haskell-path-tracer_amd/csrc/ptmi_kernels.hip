@@ -1878,17 +1878,18 @@ __global__ void __launch_bounds__(256) streams_advance_missed_kernel(const Rende
 
 // The chunk cursor of the item kernels.  A chunk is 64 slots of a region of the start-hit list; the regions come in groups
 // of four, one group per dispatch POSITION (the four tiles of a quad, most expensive quad first).  The positions are dealt to
-// queues: position p belongs to chain (p / 8) mod n_chains -- a launch works on one chain -- and to XCD p mod 8, so that the
-// tiles of a quad, whose pixels share cache lines of the planes, are worked on behind ONE L2 (dealt to any XCD, every line
-// of the planes was fetched four times).  A queue is a ticket counter: ticket j stands for chunk (j mod n) of pass (j div n),
-// n = the queue's chunks, passes outermost and positions in dispatch order.  A wave takes tickets -- one returning atomic
-// each; an item is tens to thousands of loop trips -- from the queue of the XCD it runs on (HW_REG_XCC_ID; which wave works
-// on which chunk changes no result) and, when that one is exhausted, from the other XCDs' queues.  Eight counters instead
-// of one: a single word serves ~90 atomics per microsecond and thousands of waves start together.  Regions without
-// records (tiles whose primary rays all miss) are skipped.
+// eight queues, position p to queue p mod 8 -- one queue per XCD -- so that the tiles of a quad, whose pixels share cache lines
+// of the planes, are worked on behind ONE L2 (dealt to any XCD, every line of the planes was fetched four times).  A queue is a
+// ticket counter: ticket j stands for chunk (j mod n) of pass (j div n), n = the queue's chunks, passes outermost and
+// positions in dispatch order.  A wave takes tickets -- one returning atomic each; an item is tens to thousands of loop trips
+// -- from the queue of the XCD it runs on (HW_REG_XCC_ID; which wave works on which chunk changes no result) and, when that one
+// is exhausted, from the other XCDs' queues.  Eight counters instead of one: a single word serves ~90 atomics per microsecond
+// and thousands of waves start together.  Regions without records (tiles whose primary rays all miss) are skipped.
 struct ChunkCursor {
     unsigned int taken, len, first, pass;    // of the chunk in hand: records handed out, records, first slot, pass
+    unsigned int region;                     // ... its region
     unsigned int home, tries;                // the wave's XCD; queues found exhausted (8: nothing is left)
+    bool ready;                              // (ordered passes) the chunk's previous pass has been published and acquired
 };
 __device__ __forceinline__ unsigned int xcc_id()
 {
@@ -1898,12 +1899,11 @@ __device__ __forceinline__ bool chunks_left(const ChunkCursor &c) { return c.tri
 __device__ __forceinline__ void next_chunk(ChunkCursor &c, const ItemArgs &it)
 {
     const unsigned int per = it.hits.region_slots >> 6;      // chunks per region: 1 or 2
-    const unsigned int nch = (unsigned int)it.n_chains, ch = (unsigned int)it.chain;
-    c.taken = 0; c.len = 0;
+    c.taken = 0; c.len = 0; c.ready = false;
     while (c.tries < 8u) {
         const unsigned int q = (c.home + c.tries) & 7u;
-        // positions of this chain in queue q: p = (s n_chains + chain) 8 + q < n_positions
-        const unsigned int n_pos = it.n_positions > q + 8u * ch ? (it.n_positions - q - 8u * ch - 1u) / (8u * nch) + 1u : 0u;
+        // positions in queue q: p = 8 s + q < n_positions
+        const unsigned int n_pos = it.n_positions > q ? (it.n_positions - q - 1u) / 8u + 1u : 0u;
         const unsigned int n = n_pos * 4u * per;
         unsigned int j = 0;
         if ((threadIdx.x & 63) == 0) j = atomicAdd(it.chunk_cursor + (size_t)q * kCounterStride, 1u);
@@ -1911,9 +1911,10 @@ __device__ __forceinline__ void next_chunk(ChunkCursor &c, const ItemArgs &it)
         if (n == 0u || j / n >= (unsigned int)it.passes) { ++c.tries; continue; }
         c.pass = j / n;
         const unsigned int k = j - c.pass * n, s_pos = k / (4u * per), r = k - s_pos * (4u * per);
-        const unsigned int region = ((s_pos * nch + ch) * 8u + q) * 4u + r / per, half = r % per;
-        const unsigned int have = it.hits.counts[region];
-        c.first = region * it.hits.region_slots + half * 64u;
+        c.region = (s_pos * 8u + q) * 4u + r / per;
+        const unsigned int half = r % per;
+        const unsigned int have = it.hits.counts[c.region];
+        c.first = c.region * it.hits.region_slots + half * 64u;
         c.len = have > half * 64u ? (have - half * 64u < 64u ? have - half * 64u : 64u) : 0u;
         if (c.len) return;
     }
@@ -1934,12 +1935,14 @@ __device__ __forceinline__ void record_item_cost(const RenderArgs &a, unsigned i
 #ifndef PTMI_PIXELS_WAVES
 #define PTMI_PIXELS_WAVES 7
 #endif
+constexpr unsigned int kPublishEvery = 16;                   // the fewest samples an ordered pass may hold (ItemArgs.publish_every: trips between a wave's releases)
 template <bool LDS_SCENE>
 __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixels_kernel(const RenderArgs a, const ItemArgs it)
 {
     // the lane's item: 0-2 position of the start hit, 3-5 axis and 6 half-angle scale of its bounce, 7 primitive, 8 quad,
-    // 9 the lane's count of shaded hits when the item began
-    __shared__ float item_const[10][kRenderBlock];
+    // 9 the lane's count of shaded hits when the item began, 10 the samples the item renders, 11 its region, 12 the region of
+    // the item the lane has stored but not yet published
+    __shared__ float item_const[13][kRenderBlock];
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -1951,7 +1954,18 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
     const float4 *M = S + a.scene.geom_f4();
     const int lane = threadIdx.x & 63;
     const unsigned int step_cap = (unsigned int)a.stream_step_cap;
-    const int n_spp = a.n_spp;
+    // ORDERED PASSES (it.passes > 1).  A pixel's samples are a serial chain, and with few items per lane the end of the launch is as
+    // long as the last items.  The samples are therefore cut into passes: an item renders one pass's samples of its pixel, and the
+    // pixel's seven words travel through the planes to whichever lane takes its next pass.  What orders them: an item of pass p is
+    // handed out only when region_done[its region] says that every item of the region's pass p - 1 has been PUBLISHED --
+    // stored, then made visible by an agent-scope release -- and the taking wave has acquired at agent scope.  A release is a
+    // write-back of the XCD's whole L2 and the L2 serves them one after the other: 7 168 waves releasing every 16 trips
+    // (112 write-backs per microsecond on the chip) DOUBLED the launch (1080p / 64 spp as four passes: 4.5 -> 9.4 ms).  So a wave
+    // publishes in batches, every it.publish_every trips -- at most as many as a pass has samples, since a lane must publish an
+    // item before it ends its next one, which is why short passes cannot pay -- or at once when it has nothing else to do.
+    // Nothing here depends on which XCD or CU a wave runs on.
+    const int passes = it.passes;
+    const unsigned int publish_mask = (unsigned int)it.publish_every - 1u;
     float *mine = &item_const[0][threadIdx.x];
     auto put = [&](int k, float v) { mine[k * kRenderBlock] = v; };
     auto get = [&](int k) { return mine[k * kRenderBlock]; };
@@ -1967,7 +1981,8 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
     unsigned long long lane_trips = 0, wave_trips = 0;        // lanes with an item, summed over the trips / trips
 #endif
 
-    bool busy = false, pending = false, has_ray = false, over = false;
+    bool busy = false, pending = false, has_ray = false, over = false, unpublished = false;
+    unsigned int trip = 0;
     V3 acc = mk(0.0f, 0.0f, 0.0f), pos = acc, normal = acc, d = acc, throughput = acc;
     Sfc32 pixel_seed; pixel_seed.a = pixel_seed.b = pixel_seed.c = pixel_seed.counter = 0;
     Sfc32 seed = pixel_seed;
@@ -1975,9 +1990,24 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
     uint32_t pixel4 = 0;                                      // byte offset of the lane's pixel in a plane
     unsigned int steps = 0, longest = 0, live = 0;
     for (;;) {
+        // ---- publish (ordered passes): the items this wave has stored since its last release
+        if (passes > 1 && __any(unpublished) && ((++trip & publish_mask) == 0u || !__any(busy))) {     // wave-uniform
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the write-back has completed before the counters move
+            if (unpublished) { atomicAdd(it.region_done + f2u(get(12)), 1u); unpublished = false; }
+        }
         // ---- refill: idle lanes take the next start hits of the wave's chunk (at once: an item is a pixel's whole sample chain)
         const unsigned long long idle = __ballot(!busy);
-        if (idle && chunks_left(cur)) {                      // wave-uniform
+        bool open = idle && chunks_left(cur);
+        if (open && cur.pass > 0u && !cur.ready) {           // wave-uniform: has the region's previous pass been published?
+            unsigned int done = 0;
+            if (lane == 0) done = __hip_atomic_load(it.region_done + cur.region, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            done = (unsigned int)__builtin_amdgcn_readfirstlane((int)done);
+            if (done >= cur.pass * cur.len) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); cur.ready = true; }
+            else { open = false; if (!__any(busy)) __builtin_amdgcn_s_sleep(8); }
+        }
+        if (open) {                                           // wave-uniform
             const unsigned int want = (unsigned int)__builtin_popcountll(idle), avail = cur.len - cur.taken;
             const unsigned int take = want < avail ? want : avail;
             const unsigned int rank = rank_in(idle);
@@ -1988,6 +2018,8 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
                 put(0, r0.x); put(1, r0.y); put(2, r0.z);
                 put(3, r0.w); put(4, r1.x); put(5, r1.y); put(6, r1.z);
                 put(7, r3.x); put(8, r3.w); put(9, u2f(live));
+                // the samples of this pass: n_spp over the passes, the first (n_spp mod passes) passes one more
+                put(10, u2f((uint32_t)(a.n_spp / passes + ((int)cur.pass < a.n_spp % passes ? 1 : 0)))); put(11, u2f(cur.region));
                 acc = mk(plane_at(a.planes.r, pixel4), plane_at(a.planes.g, pixel4), plane_at(a.planes.b, pixel4));
                 pixel_seed.a = plane_at(a.planes.sa, pixel4); pixel_seed.b = plane_at(a.planes.sb, pixel4);
                 pixel_seed.c = plane_at(a.planes.sc, pixel4); pixel_seed.counter = plane_at(a.planes.sctr, pixel4);
@@ -2024,7 +2056,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
             }
             ++s; steps = 0;
             over = false;
-            if (s < n_spp) {                                   // the pixel's next sample, from its cached start hit
+            if (s < (int)f2u(get(10))) {                       // the pixel's next sample of this pass, from its cached start hit
                 longest = longest > 1u ? longest : 1u;         // the primary ray's traceStep
                 seed = pixel_seed;
                 throughput = mk(1.0f, 1.0f, 1.0f);
@@ -2038,6 +2070,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
                 plane_at(a.planes.sc, pixel4) = pixel_seed.c; plane_at(a.planes.sctr, pixel4) = pixel_seed.counter;
                 record_item_cost(a, f2u(get(8)), live - f2u(get(9)));       // its shaded hits stand for the loop trips it took
                 busy = false;
+                if (passes > 1) { put(12, get(11)); unpublished = true; }      // (its next item ends >= kPublishEvery trips from now: after the publish)
             }
         }
         if (pending) {                                         // alive (a fresh sample starts with throughput 1)
@@ -2067,6 +2100,12 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
                 over = true;
             }
         }
+    }
+    if (passes > 1 && __any(unpublished)) {                  // (nobody waits for the last pass; a wave that ends earlier owes its items)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (unpublished) atomicAdd(it.region_done + f2u(get(12)), 1u);
     }
 #ifdef PTMI_TAIL_STATS
     if (lane == 0) {     // diagnostic build: [8] first start, [10] last end, [12] sum of ends, [14] waves, [16] lanes-with-item x trips, [18] trips (all u64, s_memtime ticks)
@@ -3010,6 +3049,7 @@ hipError_t launch_streams_split(const RenderArgs &a, const ItemArgs &it, unsigne
 }
 
 int streams_pixels_waves() { return PTMI_PIXELS_WAVES; }
+int streams_publish_every() { return (int)kPublishEvery; }
 int streams_split_waves() { return PTMI_SPLIT_WAVES; }
 unsigned int streams_spill_records() { return kSpill; }
 unsigned int streams_first_block() { return kFirstBlock; }

@@ -173,3 +173,24 @@ def test_c5_glass_4k_512spp_one_part_of_8(pkg, ora, form):
         scale = np.maximum(np.abs(b), 1e-3 * spp)
         assert np.max(np.abs(a[pick] - b) / scale) <= 1e-4
     assert not np.array_equal(want[0], np.zeros_like(want[0]))
+
+
+def test_c2_stream_form_equals_the_per_pixel_kernel_at_full_size(pkg):
+    """render Streams on C2's image (1920x1080, 64 spp, S16) through the stream form -- start-hit regions, ticket queues, lanes
+    that refill, a pixel's samples as four ordered passes handed from lane to lane through the planes -- against the per-pixel
+    chain kernel (which the oracle pins at small sizes and by sample-split invariance): all seven planes bit for bit, five
+    launches in a row (8 million hand-offs each)."""
+    B = pkg.binding
+    sp, pl = pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    with pkg.Context(0) as chain, pkg.Context(0) as stream:
+        for c in (chain, stream):
+            c.set_scene(sp, pl)
+            c.resize(1920, 1080)
+            c.init_output(0x5EED1234)
+        stream.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+        for k in range(5):
+            chain.render(cam, 8, 64, pkg.STREAMS)
+            stream.render(cam, 8, 64, pkg.STREAMS)
+            assert_planes_equal(stream.download_state(), chain.download_state(), "C2 through the stream form, launch %d" % k)
+        assert stream.stats()["live_bounces"] == chain.stats()["live_bounces"]

@@ -147,3 +147,39 @@ def test_overflow_levels_with_tiny_rings(pkg, ora, tmp_path_factory):
         assert st["stream_rays_spilled"] > live // 50            # the tiny ring and spill queue really overflowed
         for a, b in zip(got[:3], want[:3]):
             assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) <= REL_TOL
+
+
+@pytest.mark.parametrize("rule", ["auto", "keep"])
+def test_ordered_passes_inside_one_launch_are_bit_exact(ctx, pkg, ora, rule):
+    """Without a ray-splitting material the stream form cuts a pixel's samples into ORDERED passes inside its one launch (a
+    pixel's seven words travel through the planes from the lane that rendered one pass to whichever lane takes the next; a pass
+    is handed out once the previous one has been published with an agent-scope release): here 64 samples as 4 items of 16 and as
+    2 of 32 (PTMI_OPT_STREAM_BATCH under the result's-seed rule, where a pixel's samples are one serial chain) -- bit-identical
+    to the oracle, both seed rules, image with and without whole tiles."""
+    B = pkg.binding
+    scene = pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    spp = 64
+    for w, h in ((200, 120), (61, 13)):
+        start = initial_planes(ora, w, h)
+        seed_rule = ora.SEED_KEEP_ACCUMULATOR if rule == "keep" else None
+        want, live = ora.render_streams(scene[0], scene[1], cam, w, h, CAP, spp, start, seed_rule=seed_rule)
+        for batch in (16, 32):
+            if rule == "keep" and batch:                         # (under the keep rule a batch selects the unordered split kernel instead)
+                os.environ["PTMI_ORDERED_PASSES"] = str(spp // batch)
+            try:
+                with pkg.Context(0) as c:
+                    c.set_scene(*scene)
+                    c.resize(w, h)
+                    c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+                    if rule == "keep":
+                        c.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_KEEP_ACCUMULATOR)
+                    else:
+                        c.set_option(B.OPT_STREAM_BATCH, batch)
+                    c.upload_state(*start)
+                    c.render(cam, 15, spp, pkg.STREAMS)
+                    got, st = c.download_state(), c.stats()
+            finally:
+                os.environ.pop("PTMI_ORDERED_PASSES", None)
+            assert_planes_equal(got, want, "ordered passes of %d samples, %dx%d, %s" % (batch, w, h, rule))
+            assert st["live_bounces"] == live
