@@ -27,7 +27,7 @@ _f32p, _u32p, _i32p, _i64p, _vp = (C.POINTER(C.c_float), C.POINTER(C.c_uint32), 
 class Stats(C.Structure):
     _fields_ = [("live_bounces", C.c_uint64), ("nominal_bounces", C.c_uint64), ("samples", C.c_uint64),
                 ("last_render_ms", C.c_float), ("stream_iterations", C.c_uint32), ("stream_rays_dropped", C.c_uint64),
-                ("stream_rays_truncated", C.c_uint64), ("stream_rays_spilled", C.c_uint64)]
+                ("stream_rays_truncated", C.c_uint64), ("stream_rays_spilled", C.c_uint64), ("stream_rays_overflowed", C.c_uint64)]
 
 
 SYMBOLS = {

@@ -94,6 +94,7 @@ struct ptmi_ctx {
     uint64_t rays_dropped = 0;
     uint64_t rays_truncated = 0;
     uint64_t rays_spilled = 0;       // stream form: children that found the wave's ring full and went through HBM
+    uint64_t rays_overflowed = 0;    // ... and its spill queue too: traced by an overflow level
     void *spill_block = nullptr;     // stream form: the waves' spill queues
     size_t spill_capacity = 0;
     uint64_t live_host = 0;        // live rays counted on the host (wavefront path)
@@ -433,6 +434,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
     // `null state` (Trace.hs:166-170): the loop goes on while the last level left children in its overflow stream (a level
     // cuts the rays the step cap forbids as it reads them, and counts them)
     for (int level = 0; c->has_glass && emitted_of(level) > 0u;) {
+        c->rays_overflowed += emitted_of(level);
         const size_t cursor = (size_t)raw[cursor_of(level)] + base[(size_t)(level % kLvMaxLevels)];
         const size_t items = cursor < capacity ? cursor : capacity;
         ++level;
@@ -1076,6 +1078,7 @@ int ptmi_get_stats(ptmi_ctx *c, ptmi_stats *out)
     out->stream_rays_dropped = c->rays_dropped + sc[kScDropped];
     out->stream_rays_truncated = c->rays_truncated + sc[kScTruncated];
     out->stream_rays_spilled = c->rays_spilled;
+    out->stream_rays_overflowed = c->rays_overflowed;
     out->last_render_ms = 0.0f;
     if (c->timing && c->ev_valid) PTMI_HIP(c, hipEventElapsedTime(&out->last_render_ms, c->ev0, c->ev1));
     return PTMI_OK;
@@ -1102,7 +1105,7 @@ int ptmi_reset_stats(ptmi_ctx *c)
     PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, kItersBytes, c->stream));
     PTMI_HIP(c, hipMemsetAsync(c->d_work, 0, 64 * sizeof(unsigned int), c->stream));
     PTMI_HIP(c, hipMemsetAsync(c->d_stream_counters, 0, kScWords * sizeof(unsigned long long), c->stream));
-    c->nominal = 0; c->samples = 0; c->rays_dropped = 0; c->rays_truncated = 0; c->rays_spilled = 0; c->live_host = 0;
+    c->nominal = 0; c->samples = 0; c->rays_dropped = 0; c->rays_truncated = 0; c->rays_spilled = 0; c->rays_overflowed = 0; c->live_host = 0;
     return PTMI_OK;
 }
 

@@ -407,7 +407,7 @@ int ptmi_group_get_stats(ptmi_group *g, ptmi_stats *out)
         out->last_render_ms = s.last_render_ms > out->last_render_ms ? s.last_render_ms : out->last_render_ms;
         out->stream_iterations = s.stream_iterations > out->stream_iterations ? s.stream_iterations : out->stream_iterations;
         out->stream_rays_dropped += s.stream_rays_dropped; out->stream_rays_truncated += s.stream_rays_truncated;
-        out->stream_rays_spilled += s.stream_rays_spilled;
+        out->stream_rays_spilled += s.stream_rays_spilled; out->stream_rays_overflowed += s.stream_rays_overflowed;
     }
     return PTMI_OK;
 }

@@ -15,10 +15,12 @@
 //     piece of work" -- is expanded once per trip: the sites that end a sample or a lineage only set a per-lane flag, and
 //     one block at the top of the next trip acts on it.  (Three inlined copies of such a block cost 3-9 % per kernel.)
 //   * no MFMA: the work is scalar-per-lane f32/f64 VALU with divergent control flow.
-// Kernels in this file: render_inline_kernel (+ pooled / persistent ablations), render_streams_kernel (Streams, one chain per
-// pixel), render_streams_tree_kernel (Streams with ray splitting, one tree per pixel), streams_primary_kernel +
-// streams_level_kernel (Streams as compacted streams, one launch per level), seed / create_with / present / stitch /
-// quad_order / point-query kernels.
+// Kernels in this file: render_inline_kernel, render_streams_kernel (Streams, one chain per pixel), render_streams_tree_kernel
+// (Streams with ray splitting, one tree per pixel), the stream ("wavefront") form of Streams -- streams_primary_kernel,
+// streams_pixels_kernel, streams_split_kernel, streams_level_kernel, streams_seeds_kernel, streams_advance_missed_kernel --,
+// seed / create_with / present / stitch / quad_order / point-query kernels; with -DPTMI_ABLATIONS also the pooled and persistent
+// forms of render Inline.  Compiled a second time with -DPTMI_CONTRACTED_BUILD (render Inline only, a * b + c fused: a
+// measurement mode, see the end of the file).
 #include "ptmi_kernels.h"
 
 namespace ptmi {
@@ -2143,9 +2145,13 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
 #endif
 constexpr unsigned int kRing = PTMI_RING;                     // records of a wave's child ring (a power of two, <= 64)
 #ifndef PTMI_SPILL
-#define PTMI_SPILL 256
+#define PTMI_SPILL 4096
 #endif
-constexpr unsigned int kSpill = PTMI_SPILL;                   // records of a wave's spill queue in HBM (a power of two)
+// records of a wave's spill queue in HBM (a power of two; 256 KB per wave, 1.6 GB for the 6 144 waves of a launch).  A wave that
+// works through the inside of a glass sphere emits up to 64 children per trip and places 30: with 256 records 0.03 % of the glass
+// scene's children went on to the overflow stream -- four more launches and read-backs per call, 8.76 ms; 1 024: 47 rays, 8.61;
+// 4 096: none, 8.49.
+constexpr unsigned int kSpill = PTMI_SPILL;
 #ifndef PTMI_ITEM_BATCH
 #define PTMI_ITEM_BATCH 1
 #endif

@@ -94,6 +94,7 @@ typedef struct ptmi_stats {
     uint64_t stream_rays_dropped;  /* Streams with ray splitting: children that found no room (next stream / lane stack full) */
     uint64_t stream_rays_truncated;/* Streams: rays still alive when PTMI_OPT_STREAM_STEP_CAP cut their lineage (the reference has no cap) */
     uint64_t stream_rays_spilled;  /* Streams, stream form: children that found their wave's ring in LDS full and travelled through HBM (nothing is lost) */
+    uint64_t stream_rays_overflowed; /* ... of which those that found the wave's spill queue full too and were traced by a later launch (an overflow level) */
 } ptmi_stats;
 
 typedef struct ptmi_ctx ptmi_ctx;
@@ -161,17 +162,21 @@ enum {
      * bound (notFinished never stops a non-empty stream, Trace.hs:166-170); the default, 65536, only guarantees
      * termination, for both forms.  Rays it cuts are counted in ptmi_stats.stream_rays_truncated. */
     PTMI_OPT_STREAM_STEP_CAP = 2,
-    /* Stream form only: how many rays per pixel-sample the child streams hold (default 4); children beyond are
-     * dropped and counted in ptmi_stats.stream_rays_dropped.  The reference's vectors grow as needed. */
+    /* Stream form only: how many rays per pixel the overflow streams hold (default 4); children beyond are dropped and
+     * counted in ptmi_stats.stream_rays_dropped.  (Children wait in their wave's ring in LDS, then in its spill queue; the
+     * overflow streams are the last resort and practically unused: ptmi_stats.stream_rays_overflowed.)  The reference's vectors
+     * grow as needed. */
     PTMI_OPT_STREAM_CAPACITY = 3,
     /* PTMI_FORM_AUTO (default): the per-pixel kernels (one lane walks its pixel's rays; with GLASS: its ray trees).
-     * PTMI_FORM_STREAM: rays travel through compacted streams in HBM, one traceStep launch per level ("wavefront"). */
+     * PTMI_FORM_STREAM: the stream ("wavefront") form -- the start hits of the pixels as a compacted list, persistent waves whose
+     * lanes take items from it by ballot + prefix, refraction children compacted into a ring per wave; ONE launch per call. */
     PTMI_OPT_STREAMS_FORM = 4,
-    /* Stream form only: how many samples of every pixel share one stream (one `awhile` loop).  0 (default) = automatic:
-     * ONE for scenes without GLASS, which keeps a pixel's additions in sample order (bit-identical to the per-pixel
-     * kernels), up to 32 -- memory permitting -- with GLASS, where the order is undefined anyway.  A value > 1 without
-     * GLASS trades that order for fewer, longer launches: colours then agree to rounding only (Accelerate's `permute`
-     * does not define the order either); the RNG planes stay exact. */
+    /* Stream form only: how many samples of a pixel make one item.  0 (default) = automatic: without GLASS a pixel's whole sample
+     * chain stays in one lane, in order (bit-identical to the per-pixel kernels; few long items are cut into ORDERED passes, still
+     * bit-identical); with GLASS, where the order of a pixel's additions is undefined anyway, items of a few dozen samples run in
+     * whatever lanes take them.  k > 0: items of k samples -- under PTMI_SEED_FROM_RESULT (a pixel's samples are one serial chain)
+     * as ordered passes, bit-identical; under PTMI_SEED_KEEP_ACCUMULATOR as unordered items: colours then agree to rounding only
+     * (Accelerate's `permute` does not define the order either); the RNG planes stay exact. */
     PTMI_OPT_STREAM_BATCH = 5,
     /* The per-pixel kernels of both algorithms, a scheduling knob that changes no result: a launch of few pixels and
      * many samples (one part of a multi-GPU image) is cut into this many chained copies of the tile grid, each rendering

@@ -65,7 +65,7 @@ def one(lib, names, width=1920, height=1080, spp=64, repeats=7):
                 c.render(cam, 8, spp, algorithm)
                 st = c.stats()
                 if st["stream_rays_spilled"] or st["stream_rays_dropped"]:
-                    out[name + "_spilled/dropped"] = [st["stream_rays_spilled"], st["stream_rays_dropped"]]
+                    out[name + "_spilled/overflowed/dropped"] = [st["stream_rays_spilled"], st["stream_rays_overflowed"], st["stream_rays_dropped"]]
     return out
 
 

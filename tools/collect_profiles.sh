@@ -1,7 +1,7 @@
 #!/bin/bash
 # collect_profiles.sh TAG -- after tools/profile_round.sh ran on the GPU box: summarise and copy into profiles/ (tracked).
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/gpurun_out/prof_$TAG
 cp "$SRC/bench.json" "$ROOT/profiles/${TAG}_bench.json"
@@ -29,5 +29,7 @@ cp "$SRC/c4_part.json" "$ROOT/profiles/${TAG}_c4_part.json"
 cp "$SRC/extra.json" "$ROOT/profiles/${TAG}_extra_measurements.json"
 cp "$SRC/phase_stats.json" "$ROOT/profiles/${TAG}_phase_stats.json"
 echo "profiles/${TAG}_* written"
+for f in split_stats tail_stats; do [ -s "$SRC/$f.json" ] && cp "$SRC/$f.json" "$ROOT/profiles/${TAG}_$f.json"; done
+[ -s "$SRC/contracted.json" ] && cp "$SRC/contracted.json" "$ROOT/profiles/${TAG}_contracted_arithmetic.json"
 for f in level_stats tree_stats; do [ -s "$SRC/$f.json" ] && cp "$SRC/$f.json" "$ROOT/profiles/${TAG}_$f.json"; done
 true

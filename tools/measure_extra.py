@@ -14,6 +14,7 @@ import __graft_entry__ as graft  # noqa: E402
 def main():
     pkg = graft.load_package()
     pkg._build.build_lib()
+    pkg.binding.load_library(pkg._build.build_ablations_lib())      # the variant table needs the ablation kernels (-DPTMI_ABLATIONS)
     sp, pl = pkg.world.scene16()
     cam = pkg.world.initial_camera()
     out = {}
@@ -66,15 +67,16 @@ def main():
             ctx.synchronize()
             return round((time.perf_counter() - t0) / n * 1e3, 3)
 
-        out["c2_streams_ms"] = streams_ms()
-        ctx.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_FROM_RESULT)
-        out["c2_streams_seed_from_result_ms"] = streams_ms()
+        out["c2_streams_ms"] = streams_ms()                                  # the default seed rule: the result's seed (PTMI_SEED_AUTO)
         ctx.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_KEEP_ACCUMULATOR)
+        out["c2_streams_keep_accumulator_ms"] = streams_ms()
         ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
-        out["c2_streams_stream_form_ms"] = streams_ms(3)
+        out["c2_streams_stream_form_keep_accumulator_ms"] = streams_ms(3)
         ctx.set_option(B.OPT_STREAM_BATCH, 16)
-        out["c2_streams_stream_form_batch16_ms"] = streams_ms(3)
+        out["c2_streams_stream_form_unordered_items_of_16_ms"] = streams_ms(3)   # the split kernel on a scene without GLASS
         ctx.set_option(B.OPT_STREAM_BATCH, 0)
+        ctx.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_AUTO)
+        out["c2_streams_stream_form_ms"] = streams_ms(3)
         ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_AUTO)
         # --- the glass scene (GLASS extension), 1080p / 64 spp: tree walk (default) and stream form
         ctx.set_scene(*pkg.world.glass_scene())

@@ -14,7 +14,7 @@ import __graft_entry__ as graft  # noqa: E402
 def main():
     pkg = graft.load_package()
     out = "/tmp/libptmi_phase_stats.so"
-    pkg._build.build_lib(out=out, extra_flags=["-DPTMI_PHASE_STATS"])
+    pkg._build.build_lib(out=out, extra_flags=["-DPTMI_PHASE_STATS", "-DPTMI_ABLATIONS"])
     pkg.binding._lib = None
     pkg.binding.load_library(out)
     sp, pl = pkg.world.scene16()
@@ -40,7 +40,7 @@ def main():
     print(json.dumps({"wave_cycle_share": {"round_A": cyc[0] / sum(cyc), "round_B": cyc[1] / sum(cyc), "round_C_trace": cyc[2] / sum(cyc)}}))
     # second diagnostic build: per-sphere statistics (many atomics: never combined with the cycle stamps)
     out2 = "/tmp/libptmi_sphere_stats.so"
-    pkg._build.build_lib(out=out2, extra_flags=["-DPTMI_SPHERE_STATS"])
+    pkg._build.build_lib(out=out2, extra_flags=["-DPTMI_SPHERE_STATS", "-DPTMI_ABLATIONS"])
     pkg.binding._lib = None
     pkg.binding.load_library(out2)
     with pkg.Context(0) as ctx:

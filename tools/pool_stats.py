@@ -13,7 +13,7 @@ import __graft_entry__ as graft  # noqa: E402
 def main():
     pkg = graft.load_package()
     out = "/tmp/libptmi_pool_stats.so"
-    pkg._build.build_lib(out=out, extra_flags=["-DPTMI_POOL_STATS"])
+    pkg._build.build_lib(out=out, extra_flags=["-DPTMI_ABLATIONS", "-DPTMI_POOL_STATS"])
     pkg.binding._lib = None
     pkg.binding.load_library(out)
     sp, pl = pkg.world.scene16()

@@ -1,10 +1,10 @@
 #!/bin/bash
 # profile_round.sh -- the measurement pass behind profiles/<tag>_* (run ON the GPU box, from the repo root):
-#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/profile_round.sh r02'
-# then, back in the container:  bash tools/collect_profiles.sh r02   (copies the summaries into profiles/).
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/profile_round.sh r03'
+# then, back in the container:  bash tools/collect_profiles.sh r03   (copies the summaries into profiles/).
 # Counters are collected in their own passes (rocprofv3 --pmc with --kernel-trace only), the program itself after `--`.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -33,4 +33,8 @@ if [ -x build/valu_rates ]; then timeout -k 10 600 build/valu_rates 1 2 6 8 > "$
 timeout -k 10 400 python3 tools/c4_part.py > "$OUT/c4_part.json" 2> "$OUT/c4_part.log"; echo "c4_part rc=$?"
 timeout -k 10 400 python3 tools/measure_extra.py > "$OUT/extra.json" 2> "$OUT/extra.log"; echo "extra rc=$?"
 timeout -k 10 300 python3 tools/phase_stats.py > "$OUT/phase_stats.json" 2> "$OUT/phase_stats.log"; echo "phase rc=$?"
+# 5. the stream form: lane participation per block of the split kernel, the end of the pixels kernel's launch; the contracted-arithmetic report
+timeout -k 10 300 python3 tools/split_stats.py > "$OUT/split_stats.json" 2> "$OUT/split_stats.log"; echo "split stats rc=$?"
+timeout -k 10 300 python3 tools/tail_stats.py > "$OUT/tail_stats.json" 2> "$OUT/tail_stats.log"; echo "tail stats rc=$?"
+timeout -k 10 300 python3 tools/contracted_report.py > "$OUT/contracted.json" 2> "$OUT/contracted.log"; echo "contracted rc=$?"
 echo "all done: $OUT"
