@@ -14,7 +14,7 @@ for w in c2 streams glass_tree glass_stream s16_stream; do
     cp "$ROOT"/gpurun_out/pmc_$w/stats/*/*_kernel_stats.csv "$ROOT/profiles/${TAG}_kernel_stats_$w.csv"
 done
 cp "$SRC/valu_rates.json" "$ROOT/profiles/${TAG}_valu_rates.json"
-python3 "$ROOT/tools/valu_roofline.py" "$ROOT/profiles/${TAG}_pmc_c2.json" "$ROOT/profiles/${TAG}_valu_rates.json" "$TAG" > /dev/null
+PTMI_PROFILE_SOURCE_HASH=$(cat "$SRC/source_hash.txt" 2>/dev/null) python3 "$ROOT/tools/valu_roofline.py" "$ROOT/profiles/${TAG}_pmc_c2.json" "$ROOT/profiles/${TAG}_valu_rates.json" "$TAG" > /dev/null
 python3 - "$ROOT" "$TAG" <<'PY'
 import json, sys
 root, tag = sys.argv[1], sys.argv[2]
@@ -31,5 +31,5 @@ cp "$SRC/phase_stats.json" "$ROOT/profiles/${TAG}_phase_stats.json"
 echo "profiles/${TAG}_* written"
 for f in split_stats tail_stats; do [ -s "$SRC/$f.json" ] && cp "$SRC/$f.json" "$ROOT/profiles/${TAG}_$f.json"; done
 [ -s "$SRC/contracted.json" ] && cp "$SRC/contracted.json" "$ROOT/profiles/${TAG}_contracted_arithmetic.json"
-for f in level_stats tree_stats; do [ -s "$SRC/$f.json" ] && cp "$SRC/$f.json" "$ROOT/profiles/${TAG}_$f.json"; done
+for f in tree_stats; do [ -s "$SRC/$f.json" ] && cp "$SRC/$f.json" "$ROOT/profiles/${TAG}_$f.json"; done
 true

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """tail_stats.py [s16|glass] -- how much of a stream-form launch its end costs (diagnostic build -DPTMI_TAIL_STATS of the
 pixels kernel): every persistent wave stamps its start and end (s_memtime), counts its loop trips and the lanes that held an
-item in each.  Prints what share of the wave-time of the launch lies after waves have ended (the drain), and the mean
-number of lanes with an item per trip."""
+item in each.  Prints the waves' mean duration against the longest (all waves of the persistent grid start together, so what the mean
+lacks to the longest is wave-time after waves have ended), their histogram, and the mean number of lanes with an item per trip."""
 import json
 import os
 import sys
@@ -41,10 +41,9 @@ def main():
             ms = c.stats()["last_render_ms"]
             w = c.debug_counters()
             u64 = lambda i: int(w[i]) | (int(w[i + 1]) << 32)    # noqa: E731
-            first, last, total, waves, lane_trips, trips, longest = (~u64(8)) & (2 ** 64 - 1), u64(10), u64(12), u64(14), u64(16), u64(18), u64(20)
-            span = last - first
-            out["spp_%d" % spp] = {"render_ms": round(ms, 3), "waves": waves, "span_ticks": span, "mean_wave_ticks": round(total / max(waves, 1)),
-                                   "longest_wave_ticks": longest, "drain_share_of_wave_time": round(1.0 - total / (waves * span), 4) if waves and span else None,
+            total, waves, lane_trips, trips, longest = u64(12), u64(14), u64(16), u64(18), u64(20)
+            out["spp_%d" % spp] = {"render_ms": round(ms, 3), "waves": waves, "mean_wave_cycles": round(total / max(waves, 1)),
+                                   "longest_wave_cycles": longest, "mean_over_longest": round(total / max(waves, 1) / max(longest, 1), 4),
                                    "lanes_with_an_item_per_trip": round(lane_trips / max(trips, 1), 2), "trips_per_wave": round(trips / max(waves, 1), 1),
                                    "waves_by_duration_bins_of_2^19_cycles": [int(x) for x in w[24:64]]}
     print(json.dumps(out, indent=1))

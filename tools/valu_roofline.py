@@ -63,7 +63,8 @@ def main():
         "frac_in_profile": round(nominal / measured_cycles, 4),
         "frac_with_v_fma_f32_at_2_cycles": round(fma2 / measured_cycles, 4),
         "frac_with_v_fma_f32_as_measured": round(fma36 / measured_cycles, 4), "v_fma_f32_cycles_measured": ops8["v_fma_f32"]["cycles"],
-        "source_hash": graft.load_package()._build.source_hash(),
+        # of the sources the PROFILED binary was built from (tools/profile_round.sh records it on the GPU box)
+        "source_hash": os.environ.get("PTMI_PROFILE_SOURCE_HASH") or graft.load_package()._build.source_hash(),
         "avg_issue_cycles_per_instr": round(nominal / total, 4),
         "measured_simd_cycles_per_instr": round(measured_cycles / total, 4),
         "priced_with_measured_rates": {"issue_cycles": measured_price, "frac": round(measured_price / measured_cycles, 4),
