@@ -184,3 +184,40 @@ def test_ordered_passes_inside_one_launch_are_bit_exact(ctx, pkg, ora, rule):
                 os.environ.pop("PTMI_ORDERED_PASSES", None)
             assert_planes_equal(got, want, "ordered passes of %d samples, %dx%d, %s" % (batch, w, h, rule))
             assert st["live_bounces"] == live
+
+
+def test_stream_form_with_a_scene_too_big_for_lds(ctx, pkg, ora):
+    """A scene of 300 primitives (a third of them GLASS) is read through scalar loads instead of LDS in every kernel of the stream
+    form (primary, split, overflow levels); same bar as for the small glass scene: counts and RNG planes exact, colours to 1e-4."""
+    B = pkg.binding
+    r = np.random.default_rng(300)
+    wd = pkg.world
+    n = 298
+    spheres = np.zeros(n, wd.SPHERE_DTYPE)
+    spheres["position"] = r.uniform(-25, 25, (n, 3)) + np.array([0, 3, -25])
+    spheres["radius"] = r.uniform(0.3, 2.0, n)
+    spheres["color"] = r.uniform(0.2, 1, (n, 3))
+    spheres["illuminance"] = np.where(r.random(n) < 0.1, 20.0, 0.0)
+    spheres["brdf_tag"] = np.where(r.random(n) < 0.33, wd.GLASS, wd.GLOSSY)
+    spheres["brdf_param"] = np.where(spheres["brdf_tag"] == wd.GLASS, 1.5, r.uniform(0.2, 1.0, n))
+    _, planes = wd.main_scene()
+    planes = planes.copy()
+    planes["brdf_tag"] = wd.GLOSSY                             # non-negative contributions only: a relative tolerance needs them
+    planes["brdf_param"] = 0.7
+    cam = wd.initial_camera()
+    w, h, spp, cap = 144, 80, 3, 12
+    start = initial_planes(ora, w, h)
+    want, live, dropped, steps, cut = ora.render_streams_wavefront(spheres, planes, cam, w, h, cap, spp, start, capacity_factor=64, want_truncated=True)
+    assert dropped == 0
+    ctx.set_option(B.OPT_STREAM_STEP_CAP, cap)
+    ctx.set_option(B.OPT_STREAM_CAPACITY, 64)
+    try:
+        got, st = render(ctx, pkg, (spheres, planes), cam, w, h, spp, start, stream_form=True)
+    finally:
+        ctx.set_option(B.OPT_STREAM_STEP_CAP, 1 << 16)
+        ctx.set_option(B.OPT_STREAM_CAPACITY, 4)
+    for a, b in zip(got[3:], want[3:]):
+        assert np.array_equal(a, b)
+    assert st["live_bounces"] == live and st["stream_rays_dropped"] == 0 and st["stream_rays_truncated"] == cut
+    for a, b in zip(got[:3], want[:3]):
+        assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3 + 1e-4 * np.max(np.abs(b)))) <= REL_TOL
