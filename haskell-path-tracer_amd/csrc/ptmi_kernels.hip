@@ -1432,13 +1432,19 @@ __device__ __forceinline__ void glass_children(V3 color, float ior, V3 p, V3 n, 
 // that are glass themselves -- takes the general path.  (With a step cap below 3 the children could be cut: no caching.)
 // ---------------------------------------------------------------------------------------
 #ifndef PTMI_TREE_WAVES
-#define PTMI_TREE_WAVES 5
+#define PTMI_TREE_WAVES 6        // 80 VGPRs (three values spilled around the shade) and a start record of 2 x 10 words: 8.39 -> 7.96 ms on the glass scene
 #endif
 template <bool LDS_SCENE, int TILE_W = 0>
 __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_tree_kernel(const RenderArgs a)
 {
-    // two start hits per lane: position (3), incoming direction (3), throughput (3), primitive, steps | draws << 8
-    __shared__ uint32_t start_rec[22][kRenderBlock];
+    // two start hits per lane: position (3), incoming direction (3), throughput (3), primitive | steps << 16 | draws << 24
+    // (The start hits' normals are recomputed at every sample start -- normal_at, the second half of hit_record.  Kept in LDS they save
+    // 2.4 % at 5 waves per SIMD (8.39 -> 8.19 ms), but six waves' columns then no longer fit a CU, and the sixth wave is worth 5 %.)
+#ifndef PTMI_TREE_NORMAL_LDS
+#define PTMI_TREE_NORMAL_LDS 0
+#endif
+    constexpr int kEntry = PTMI_TREE_NORMAL_LDS ? 13 : 10;   // words per start hit
+    __shared__ uint32_t start_rec[2 * kEntry][kRenderBlock];
 
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
@@ -1474,12 +1480,13 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
             for (int s = 0; s < n_spp; ++s) (void)random_float(pixel_seed);     // updateSeed only
         } else {
             uint32_t *rec = &start_rec[0][threadIdx.x];
-            auto put_entry = [&](int e, V3 p, V3 dir, V3 t, int prim, unsigned int steps_done, unsigned int draws) {
-                uint32_t *q = rec + (size_t)e * 11 * kRenderBlock;
+            auto put_entry = [&](int e, V3 p, V3 nrm, V3 dir, V3 t, int prim, unsigned int steps_done, unsigned int draws) {
+                uint32_t *q = rec + (size_t)e * kEntry * kRenderBlock;
                 q[0] = f2u(p.x); q[kRenderBlock] = f2u(p.y); q[2 * kRenderBlock] = f2u(p.z);
                 q[3 * kRenderBlock] = f2u(dir.x); q[4 * kRenderBlock] = f2u(dir.y); q[5 * kRenderBlock] = f2u(dir.z);
                 q[6 * kRenderBlock] = f2u(t.x); q[7 * kRenderBlock] = f2u(t.y); q[8 * kRenderBlock] = f2u(t.z);
-                q[9 * kRenderBlock] = (uint32_t)prim; q[10 * kRenderBlock] = steps_done | (draws << 8);
+                q[9 * kRenderBlock] = (uint32_t)prim | (steps_done << 16) | (draws << 24);
+                if (PTMI_TREE_NORMAL_LDS) { q[10 * kRenderBlock] = f2u(nrm.x); q[11 * kRenderBlock] = f2u(nrm.y); q[12 * kRenderBlock] = f2u(nrm.z); }
             };
             V3 pos, normal;                                       // pos: the hit to shade, then the next ray's origin
             hit_record(S, ns, h0.idx, origin, primary, h0.t, pos, normal);
@@ -1503,11 +1510,11 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                         V3 hp, hn;
                         hit_record(S, ns, h.idx, ro, rd, h.t, hp, hn);
                         if (n_entries == 0) first_is_reflection = k == 0;
-                        put_entry(n_entries++, hp, rd, rt, h.idx, 1u, 3u + (unsigned int)k);
+                        put_entry(n_entries++, hp, hn, rd, rt, h.idx, 1u, 3u + (unsigned int)k);
                     }
                 }
             } else {
-                put_entry(0, pos, primary, mk(1.0f, 1.0f, 1.0f), h0.idx, 0u, 0u);
+                put_entry(0, pos, normal, primary, mk(1.0f, 1.0f, 1.0f), h0.idx, 0u, 0u);
                 n_entries = 1;
             }
             // children waiting for this lane: origin, direction, throughput, seed, step index (RayState, Trace.hs:45); scratch
@@ -1535,15 +1542,15 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
             auto next_start = [&]() {
                 for (;;) {
                     if (entry_i < n_entries) {
-                        const uint32_t *q = rec + (size_t)entry_i * 11 * kRenderBlock;
+                        const uint32_t *q = rec + (size_t)entry_i * kEntry * kRenderBlock;
                         pos = mk(u2f(q[0]), u2f(q[kRenderBlock]), u2f(q[2 * kRenderBlock]));
                         d = mk(u2f(q[3 * kRenderBlock]), u2f(q[4 * kRenderBlock]), u2f(q[5 * kRenderBlock]));
                         throughput = mk(u2f(q[6 * kRenderBlock]), u2f(q[7 * kRenderBlock]), u2f(q[8 * kRenderBlock]));
-                        idx = (int)q[9 * kRenderBlock];
-                        const uint32_t meta = q[10 * kRenderBlock];
+                        idx = (int)(q[9 * kRenderBlock] & 0xffffu);
+                        const uint32_t meta = q[9 * kRenderBlock] >> 16;
                         ++entry_i;
                         steps = meta & 0xffu;
-                        normal = normal_at(S, ns, idx, pos);
+                        normal = PTMI_TREE_NORMAL_LDS ? mk(u2f(q[10 * kRenderBlock]), u2f(q[11 * kRenderBlock]), u2f(q[12 * kRenderBlock])) : normal_at(S, ns, idx, pos);
                         seed = pixel_seed;
                         for (uint32_t k = 0; k < (meta >> 8); ++k) (void)sfc32_next(seed);     // the draws its ray's ancestors made
                         pending = true; has_ray = false;
@@ -1938,7 +1945,7 @@ __device__ __forceinline__ void record_item_cost(const RenderArgs &a, unsigned i
 #define PTMI_PIXELS_WAVES 7
 #endif
 constexpr unsigned int kPublishEvery = 16;                   // the fewest samples an ordered pass may hold (ItemArgs.publish_every: trips between a wave's releases)
-template <bool LDS_SCENE>
+template <bool LDS_SCENE, bool PASSES>
 __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixels_kernel(const RenderArgs a, const ItemArgs it)
 {
     // the lane's item: 0-2 position of the start hit, 3-5 axis and 6 half-angle scale of its bounce, 7 primitive, 8 quad,
@@ -1966,7 +1973,9 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
     // publishes in batches, every it.publish_every trips -- at most as many as a pass has samples, since a lane must publish an
     // item before it ends its next one, which is why short passes cannot pay -- or at once when it has nothing else to do.
     // Nothing here depends on which XCD or CU a wave runs on.
-    const int passes = it.passes;
+    // (PASSES is a template parameter: carried as run-time branches the blocks below cost the one-pass kernel 3.8 % -- 4.57 -> 4.75 ms on
+    // S16 -- in scalar registers spilled and instructions per trip)
+    const int passes = PASSES ? it.passes : 1;
     const unsigned int publish_mask = (unsigned int)it.publish_every - 1u;
     float *mine = &item_const[0][threadIdx.x];
     auto put = [&](int k, float v) { mine[k * kRenderBlock] = v; };
@@ -3033,8 +3042,13 @@ hipError_t launch_streams_pixels(const RenderArgs &a, const ItemArgs &it, unsign
     if (grid == 0) return hipSuccess;
     const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
     const dim3 g(grid), b(kRenderBlock);
-    if (lds > kMaxSceneLds) hipLaunchKernelGGL((streams_pixels_kernel<false>), g, b, 0, stream, a, it);
-    else                    hipLaunchKernelGGL((streams_pixels_kernel<true>), g, b, lds, stream, a, it);
+    if (it.passes > 1) {
+        if (lds > kMaxSceneLds) hipLaunchKernelGGL((streams_pixels_kernel<false, true>), g, b, 0, stream, a, it);
+        else                    hipLaunchKernelGGL((streams_pixels_kernel<true, true>), g, b, lds, stream, a, it);
+    } else {
+        if (lds > kMaxSceneLds) hipLaunchKernelGGL((streams_pixels_kernel<false, false>), g, b, 0, stream, a, it);
+        else                    hipLaunchKernelGGL((streams_pixels_kernel<true, false>), g, b, lds, stream, a, it);
+    }
     return hipGetLastError();
 }
 

@@ -24,8 +24,9 @@ BUDGETS = {
     "render_inline_kernel<false, 0, 8>": (72, 32, 2560, 6, 6),         # scene through scalar loads (big scenes)
     "render_streams_kernel<true, 8>": (72, 32, 2816, 3, 3),            # 7 waves/SIMD
     "render_streams_kernel<false, 8>": (72, 32, 2816, 3, 3),
-    "render_streams_tree_kernel<true, 8>": (96, 12 * 14 * 4 + 16, 5632, 6, 6),   # 5 waves/SIMD; waiting children: the first 4 per lane as global 64-byte records, the rest in scratch (12 entries x 14 words)
-    "streams_pixels_kernel<true>": (72, 0, 3584, 0, 0),                # stream form, rays never split: 7 waves/SIMD, nothing in scratch
+    "render_streams_tree_kernel<true, 8>": (80, 12 * 14 * 4 + 64, 5120, 8, 12),   # 6 waves/SIMD; waiting children: the first 4 per lane as global 64-byte records, the rest in scratch (12 entries x 14 words); three values spilled around the shade
+    "streams_pixels_kernel<true, false>": (72, 0, 3584, 0, 0),         # stream form, rays never split: 7 waves/SIMD, nothing in scratch
+    "streams_pixels_kernel<true, true>": (72, 0, 3584, 0, 0),          # ... with ordered passes
     "streams_split_kernel<true, true>": (80, 0, 5568, 0, 0),           # stream form with the child ring: 6 waves/SIMD (registers and LDS), nothing in scratch
     "streams_level_kernel<true>": (80, 0, 0, 0, 0),                    # overflow levels: 6 waves/SIMD
 }
