@@ -130,7 +130,6 @@ struct ItemArgs {
     unsigned int n_positions;       // groups of four regions (dispatch positions): hits.n_regions / 4
     int passes;                     // tickets run over the chunks this many times: a pixel's samples in that many items
     unsigned int *region_done;      // streams_pixels_kernel, passes > 1: per region, the items published so far (zero at launch)
-    int publish_every;              // ... and the trips between a wave's releases: a power of two, at most the samples of a pass
     unsigned int *chunk_cursor;     // device: the launch's eight ticket counters, kCounterStride words apart, zero at launch
     // streams_split_kernel only
     int samples_per_pass;           // a pixel's samples are cut into `passes` items of this many samples (the last one shorter)
@@ -148,7 +147,7 @@ struct ItemArgs {
 hipError_t launch_streams_pixels(const RenderArgs &a, const ItemArgs &it, unsigned int grid, hipStream_t stream);
 hipError_t launch_streams_split(const RenderArgs &a, const ItemArgs &it, unsigned int grid, hipStream_t stream);
 int streams_pixels_waves();
-int streams_publish_every();         // ordered passes: a pass must hold at least this many samples           // waves per SIMD the item kernels are built for (persistent grids)
+int streams_min_pass_samples();      // ordered passes: a pass must hold at least this many samples           // waves per SIMD the item kernels are built for (persistent grids)
 int streams_split_waves();
 unsigned int streams_spill_records();   // records of a wave's spill queue in HBM
 unsigned int streams_regions(int width, int rows_local);    // regions of the start-hit list

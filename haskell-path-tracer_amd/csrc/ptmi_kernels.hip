@@ -1764,6 +1764,11 @@ template <typename T> __device__ __forceinline__ T &plane_at(T *base, uint32_t b
 {
     return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off);
 }
+// agent-scope relaxed accesses (global_load / global_store ... sc1): the load passes the CU's L1 by, the store is written through
+__device__ __forceinline__ float load_agent(const float *p) { return u2f(__hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ uint32_t load_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_agent(float *p, float v) { __hip_atomic_store(reinterpret_cast<uint32_t *>(p), f2u(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // The start-hit list.  One workgroup = one quad of four x-adjacent 8x8 tiles (TILES) or 256 consecutive pixels, one wave
 // = one region.  Dispatch position p works on quad quad_order[p] (most expensive first, once costs are known), and its
@@ -1944,14 +1949,13 @@ __device__ __forceinline__ void record_item_cost(const RenderArgs &a, unsigned i
 #ifndef PTMI_PIXELS_WAVES
 #define PTMI_PIXELS_WAVES 7
 #endif
-constexpr unsigned int kPublishEvery = 16;                   // the fewest samples an ordered pass may hold (ItemArgs.publish_every: trips between a wave's releases)
+constexpr int kMinPassSamples = 1;                           // the fewest samples an ordered pass may hold (a lane publishes an item before it takes the next)
 template <bool LDS_SCENE, bool PASSES>
 __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixels_kernel(const RenderArgs a, const ItemArgs it)
 {
     // the lane's item: 0-2 position of the start hit, 3-5 axis and 6 half-angle scale of its bounce, 7 primitive, 8 quad,
-    // 9 the lane's count of shaded hits when the item began, 10 the samples the item renders, 11 its region, 12 the region of
-    // the item the lane has stored but not yet published
-    __shared__ float item_const[13][kRenderBlock];
+    // 9 the lane's count of shaded hits when the item began, 10 the samples the item renders, 11 its region
+    __shared__ float item_const[12][kRenderBlock];
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -1965,18 +1969,20 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
     const unsigned int step_cap = (unsigned int)a.stream_step_cap;
     // ORDERED PASSES (it.passes > 1).  A pixel's samples are a serial chain, and with few items per lane the end of the launch is as
     // long as the last items.  The samples are therefore cut into passes: an item renders one pass's samples of its pixel, and the
-    // pixel's seven words travel through the planes to whichever lane takes its next pass.  What orders them: an item of pass p is
-    // handed out only when region_done[its region] says that every item of the region's pass p - 1 has been PUBLISHED --
-    // stored, then made visible by an agent-scope release -- and the taking wave has acquired at agent scope.  A release is a
-    // write-back of the XCD's whole L2 and the L2 serves them one after the other: 7 168 waves releasing every 16 trips
-    // (112 write-backs per microsecond on the chip) DOUBLED the launch (1080p / 64 spp as four passes: 4.5 -> 9.4 ms).  So a wave
-    // publishes in batches, every it.publish_every trips -- at most as many as a pass has samples, since a lane must publish an
-    // item before it ends its next one, which is why short passes cannot pay -- or at once when it has nothing else to do.
+    // pixel's seven words travel through the planes to whichever lane -- of any wave, on any XCD -- takes its next pass.  What orders
+    // them: an item of pass p is handed out only when region_done[its region] says that every item of the region's pass p - 1 has
+    // been PUBLISHED.  The L2s of the eight XCDs are not coherent with each other and a CU's L1 is never refreshed, so the seven
+    // words are stored WRITE-THROUGH (sc1: agent-scope relaxed atomic stores), the storing wave waits for its stores (vmcnt(0))
+    // before its lanes add to the region's counter (agent-scope atomics), and the taking lanes read counter and words with sc1
+    // loads, which pass the L1 by and are served coherently (MI355X_MICROARCH.md, "Valid forms": every store of the handed-off bytes
+    // sc1 and drained before the counter moves, every load of them sc1; the loads come after the poll of the same wave).  No fence:
+    // an agent-scope release is a write-back of the XCD's whole L2, and the L2 serves them one after the other -- 7 168 waves
+    // releasing every 16 trips (112 write-backs per microsecond on the chip) DOUBLED the launch (1080p / 64 spp as four passes:
+    // 4.5 -> 9.4 ms), and releasing in batches of up to 256 trips still cost more than short passes gained.
     // Nothing here depends on which XCD or CU a wave runs on.
     // (PASSES is a template parameter: carried as run-time branches the blocks below cost the one-pass kernel 3.8 % -- 4.57 -> 4.75 ms on
     // S16 -- in scalar registers spilled and instructions per trip)
     const int passes = PASSES ? it.passes : 1;
-    const unsigned int publish_mask = (unsigned int)it.publish_every - 1u;
     float *mine = &item_const[0][threadIdx.x];
     auto put = [&](int k, float v) { mine[k * kRenderBlock] = v; };
     auto get = [&](int k) { return mine[k * kRenderBlock]; };
@@ -1990,10 +1996,10 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
 #ifdef PTMI_TAIL_STATS
     const unsigned long long t_start = __builtin_readcyclecounter();
     unsigned long long lane_trips = 0, wave_trips = 0;        // lanes with an item, summed over the trips / trips
+    unsigned long long ph_refill = 0, ph_over = 0, ph_refills = 0, ph_ends = 0, ph_taken = 0, ph_t = 0;   // (-DPTMI_TAIL_PHASES) cycles in the refill block / in the sample-end block of trips that end an item
 #endif
 
     bool busy = false, pending = false, has_ray = false, over = false, unpublished = false;
-    unsigned int trip = 0;
     V3 acc = mk(0.0f, 0.0f, 0.0f), pos = acc, normal = acc, d = acc, throughput = acc;
     Sfc32 pixel_seed; pixel_seed.a = pixel_seed.b = pixel_seed.c = pixel_seed.counter = 0;
     Sfc32 seed = pixel_seed;
@@ -2001,23 +2007,24 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
     uint32_t pixel4 = 0;                                      // byte offset of the lane's pixel in a plane
     unsigned int steps = 0, longest = 0, live = 0;
     for (;;) {
-        // ---- publish (ordered passes): the items this wave has stored since its last release
-        if (passes > 1 && __any(unpublished) && ((++trip & publish_mask) == 0u || !__any(busy))) {     // wave-uniform
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the write-back has completed before the counters move
-            if (unpublished) { atomicAdd(it.region_done + f2u(get(12)), 1u); unpublished = false; }
+        // ---- publish (ordered passes): the items whose words this wave stored in its last trip (a trip ago: the wait is free)
+        if (PASSES && __any(unpublished)) {                   // wave-uniform
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the write-through stores have completed before the counters move
+            if (unpublished) { atomicAdd(it.region_done + f2u(get(11)), 1u); unpublished = false; }
         }
         // ---- refill: idle lanes take the next start hits of the wave's chunk (at once: an item is a pixel's whole sample chain)
         const unsigned long long idle = __ballot(!busy);
         bool open = idle && chunks_left(cur);
-        if (open && cur.pass > 0u && !cur.ready) {           // wave-uniform: has the region's previous pass been published?
+        if (PASSES && open && cur.pass > 0u && !cur.ready) {           // wave-uniform: has the region's previous pass been published?
             unsigned int done = 0;
             if (lane == 0) done = __hip_atomic_load(it.region_done + cur.region, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             done = (unsigned int)__builtin_amdgcn_readfirstlane((int)done);
-            if (done >= cur.pass * cur.len) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); cur.ready = true; }
+            if (done >= cur.pass * cur.len) cur.ready = true;
             else { open = false; if (!__any(busy)) __builtin_amdgcn_s_sleep(8); }
         }
+#ifdef PTMI_TAIL_STATS
+        if (open) { ph_t = __builtin_readcyclecounter(); ++ph_refills; }
+#endif
         if (open) {                                           // wave-uniform
             const unsigned int want = (unsigned int)__builtin_popcountll(idle), avail = cur.len - cur.taken;
             const unsigned int take = want < avail ? want : avail;
@@ -2031,13 +2038,23 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
                 put(7, r3.x); put(8, r3.w); put(9, u2f(live));
                 // the samples of this pass: n_spp over the passes, the first (n_spp mod passes) passes one more
                 put(10, u2f((uint32_t)(a.n_spp / passes + ((int)cur.pass < a.n_spp % passes ? 1 : 0)))); put(11, u2f(cur.region));
-                acc = mk(plane_at(a.planes.r, pixel4), plane_at(a.planes.g, pixel4), plane_at(a.planes.b, pixel4));
-                pixel_seed.a = plane_at(a.planes.sa, pixel4); pixel_seed.b = plane_at(a.planes.sb, pixel4);
-                pixel_seed.c = plane_at(a.planes.sc, pixel4); pixel_seed.counter = plane_at(a.planes.sctr, pixel4);
+                if (PASSES) {                                  // another wave's stores of a moment ago: sc1 loads
+                    acc = mk(load_agent(&plane_at(a.planes.r, pixel4)), load_agent(&plane_at(a.planes.g, pixel4)), load_agent(&plane_at(a.planes.b, pixel4)));
+                    pixel_seed.a = load_agent(&plane_at(a.planes.sa, pixel4)); pixel_seed.b = load_agent(&plane_at(a.planes.sb, pixel4));
+                    pixel_seed.c = load_agent(&plane_at(a.planes.sc, pixel4)); pixel_seed.counter = load_agent(&plane_at(a.planes.sctr, pixel4));
+                } else {
+                    acc = mk(plane_at(a.planes.r, pixel4), plane_at(a.planes.g, pixel4), plane_at(a.planes.b, pixel4));
+                    pixel_seed.a = plane_at(a.planes.sa, pixel4); pixel_seed.b = plane_at(a.planes.sb, pixel4);
+                    pixel_seed.c = plane_at(a.planes.sc, pixel4); pixel_seed.counter = plane_at(a.planes.sctr, pixel4);
+                }
                 s = -1; busy = true; over = true; pending = false; has_ray = false;
             }
             cur.taken += take;
             if (cur.taken >= cur.len) next_chunk(cur, it);
+#ifdef PTMI_TAIL_STATS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ph_taken += take; ph_refill += __builtin_readcyclecounter() - ph_t;
+#endif
         }
         if (!__any(busy) && !chunks_left(cur)) break;      // (no lane busy, chunks left: nothing below has a lane to run for; the next trip refills)
 #ifdef PTMI_TAIL_STATS
@@ -2058,6 +2075,10 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
                 bounce_axis(mb, normal, d, axis, hk);
             }
         }
+#ifdef PTMI_TAIL_STATS
+        const bool ph_ending = __any(over && s + 1 >= (int)f2u(get(10)));
+        if (ph_ending) { ph_t = __builtin_readcyclecounter(); ++ph_ends; }
+#endif
         if (over) {
             if (s >= 0) {                                      // a sample has been rendered
                 if (a.seed_from_result && steps > 0u) {        // combine new old: the seed the sample's last hit carried
@@ -2076,14 +2097,23 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
                 axis = mk(get(3), get(4), get(5)); hk = get(6);
                 pending = true;
             } else {                                           // the pixel is done: its seven words, once
-                plane_at(a.planes.r, pixel4) = acc.x; plane_at(a.planes.g, pixel4) = acc.y; plane_at(a.planes.b, pixel4) = acc.z;
-                plane_at(a.planes.sa, pixel4) = pixel_seed.a; plane_at(a.planes.sb, pixel4) = pixel_seed.b;
-                plane_at(a.planes.sc, pixel4) = pixel_seed.c; plane_at(a.planes.sctr, pixel4) = pixel_seed.counter;
+                if (PASSES) {                                  // write-through: the pixel's next pass may run behind another L2
+                    store_agent(&plane_at(a.planes.r, pixel4), acc.x); store_agent(&plane_at(a.planes.g, pixel4), acc.y); store_agent(&plane_at(a.planes.b, pixel4), acc.z);
+                    store_agent(&plane_at(a.planes.sa, pixel4), pixel_seed.a); store_agent(&plane_at(a.planes.sb, pixel4), pixel_seed.b);
+                    store_agent(&plane_at(a.planes.sc, pixel4), pixel_seed.c); store_agent(&plane_at(a.planes.sctr, pixel4), pixel_seed.counter);
+                    unpublished = true;                        // published at the top of the next trip
+                } else {
+                    plane_at(a.planes.r, pixel4) = acc.x; plane_at(a.planes.g, pixel4) = acc.y; plane_at(a.planes.b, pixel4) = acc.z;
+                    plane_at(a.planes.sa, pixel4) = pixel_seed.a; plane_at(a.planes.sb, pixel4) = pixel_seed.b;
+                    plane_at(a.planes.sc, pixel4) = pixel_seed.c; plane_at(a.planes.sctr, pixel4) = pixel_seed.counter;
+                }
                 record_item_cost(a, f2u(get(8)), live - f2u(get(9)));       // its shaded hits stand for the loop trips it took
                 busy = false;
-                if (passes > 1) { put(12, get(11)); unpublished = true; }      // (its next item ends >= kPublishEvery trips from now: after the publish)
             }
         }
+#ifdef PTMI_TAIL_STATS
+        if (ph_ending) ph_over += __builtin_readcyclecounter() - ph_t;
+#endif
         if (pending) {                                         // alive (a fresh sample starts with throughput 1)
             const bool capped = steps + 1u >= step_cap;
             hit_seed = seed;
@@ -2112,11 +2142,9 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
             }
         }
     }
-    if (passes > 1 && __any(unpublished)) {                  // (nobody waits for the last pass; a wave that ends earlier owes its items)
+    if (PASSES && __any(unpublished)) {                      // (nobody waits for the last pass; a wave that ends earlier owes its items)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (unpublished) atomicAdd(it.region_done + f2u(get(12)), 1u);
+        if (unpublished) atomicAdd(it.region_done + f2u(get(11)), 1u);
     }
 #ifdef PTMI_TAIL_STATS
     if (lane == 0) {     // diagnostic build: [8] first start, [10] last end, [12] sum of ends, [14] waves, [16] lanes-with-item x trips, [18] trips (all u64, s_memtime ticks)
@@ -2125,8 +2153,12 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
         atomicMax(wc + 0, ~t_start); atomicMax(wc + 1, t_end); atomicAdd(wc + 2, t_end - t_start); atomicAdd(wc + 3, 1ull);
         atomicAdd(wc + 4, lane_trips); atomicAdd(wc + 5, wave_trips);
         atomicMax(wc + 6, t_end - t_start);
+#ifdef PTMI_TAIL_PHASES
+        atomicAdd(wc + 8, ph_refill); atomicAdd(wc + 9, ph_over); atomicAdd(wc + 10, ph_refills); atomicAdd(wc + 11, ph_ends); atomicAdd(wc + 12, ph_taken);
+#else
         const unsigned long long bin = (t_end - t_start) >> 19;               // [24, 64): waves by duration, bins of 2^19 cycles
         atomicAdd(a.work_counter + 24 + (bin < 39ull ? (unsigned int)bin : 39u), 1u);
+#endif
     }
 #endif
     // statistics: the per-pixel kernels' sharded counters
@@ -3069,7 +3101,7 @@ hipError_t launch_streams_split(const RenderArgs &a, const ItemArgs &it, unsigne
 }
 
 int streams_pixels_waves() { return PTMI_PIXELS_WAVES; }
-int streams_publish_every() { return (int)kPublishEvery; }
+int streams_min_pass_samples() { return kMinPassSamples; }
 int streams_split_waves() { return PTMI_SPLIT_WAVES; }
 unsigned int streams_spill_records() { return kSpill; }
 unsigned int streams_first_block() { return kFirstBlock; }

@@ -178,9 +178,10 @@ def test_c5_glass_4k_512spp_one_part_of_8(pkg, ora, form):
 
 def test_c2_stream_form_equals_the_per_pixel_kernel_at_full_size(pkg):
     """render Streams on C2's image (1920x1080, 64 spp, S16) through the stream form -- start-hit regions, ticket queues, lanes
-    that refill, a pixel's samples as four ordered passes handed from lane to lane through the planes -- against the per-pixel
-    chain kernel (which the oracle pins at small sizes and by sample-split invariance): all seven planes bit for bit, five
-    launches in a row (8 million hand-offs each)."""
+    that refill -- against the per-pixel chain kernel (which the oracle pins at small sizes and by sample-split invariance): all
+    seven planes bit for bit, five launches in a row.  The first two launches render a pixel's samples as ONE item, the others
+    as 4, 8 and 16 ORDERED PASSES handed from lane to lane through the planes (write-through stores, a counter per region,
+    sc1 loads; no fence): 8, 17 and 33 million hand-offs per launch, between waves on any two XCDs."""
     B = pkg.binding
     sp, pl = pkg.world.scene16()
     cam = pkg.world.initial_camera()
@@ -190,8 +191,10 @@ def test_c2_stream_form_equals_the_per_pixel_kernel_at_full_size(pkg):
             c.resize(1920, 1080)
             c.init_output(0x5EED1234)
         stream.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
-        for k in range(5):
+        for k, batch in enumerate((0, 0, 16, 8, 4)):
+            stream.set_option(B.OPT_STREAM_BATCH, batch)
             chain.render(cam, 8, 64, pkg.STREAMS)
             stream.render(cam, 8, 64, pkg.STREAMS)
-            assert_planes_equal(stream.download_state(), chain.download_state(), "C2 through the stream form, launch %d" % k)
+            assert_planes_equal(stream.download_state(), chain.download_state(),
+                                "C2 through the stream form, launch %d (items of %s samples)" % (k, batch or "all"))
         assert stream.stats()["live_bounces"] == chain.stats()["live_bounces"]

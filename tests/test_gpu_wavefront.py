@@ -154,8 +154,8 @@ def test_overflow_levels_with_tiny_rings(pkg, ora, tmp_path_factory):
 def test_ordered_passes_inside_one_launch_are_bit_exact(ctx, pkg, ora, rule):
     """Without a ray-splitting material the stream form cuts a pixel's samples into ORDERED passes inside its one launch (a
     pixel's seven words travel through the planes from the lane that rendered one pass to whichever lane takes the next; a pass
-    is handed out once the previous one has been published with an agent-scope release): here 64 samples as 4 items of 16 and as
-    2 of 32 (PTMI_OPT_STREAM_BATCH under the result's-seed rule, where a pixel's samples are one serial chain) -- bit-identical
+    is handed out once the previous one has been published: write-through stores, then the region's counter): here 64 samples as
+    4 items of 16 and as 2 of 32 (PTMI_OPT_STREAM_BATCH under the result's-seed rule, where a pixel's samples are one serial chain) -- bit-identical
     to the oracle, both seed rules, image with and without whole tiles."""
     B = pkg.binding
     scene = pkg.world.scene16()

@@ -14,10 +14,11 @@ import __graft_entry__ as graft  # noqa: E402
 
 def main():
     pkg = graft.load_package()
-    lib = os.path.join(ROOT, "build", "ab", "tailstats.so")
+    phases = "phases" in sys.argv[1:]      # ... and the cycles its waves spend in the refill block and in the trips that end items
+    lib = os.path.join(ROOT, "build", "ab", "tailphases.so" if phases else "tailstats.so")
     if not os.path.exists(lib):
         os.makedirs(os.path.dirname(lib), exist_ok=True)
-        pkg._build.build_lib(out=lib, extra_flags=["-DPTMI_TAIL_STATS"])
+        pkg._build.build_lib(out=lib, extra_flags=["-DPTMI_TAIL_STATS"] + (["-DPTMI_TAIL_PHASES"] if phases else []))
     if len(sys.argv) > 1 and sys.argv[1] == "build":
         return
     pkg.binding._lib = None
@@ -46,6 +47,13 @@ def main():
                                    "longest_wave_cycles": longest, "mean_over_longest": round(total / max(waves, 1) / max(longest, 1), 4),
                                    "lanes_with_an_item_per_trip": round(lane_trips / max(trips, 1), 2), "trips_per_wave": round(trips / max(waves, 1), 1),
                                    "waves_by_duration_bins_of_2^19_cycles": [int(x) for x in w[24:64]]}
+            if phases:
+                del out["spp_%d" % spp]["waves_by_duration_bins_of_2^19_cycles"]
+                refill, over, refills, ends, taken = u64(24), u64(26), u64(28), u64(30), u64(32)
+                out["spp_%d" % spp].update({"refill_share_of_wave_cycles": round(refill / max(total, 1), 4), "item_end_trips_share": round(over / max(total, 1), 4),
+                                            "refills_per_wave": round(refills / max(waves, 1), 1), "cycles_per_refill": round(refill / max(refills, 1)),
+                                            "items_per_refill": round(taken / max(refills, 1), 2), "item_end_trips_per_wave": round(ends / max(waves, 1), 1),
+                                            "cycles_per_item_end_block": round(over / max(ends, 1)), "cycles_per_trip": round(total / max(trips, 1))})
     print(json.dumps(out, indent=1))
 
 
