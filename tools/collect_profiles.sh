@@ -29,7 +29,8 @@ cp "$SRC/c4_part.json" "$ROOT/profiles/${TAG}_c4_part.json"
 cp "$SRC/extra.json" "$ROOT/profiles/${TAG}_extra_measurements.json"
 cp "$SRC/phase_stats.json" "$ROOT/profiles/${TAG}_phase_stats.json"
 echo "profiles/${TAG}_* written"
-for f in split_stats tail_stats; do [ -s "$SRC/$f.json" ] && cp "$SRC/$f.json" "$ROOT/profiles/${TAG}_$f.json"; done
+for w in streams s16_stream; do [ -d "$ROOT/gpurun_out/pmcx_$w" ] && python3 "$ROOT/tools/pmc_summary.py" "$ROOT/gpurun_out/pmcx_$w" > "$ROOT/profiles/${TAG}_pmc_issue_$w.json"; done
+for f in split_stats tail_stats tail_phases; do [ -s "$SRC/$f.json" ] && cp "$SRC/$f.json" "$ROOT/profiles/${TAG}_$f.json"; done
 [ -s "$SRC/contracted.json" ] && cp "$SRC/contracted.json" "$ROOT/profiles/${TAG}_contracted_arithmetic.json"
 for f in tree_stats; do [ -s "$SRC/$f.json" ] && cp "$SRC/$f.json" "$ROOT/profiles/${TAG}_$f.json"; done
 true

@@ -38,5 +38,9 @@ timeout -k 10 300 python3 tools/phase_stats.py > "$OUT/phase_stats.json" 2> "$OU
 # 5. the stream form: lane participation per block of the split kernel, the end of the pixels kernel's launch; the contracted-arithmetic report
 timeout -k 10 300 python3 tools/split_stats.py > "$OUT/split_stats.json" 2> "$OUT/split_stats.log"; echo "split stats rc=$?"
 timeout -k 10 300 python3 tools/tail_stats.py > "$OUT/tail_stats.json" 2> "$OUT/tail_stats.log"; echo "tail stats rc=$?"
+timeout -k 10 300 python3 tools/tail_stats.py phases > "$OUT/tail_phases.json" 2>> "$OUT/tail_stats.log"; echo "tail phases rc=$?"
+# 6. issue-side counters of the two forms of render Streams on S16 (branches, instruction fetch, scalar and LDS issue)
+bash tools/pmc_extra.sh streams --algorithm streams > "$OUT/pmcx_streams.log" 2>&1; echo "pmcx streams rc=$?"
+bash tools/pmc_extra.sh s16_stream --algorithm streams --streams-form stream > "$OUT/pmcx_s16_stream.log" 2>&1; echo "pmcx s16 stream rc=$?"
 timeout -k 10 300 python3 tools/contracted_report.py > "$OUT/contracted.json" 2> "$OUT/contracted.log"; echo "contracted rc=$?"
 echo "all done: $OUT"
