@@ -76,7 +76,12 @@ def test_random_scenes_inline_and_streams(ctx, actx, pkg, ora):
             ctx.upload_state(*start)
             stream_form = case % 2 == 1                            # the stream ("wavefront") form or the per-pixel form
             ctx.set_variant(9 if stream_form else 0)
+            # (stream form: every other case cuts the pixels' sample chains into ordered passes of 1 to 3 samples -- hand-offs between
+            # lanes through the planes; no result may depend on it)
+            batch = int(r.choice([0, 1, 2, 3])) if stream_form else 0
+            ctx.set_option(pkg.binding.OPT_STREAM_BATCH, batch)
             ctx.render(cam, limit, spp, pkg.STREAMS)
+            ctx.set_option(pkg.binding.OPT_STREAM_BATCH, 0)
             ctx.set_variant(0)
             got = ctx.download_state()
             with np.errstate(all="ignore"):
@@ -84,7 +89,7 @@ def test_random_scenes_inline_and_streams(ctx, actx, pkg, ora):
                     want = ora.render_streams_wavefront(spheres, planes, cam, w, h, 1 << 16, spp, start)[0]
                 else:
                     want, _ = ora.render_streams(spheres, planes, cam, w, h, 1 << 16, spp, start)
-            assert_planes_equal(got, want, "fuzz case %d streams (%s)" % (case, "stream form" if stream_form else "per-pixel form"))
+            assert_planes_equal(got, want, "fuzz case %d streams (%s)" % (case, "stream form, items of %d samples" % batch if stream_form else "per-pixel form"))
         checked += 1
         if case % 5000 == 4999:
             print("fuzz: %d cases" % (case + 1), flush=True)
