@@ -543,16 +543,18 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
     } else if (stream_form) {                              // rays travel through streams in HBM (PTMI_OPT_STREAMS_FORM; variant 9)
         if (int rc = render_streams_wavefront(c, a, n_spp, *camera)) return rc;
     } else if (c->has_glass) {                             // rays may split: the per-pixel tree walk
-        // the first waiting children of every lane as 64-byte records in global memory (ptmi_kernels.hip); without the block
-        // (the device could not give it) every entry lives in scratch memory, as slow writes but the same results
+        // the first waiting children of every lane as 64-byte records in global memory (ptmi_kernels.hip): 16 KB per tile
         const size_t want = (size_t)tree_workgroups(width, rows_local) * kTreeFastLevels * 64 * 64;
         if (want > c->tree_stack_bytes) {
             PTMI_HIP(c, hipStreamSynchronize(c->stream));
             if (c->tree_stack) { (void)hipFree(c->tree_stack); c->tree_stack = nullptr; c->tree_stack_bytes = 0; }
-            if (hipMalloc(&c->tree_stack, want) == hipSuccess) c->tree_stack_bytes = want;
-            else { (void)hipGetLastError(); c->tree_stack = nullptr; }
+            if (hipMalloc(&c->tree_stack, want) != hipSuccess) {
+                (void)hipGetLastError(); c->tree_stack = nullptr;
+                return fail(c, PTMI_ENOMEM, "no device memory for the tree walk's records of waiting children (16 KB per 8x8 tile)");
+            }
+            c->tree_stack_bytes = want;
         }
-        a.tree_stack = want <= c->tree_stack_bytes ? static_cast<float4 *>(c->tree_stack) : nullptr;
+        a.tree_stack = static_cast<float4 *>(c->tree_stack);
         PTMI_HIP(c, launch_render_streams_tree(a, c->variant, c->stream));
     } else {
         PTMI_HIP(c, launch_render_streams(a, c->variant, c->stream));

@@ -55,7 +55,7 @@ struct RenderArgs {
     int seed_from_result;                 // PTMI_SEED_FROM_RESULT: a hit's ray seed replaces the pixel's (assumption A5)
     unsigned long long *stream_counters;  // device: [kScTruncated] rays cut by the cap, [kScDropped] children that found no room
     // tree walk: the first kTreeFastLevels waiting children of every lane, [tile workgroup][level][lane] records of four float4
-    // (tree_stack_tiles workgroups); NULL = everything in scratch
+    // (tree_stack_tiles workgroups); required by render_streams_tree_kernel
     float4 *tree_stack;
 };
 enum { kScTruncated = 0, kScDropped = 1, kScWords = 4 };

@@ -1526,7 +1526,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
             // entries live in scratch memory, where a push is fourteen lane-strided dwords, each a partial line: with the
             // whole stack in scratch the kernel wrote 4 GB per 1080p / 64-spp launch (70 times the planes).
             uint32_t stack_w[kTreeStackDepth - kTreeFastLevels][14];
-            float4 *fast = a.tree_stack ? a.tree_stack + ((size_t)wg * kTreeFastLevels * kRenderBlock + threadIdx.x) * 4 : nullptr;
+            float4 *const fast = a.tree_stack + ((size_t)wg * kTreeFastLevels * kRenderBlock + threadIdx.x) * 4;   // (never NULL: the call fails without the block)
             int sp = 0, entry_i = 0;
             int s = 0, idx = h0.idx;
             unsigned int steps = 0, deepest = 0;                 // deepest: traceSteps of the sample's longest lineage
@@ -1566,13 +1566,13 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                 if (sp > 0) {                                     // the most recent waiting child
                     --sp;
                     uint32_t e[14];
-                    if (fast && sp < kTreeFastLevels) {
+                    if (sp < kTreeFastLevels) {
                         const float4 *r = fast + (size_t)sp * kRenderBlock * 4;
                         const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
                         e[0] = f2u(r0.x); e[1] = f2u(r0.y); e[2] = f2u(r0.z); e[3] = f2u(r0.w); e[4] = f2u(r1.x); e[5] = f2u(r1.y); e[6] = f2u(r1.z);
                         e[7] = f2u(r1.w); e[8] = f2u(r2.x); e[9] = f2u(r2.y); e[10] = f2u(r2.z); e[11] = f2u(r2.w); e[12] = f2u(r3.x); e[13] = f2u(r3.y);
                     } else {
-                        const int q0 = fast ? sp - kTreeFastLevels : sp;
+                        const int q0 = sp - kTreeFastLevels;
                         for (int q = 0; q < 14; ++q) e[q] = stack_w[q0 < kTreeStackDepth - kTreeFastLevels ? q0 : 0][q];
                     }
                     pos = mk(u2f(e[0]), u2f(e[1]), u2f(e[2]));
@@ -1627,7 +1627,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                         else {
                             // while the cached reflection's subtree is walked, the cached refraction "waits": one slot less
                             if (sp < kTreeStackDepth - ((prefix && entry_i == 1 && first_is_reflection) ? 1 : 0)) {
-                                if (fast && sp < kTreeFastLevels) {
+                                if (sp < kTreeFastLevels) {
                                     float4 *r = fast + (size_t)sp * kRenderBlock * 4;
                                     r[0] = float4{ko[1].x, ko[1].y, ko[1].z, kd[1].x};
                                     r[1] = float4{kd[1].y, kd[1].z, kt[1].x, kt[1].y};
@@ -1636,7 +1636,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                                 } else {
                                     const uint32_t e[14] = {f2u(ko[1].x), f2u(ko[1].y), f2u(ko[1].z), f2u(kd[1].x), f2u(kd[1].y), f2u(kd[1].z),
                                                             f2u(kt[1].x), f2u(kt[1].y), f2u(kt[1].z), ks[1].a, ks[1].b, ks[1].c, ks[1].counter, steps};
-                                    const int q0 = fast ? sp - kTreeFastLevels : sp;
+                                    const int q0 = sp - kTreeFastLevels;
                                     for (int q = 0; q < 14; ++q) stack_w[q0 < kTreeStackDepth - kTreeFastLevels ? q0 : 0][q] = e[q];
                                 }
                                 ++sp;
