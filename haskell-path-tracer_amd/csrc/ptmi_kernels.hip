@@ -1510,9 +1510,15 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                         V3 hp, hn;
                         hit_record(S, ns, h.idx, ro, rd, h.t, hp, hn);
                         if (n_entries == 0) first_is_reflection = k == 0;
-                        put_entry(n_entries++, hp, hn, rd, rt, h.idx, 1u, 3u + (unsigned int)k);
+                        put_entry(n_entries++, hp, hn, rd, rt, h.idx, 1u, (unsigned int)k);
                     }
                 }
+                // THE LEAD SEED.  A sample's reflection child carries the sample's seed advanced by 3 raw draws, its refraction
+                // child by 4, and updateSeed moves the pixel's seed on by one: so from here to the end of the pixel `pixel_seed`
+                // holds the pixel's seed advanced by 3 -- the reflection's seed as it stands, the refraction's one step further --
+                // and is stepped back three times before it is stored (sfc32_prev, the exact inverse).  Seven SFC32 steps per
+                // sample become at most two.
+                (void)sfc32_next(pixel_seed); (void)sfc32_next(pixel_seed); (void)sfc32_next(pixel_seed);
             } else {
                 put_entry(0, pos, normal, primary, mk(1.0f, 1.0f, 1.0f), h0.idx, 0u, 0u);
                 n_entries = 1;
@@ -1551,8 +1557,8 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                         ++entry_i;
                         steps = meta & 0xffu;
                         normal = PTMI_TREE_NORMAL_LDS ? mk(u2f(q[10 * kRenderBlock]), u2f(q[11 * kRenderBlock]), u2f(q[12 * kRenderBlock])) : normal_at(S, ns, idx, pos);
-                        seed = pixel_seed;
-                        for (uint32_t k = 0; k < (meta >> 8); ++k) (void)sfc32_next(seed);     // the draws its ray's ancestors made
+                        seed = pixel_seed;                        // (with a prefix: the lead seed -- the draws the ray's ancestors made)
+                        if (meta >> 8) (void)sfc32_next(seed);    // the refraction child: one more
                         pending = true; has_ray = false;
                         return;
                     }
@@ -1676,6 +1682,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
             atomicAdd(a.work_counter + 1, trips); atomicAdd(a.work_counter + 2, st_dead);
             atomicAdd(a.work_counter + 3, st_shade); atomicAdd(a.work_counter + 4, st_trace);
 #endif
+            if (prefix) { sfc32_prev(pixel_seed); sfc32_prev(pixel_seed); sfc32_prev(pixel_seed); }     // the lead seed back to the pixel's
         }
 #ifdef PTMI_TREE_STATS_MAP
         acc.x = (float)trips;                                         // diagnostic build: the red plane becomes the per-pixel cost map
@@ -2201,7 +2208,7 @@ template <bool LDS_SCENE, bool TILES>
 __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_kernel(const RenderArgs a, const ItemArgs it)
 {
     // the lane's own item: 0-2 position of the start hit, 3-5 normal, 6-8 incoming direction, 9-11 throughput,
-    // 12 primitive | meta << 16, 13 pixel, 14-17 the seed its next sample starts from
+    // 12 primitive | meta << 16, 13 pixel, 14-17 the seed the ray of its next sample carries
     __shared__ float item_rec[18][kRenderBlock];
     __shared__ uint32_t ring[15][kRing];                      // children waiting for a lane: RayQueue's record, word by word (15 words)
     extern __shared__ float4 lds_scene[];
@@ -2278,11 +2285,15 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                 const uint32_t px = f2u(r3.y);
                 // initialState (Trace.hs:158-162) one step on: the cached start hit; the item's first sample starts from the
                 // pixel's seed advanced by (pass * samples_per_pass) draws, which is what that many updateSeeds leave
-                const uint4 s0 = it.seed_snapshots[(size_t)cur.pass * it.n_px + px];
+                // ... and, for a child of a cached glass primary hit, by the 3 or 4 raw draws its ancestors made: the item keeps the
+                // seed its next sample's RAY carries, which updateSeed moves on by one like the pixel's own
+                const uint4 snap = it.seed_snapshots[(size_t)cur.pass * it.n_px + px];
+                Sfc32 s0; s0.a = snap.x; s0.b = snap.y; s0.c = snap.z; s0.counter = snap.w;
+                for (uint32_t q = 0; q < (f2u(r3.z) >> 8); ++q) (void)sfc32_next(s0);
                 put(0, r0.x); put(1, r0.y); put(2, r0.z); put(3, r0.w); put(4, r1.x); put(5, r1.y);
                 put(6, r1.z); put(7, r1.w); put(8, r2.x); put(9, r2.y); put(10, r2.z); put(11, r2.w);
                 put(12, u2f(f2u(r3.x) | (f2u(r3.z) << 16))); put(13, r3.y);
-                put(14, u2f(s0.x)); put(15, u2f(s0.y)); put(16, u2f(s0.z)); put(17, u2f(s0.w));
+                put(14, u2f(s0.a)); put(15, u2f(s0.b)); put(16, u2f(s0.c)); put(17, u2f(s0.counter));
                 item_trips = 0;
                 const int first_sample = (int)cur.pass * it.samples_per_pass;
                 samples_left = a.n_spp - first_sample < it.samples_per_pass ? a.n_spp - first_sample : it.samples_per_pass;
@@ -2349,10 +2360,9 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                 idx = (int)(pm & 0xffffu);
                 pixel = f2u(get(13));
                 Sfc32 ss; ss.a = f2u(get(14)); ss.b = f2u(get(15)); ss.c = f2u(get(16)); ss.counter = f2u(get(17));
-                seed = ss;
-                (void)random_float(ss);                        // updateSeed (Trace.hs:190-191): the next sample starts one draw further
+                seed = ss;                                     // (already past the draws its ray's ancestors made)
+                (void)sfc32_next(ss);                          // updateSeed (Trace.hs:190-191): the next sample starts one draw further
                 put(14, u2f(ss.a)); put(15, u2f(ss.b)); put(16, u2f(ss.c)); put(17, u2f(ss.counter));
-                for (uint32_t q = 0; q < (pm >> 24); ++q) (void)sfc32_next(seed);          // the draws its ray's ancestors made
                 depth = (pm >> 16) & 0xffu;
                 deepest = deepest > 1u ? deepest : 1u;        // the primary ray's traceStep
                 pending = true; foreign = false;              // (a start hit of a dead ray -- a reflection of weight ~0 -- waits for the next trip's first block)
