@@ -1385,17 +1385,46 @@ __device__ __forceinline__ void queue_store(const RayQueue &q, unsigned int i, V
     r[3] = float4{u2f(s.c), u2f(s.counter), u2f(depth), 0.0f};
 }
 
+// The two constants of a GLASS material that glass_children needs: eta = 1 / ior and Schlick's r0 = ((1 - ior) / (1 + ior))^2 -- two
+// divisions per glass hit.  A kernel that keeps the scene in LDS computes them once per workgroup, with the same operations, into the
+// two words of the material record that GLASS leaves unused (mb.z, mb.w of the LDS copy); one that reads the scene through scalar
+// loads computes them at the hit.
+struct GlassConstants { float eta, r0; };
+__device__ __forceinline__ GlassConstants glass_constants(float ior)
+{
+    GlassConstants g;
+    g.eta = 1.0f / ior;
+    const float q = (1.0f - ior) / (1.0f + ior);
+    g.r0 = q * q;
+    return g;
+}
+__device__ __forceinline__ void stage_glass_constants(float4 *lds, const SceneView &scene)
+{
+    float4 *M = lds + scene.geom_f4();
+    const int n = scene.n_spheres + scene.n_planes;
+    for (int i = threadIdx.x; i < n; i += kRenderBlock) {
+        float4 mb = M[2 * i + 1];
+        if (f2u(mb.x) == 2u) { const GlassConstants g = glass_constants(mb.y); mb.z = g.eta; mb.w = g.r0; M[2 * i + 1] = mb; }
+    }
+}
+template <bool LDS_SCENE>
+__device__ __forceinline__ GlassConstants glass_constants_of(float4 mb)
+{
+    if (LDS_SCENE) { GlassConstants g; g.eta = mb.z; g.r0 = mb.w; return g; }
+    return glass_constants(mb.y);
+}
+
 // GLASS ior (extension): reflection child + refraction child; see the oracle's glass_children for the spec.
-__device__ __forceinline__ void glass_children(V3 color, float ior, V3 p, V3 n, V3 d, V3 throughput, Sfc32 seed,
+__device__ __forceinline__ void glass_children(V3 color, GlassConstants gc, V3 p, V3 n, V3 d, V3 throughput, Sfc32 seed,
                                                V3 o_out[2], V3 d_out[2], V3 t_out[2], Sfc32 s_out[2])
 {
     (void)gen_component(seed); (void)gen_component(seed); (void)gen_component(seed);   // genVec is drawn before the match
     const float dn = dot(d, n);
     const float cosi = -dn;
-    const float eta = 1.0f / ior;
+    const float eta = gc.eta;
     const float k = 1.0f - (eta * eta) * (1.0f - cosi * cosi);
     const V3 reflection = d - scale_l(2.0f * dn, n);
-    float r0 = (1.0f - ior) / (1.0f + ior); r0 = r0 * r0;
+    const float r0 = gc.r0;
     const float mm = 1.0f - cosi;
     float R = r0 + (1.0f - r0) * (((mm * mm) * (mm * mm)) * mm);
     V3 refraction;
@@ -1452,6 +1481,8 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
         const int total = a.scene.total_f4();
         for (int i = threadIdx.x; i < total; i += kRenderBlock) lds_scene[i] = a.scene.packed[i];
         __syncthreads();
+        stage_glass_constants(lds_scene, a.scene);
+        __syncthreads();
     }
     const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
     const float4 *M = S + a.scene.geom_f4();
@@ -1502,7 +1533,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
             if (prefix) {
                 emit0 = scale_r(mk(ma0.x, ma0.y, ma0.z), ma0.w) * mk(1.0f, 1.0f, 1.0f);     // computeResult of the primary hit
                 V3 ko[2], kd[2], kt[2]; Sfc32 ks[2];
-                glass_children(mk(ma0.x, ma0.y, ma0.z), mb0.y, pos, normal, primary, mk(1.0f, 1.0f, 1.0f), pixel_seed, ko, kd, kt, ks);
+                glass_children(mk(ma0.x, ma0.y, ma0.z), glass_constants_of<LDS_SCENE>(mb0), pos, normal, primary, mk(1.0f, 1.0f, 1.0f), pixel_seed, ko, kd, kt, ks);
                 for (int k = 0; k < 2; ++k) {
                     const V3 ro = k == 0 ? ko[0] : ko[1], rd = k == 0 ? kd[0] : kd[1], rt = k == 0 ? kt[0] : kt[1];
                     const HitSel h = check_hit(S, ns, np, ro, rd);
@@ -1627,7 +1658,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                         acc = acc + (scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);
                         ++steps;
                         V3 ko[2], kd[2], kt[2]; Sfc32 ks[2];
-                        glass_children(mk(ma.x, ma.y, ma.z), mb.y, pos, normal, d, throughput, seed, ko, kd, kt, ks);
+                        glass_children(mk(ma.x, ma.y, ma.z), glass_constants_of<LDS_SCENE>(mb), pos, normal, d, throughput, seed, ko, kd, kt, ks);
                         live += 2u;
                         if (capped) { cut += 2u; pending = false; ended = true; }
                         else {
@@ -1831,7 +1862,7 @@ __global__ void __launch_bounds__(256) streams_primary_kernel(const RenderArgs a
             split = out.region_slots > 64u && f2u(mb.x) == 2u && a.stream_step_cap >= 3 && emit.x == 0.0f && emit.y == 0.0f && emit.z == 0.0f;
             if (split) {
                 V3 ko[2], kd[2], kt[2]; Sfc32 ks[2]; Sfc32 dummy; dummy.a = dummy.b = dummy.c = dummy.counter = 0;
-                glass_children(mk(ma.x, ma.y, ma.z), mb.y, p0, n0, primary, mk(1.0f, 1.0f, 1.0f), dummy, ko, kd, kt, ks);
+                glass_children(mk(ma.x, ma.y, ma.z), glass_constants(mb.y), p0, n0, primary, mk(1.0f, 1.0f, 1.0f), dummy, ko, kd, kt, ks);
                 for (int k = 0; k < 2; ++k) {
                     const V3 ro = k == 0 ? ko[0] : ko[1], rd = k == 0 ? kd[0] : kd[1], rt = k == 0 ? kt[0] : kt[1];
                     const HitSel hc = check_hit(S, ns, np, ro, rd);
@@ -2217,6 +2248,8 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
         const int total = a.scene.total_f4();
         for (int i = threadIdx.x; i < total; i += kRenderBlock) lds_scene[i] = a.scene.packed[i];
         __syncthreads();
+        stage_glass_constants(lds_scene, a.scene);
+        __syncthreads();
     }
     const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
     const float4 *M = S + a.scene.geom_f4();
@@ -2401,7 +2434,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
             if (f2u(mb.x) == 2u) {                            // GLASS (extension): reflection stays, refraction is emitted
                 contribution = scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput;
                 V3 co[2], cd[2], ct[2]; Sfc32 cs[2];
-                glass_children(mk(ma.x, ma.y, ma.z), mb.y, o, normal, d, throughput, seed, co, cd, ct, cs);
+                glass_children(mk(ma.x, ma.y, ma.z), glass_constants_of<LDS_SCENE>(mb), o, normal, d, throughput, seed, co, cd, ct, cs);
                 o = co[0]; d = cd[0]; throughput = ct[0]; seed = cs[0];
                 ko = co[1]; kd = cd[1]; kt = ct[1]; ks = cs[1];
                 emits = true;
@@ -2528,6 +2561,8 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
         const int total = a.scene.total_f4();
         for (int i = threadIdx.x; i < total; i += kRenderBlock) lds_scene[i] = a.scene.packed[i];
         __syncthreads();
+        stage_glass_constants(lds_scene, a.scene);
+        __syncthreads();
     }
     const float4 *S = LDS_SCENE ? lds_scene : a.scene.packed;
     const float4 *M = S + a.scene.geom_f4();
@@ -2601,7 +2636,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
             if (f2u(mb.x) == 2u) {
                 contribution = scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput;
                 V3 co[2], cd[2], ct[2]; Sfc32 cs[2];
-                glass_children(mk(ma.x, ma.y, ma.z), mb.y, o, normal, d, throughput, seed, co, cd, ct, cs);
+                glass_children(mk(ma.x, ma.y, ma.z), glass_constants_of<LDS_SCENE>(mb), o, normal, d, throughput, seed, co, cd, ct, cs);
                 o = co[0]; d = cd[0]; throughput = ct[0]; seed = cs[0];
                 ko = co[1]; kd = cd[1]; kt = ct[1]; ks = cs[1];
                 emits = true;
