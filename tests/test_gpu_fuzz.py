@@ -157,12 +157,21 @@ def test_random_scenes_with_non_finite_and_denormal_numbers(ctx, pkg, ora):
         # Streams has no bounce limit (Trace.hs:166-170): a path whose throughput is NaN or infinite runs into the
         # 65 536-step cap, so only small images go through it here (the oracle walks those steps on one thread)
         if case % 3 == 0 and w * h * spp <= 150:
-            ctx.upload_state(*start)
-            ctx.render(cam, limit, spp, pkg.STREAMS)
-            got = ctx.download_state()
             with np.errstate(all="ignore"):
                 want, _ = ora.render_streams(spheres, planes, cam, w, h, 1 << 16, spp, start)
-            assert_planes_equal_up_to_nan_payload(got, want, what + " streams")
+            # both forms: the per-pixel chain, and the stream form (start-hit list, lanes that refill; every other time with
+            # the sample chains cut into ordered passes of one or two samples)
+            for form, batch in ((pkg.binding.FORM_AUTO, 0), (pkg.binding.FORM_STREAM, int(r.choice([0, 1, 2])))):
+                ctx.set_option(pkg.binding.OPT_STREAMS_FORM, form)
+                ctx.set_option(pkg.binding.OPT_STREAM_BATCH, batch)
+                try:
+                    ctx.upload_state(*start)
+                    ctx.render(cam, limit, spp, pkg.STREAMS)
+                    got = ctx.download_state()
+                finally:
+                    ctx.set_option(pkg.binding.OPT_STREAMS_FORM, pkg.binding.FORM_AUTO)
+                    ctx.set_option(pkg.binding.OPT_STREAM_BATCH, 0)
+                assert_planes_equal_up_to_nan_payload(got, want, what + (" streams, stream form, items of %d" % batch if form else " streams"))
         if case % 500 == 499:
             print("extreme fuzz: %d cases" % (case + 1), flush=True)
 
