@@ -49,6 +49,12 @@ struct ptmi_ctx {
 
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_snap = nullptr;
+    // The stream form's tail (render_streams_wavefront): the end of the dispatch order is rendered by the per-pixel kernel on a
+    // stream of its own, beside the persistent launch.  d_tail_start: where that end begins (written by the order kernel).
+    hipStream_t tail_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    unsigned int *d_tail_start = nullptr;
+    int opt_tail_permille = 150;               // thousandths of the recorded cost the tail may hold (PTMI_STREAM_TAIL in the environment; 0 = no tail)
     bool ev_valid = false;
     int variant = 0;
     Stager stager;                          // pinned ring + worker threads for host-buffer entry points (ptmi_stage.h)
@@ -319,8 +325,6 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
         // items: with three items per lane (1080p) a quarter of the wave-time of the launch lay after the first wave had ended.
         // The samples are therefore cut into ordered passes INSIDE the one launch (streams_pixels_kernel): a pixel's next pass is
         // handed out once its previous one has been published.
-        PTMI_HIP(c, launch_streams_advance_missed(a, hits, n_spp, c->stream));
-        PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, kItersBytes, c->stream));
         const unsigned int grid_full = (unsigned int)(cus * 4 * streams_pixels_waves());
         const unsigned long long lanes = 64ull * grid_full;
         int passes = 1;
@@ -337,6 +341,29 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
         if (passes < 1) passes = 1;
         it.passes = passes;
         it.chunk_cursor = tickets_of(0);
+        // THE TAIL.  A lane renders a pixel's whole sample chain, so the persistent launch ends as its last items do: its waves end between
+        // 70 and 100 % of it.  The cheapest quads of the dispatch order -- the order kernel marks where they begin, on the device -- are
+        // therefore left to the per-pixel chain kernel, launched beside the persistent kernel on a low-priority stream: its waves (one
+        // tile each) take the slots the persistent waves leave as they end.  Every pixel is rendered by exactly one of the two kernels,
+        // by the same arithmetic: no result depends on where the boundary lies.
+        // (Only while a pixel's samples are ONE item: where they are cut into ordered passes the end of the launch is short already, and a
+        // tail wave would render its tile's many samples in one piece -- 1080p / 256 spp: 16.99 ms with four passes, 17.86 with a tail beside them.)
+        const unsigned int *tail = (passes == 1 && c->opt_tail_permille > 0 && a.quad_order && c->d_tail_start && quad_positions(a.width, a.rows_local) > 0) ? c->d_tail_start : nullptr;
+        if (tail && !c->tail_stream) {
+            int least = 0, greatest = 0;
+            PTMI_HIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+            PTMI_HIP(c, hipStreamCreateWithPriority(&c->tail_stream, hipStreamNonBlocking, least));
+            PTMI_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            PTMI_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        }
+        it.tail_start = tail;
+        PTMI_HIP(c, launch_streams_advance_missed(a, hits, n_spp, tail, c->stream));
+        PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, kItersBytes, c->stream));
+        if (tail) {
+            PTMI_HIP(c, hipEventRecord(c->ev_fork, c->stream));
+            PTMI_HIP(c, hipStreamWaitEvent(c->tail_stream, c->ev_fork, 0));
+        }
+
         if (passes > 1) {
             if (n_regions > c->region_done_words) {
                 PTMI_HIP(c, hipStreamSynchronize(c->stream));
@@ -351,6 +378,11 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
         const unsigned long long tickets = (unsigned long long)n_regions * (unsigned long long)passes;
         if (grid > tickets) grid = (unsigned int)(tickets < 1 ? 1 : tickets);
         PTMI_HIP(c, launch_streams_pixels(a, it, grid, c->stream));
+        if (tail) {
+            PTMI_HIP(c, launch_render_streams_tail(a, tail, c->tail_stream));
+            PTMI_HIP(c, hipEventRecord(c->ev_join, c->tail_stream));
+            PTMI_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        }
         return PTMI_OK;
     }
 
@@ -516,9 +548,14 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
         // order_state counts the launches made with this key.  Every launch adds its costs (a 1-spp launch says little
         // on its own: the compat entry renders one sample per call); the order is rebuilt before launch 1, 2, 4, 8, ...
         const int launches = c->order_state;
-        if (launches == 0) PTMI_HIP(c, hipMemsetAsync(c->d_quad_cost, 0, n_quads * sizeof(unsigned int), c->stream));
-        else if ((launches & (launches - 1)) == 0 && launches < (1 << 20)) {
-            PTMI_HIP(c, launch_quad_order(c->d_quad_cost, c->d_quad_order, c->d_quad_class, n_quads, c->stream));
+        if (!c->d_tail_start) PTMI_HIP(c, hipMalloc(&c->d_tail_start, 64));
+        if (launches == 0) {
+            PTMI_HIP(c, hipMemsetAsync(c->d_quad_cost, 0, n_quads * sizeof(unsigned int), c->stream));
+            PTMI_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->d_tail_start), (int)n_quads, 1, c->stream));   // no tail yet
+        } else if ((launches & (launches - 1)) == 0 && launches < (1 << 20)) {
+            // (the stream form: the order kernel also says where the order's cheap end begins -- render_streams_wavefront)
+            PTMI_HIP(c, launch_quad_order(c->d_quad_cost, c->d_quad_order, c->d_quad_class, n_quads, stream_form ? c->d_tail_start : nullptr,
+                                          (unsigned int)(c->opt_tail_permille > 0 ? c->opt_tail_permille : 0), c->stream));
             ++c->order_generation;
         }
         if (launches > 0) a.quad_order = c->d_quad_order;
@@ -619,6 +656,7 @@ int ptmi_create(ptmi_ctx **out, int device)
     if (!c) return fail(nullptr, PTMI_ENOMEM, "host allocation failed");
     c->device = device;
     if (const char *e = std::getenv("PTMI_ORDERED_PASSES")) c->opt_ordered_passes = std::atoi(e);
+    if (const char *e = std::getenv("PTMI_STREAM_TAIL")) c->opt_tail_permille = std::atoi(e);     // thousandths of the cost; 0 = no tail
     auto bail = [&](hipError_t err, const char *what) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);
         ptmi_destroy(c);
@@ -668,6 +706,10 @@ void ptmi_destroy(ptmi_ctx *c)
     if (c->d_quad_cost) (void)hipFree(c->d_quad_cost);
     if (c->d_quad_order) (void)hipFree(c->d_quad_order);
     if (c->d_quad_class) (void)hipFree(c->d_quad_class);
+    if (c->d_tail_start) (void)hipFree(c->d_tail_start);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->tail_stream) { (void)hipStreamSynchronize(c->tail_stream); (void)hipStreamDestroy(c->tail_stream); }
     if (c->d_chunk_done) (void)hipFree(c->d_chunk_done);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);

@@ -57,6 +57,10 @@ struct RenderArgs {
     // tree walk: the first kTreeFastLevels waiting children of every lane, [tile workgroup][level][lane] records of four float4
     // (tree_stack_tiles workgroups); required by render_streams_tree_kernel
     float4 *tree_stack;
+    // render_streams_kernel as the TAIL of the stream form (streams_pixels_kernel's launch): the workgroups start at dispatch position
+    // *first_position (a device word: where the stream form's part of the dispatch order ends) and those past the grid do nothing;
+    // costs are recorded in the stream form's unit (shaded hits per quad).  NULL = the whole grid, as ever.
+    const unsigned int *first_position;
 };
 enum { kScTruncated = 0, kScDropped = 1, kScWords = 4 };
 constexpr int kTreeStackDepth = 16;        // per-pixel tree walk: pending children a lane can hold (render_streams_tree_kernel)
@@ -128,6 +132,7 @@ struct LevelArgs {
 struct ItemArgs {
     HitList hits;
     unsigned int n_positions;       // groups of four regions (dispatch positions): hits.n_regions / 4
+    const unsigned int *tail_start; // streams_pixels_kernel: a device word -- the positions from there on are left to the per-pixel kernel (NULL: none)
     int passes;                     // tickets run over the chunks this many times: a pixel's samples in that many items
     unsigned int *region_done;      // streams_pixels_kernel, passes > 1: per region, the items published so far (zero at launch)
     unsigned int *chunk_cursor;     // device: the launch's eight ticket counters, kCounterStride words apart, zero at launch
@@ -155,7 +160,8 @@ hipError_t launch_streams_seeds(Planes p, uint4 *snapshots, long long n, int pas
 hipError_t launch_streams_level(const RenderArgs &a, const LevelArgs &lv, unsigned int grid, hipStream_t stream);
 hipError_t launch_streams_primary(const RenderArgs &a, HitList hits, unsigned int *counters, hipStream_t stream);
 // updateSeeds for the pixels without start hits (the ordered item kernel advances the others itself)
-hipError_t launch_streams_advance_missed(const RenderArgs &a, HitList hits, int draws, hipStream_t stream);
+hipError_t launch_streams_advance_missed(const RenderArgs &a, HitList hits, int draws, const unsigned int *tail_start, hipStream_t stream);
+hipError_t launch_render_streams_tail(const RenderArgs &a, const unsigned int *first_position, hipStream_t stream);
 unsigned int streams_first_block();   // output slots every wave of a level owns from the start
 
 hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t stream);
@@ -164,7 +170,8 @@ hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t s
 hipError_t launch_render_streams_tree(const RenderArgs &a, int variant, hipStream_t stream);   // scenes with GLASS: per-pixel tree walk
 unsigned int tree_workgroups(int width, int rows_local);   // workgroups per copy of its grid (RenderArgs.tree_stack holds kTreeFastLevels x 64 records of 64 B for each)
 unsigned int quad_positions(int width, int rows_local);                    // entries of quad_order / quad_cost (0 = tiles not used)
-hipError_t launch_quad_order(const unsigned int *cost, unsigned int *order, unsigned int *cls, unsigned int n, hipStream_t stream);
+hipError_t launch_quad_order(const unsigned int *cost, unsigned int *order, unsigned int *cls, unsigned int n, unsigned int *tail_start,
+                             unsigned int tail_permille, hipStream_t stream);
 bool uses_quad_order(const RenderArgs &a, int algorithm_inline, int variant);
 hipError_t launch_seed(Planes p, int width, int rows_local, int stripe_rows, int n_parts, int part,
                        uint64_t seed0, bool clear_color, hipStream_t stream);

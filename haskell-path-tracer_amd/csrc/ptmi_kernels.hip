@@ -416,7 +416,8 @@ __host__ inline unsigned int tile_grid(const RenderArgs &a, int tw)
 template <int TILE_W>
 __device__ __forceinline__ void enter_sample_chunk(const RenderArgs &a, unsigned int &wg, int &chunk, int &n_spp_chunk)
 {
-    wg = blockIdx.x; chunk = 0; n_spp_chunk = a.n_spp;
+    wg = blockIdx.x + (a.first_position ? 4u * *a.first_position : 0u);     // (the tail of the stream form: RenderArgs.first_position)
+    chunk = 0; n_spp_chunk = a.n_spp;
     if (TILE_W > 0 && a.spp_chunks > 1) {
         // The workgroup's place in the chain of copies is a TICKET, not blockIdx: HIP promises nothing about the order in which
         // workgroups are dispatched, and a consumer that waited for a producer not yet dispatched -- with every slot held by
@@ -1225,6 +1226,9 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_STREAMS_WAVES) render_strea
     __shared__ float pixel_const[11][kRenderBlock];         // per-lane restart record (rows 0..6) and the last hit's seed (7..10)
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
+    // As the tail of the stream form the grid covers every dispatch position, and its workgroups start where the stream form's part
+    // ends (a device word): those that would pass the last position have nothing to do.
+    if (TILE_W > 0 && a.first_position && blockIdx.x + 4u * *a.first_position >= gridDim.x) return;
     if (LDS_SCENE) {
         const int total = a.scene.total_f4();
         for (int i = threadIdx.x; i < total; i += kRenderBlock) lds_scene[i] = a.scene.packed[i];
@@ -1348,7 +1352,14 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_STREAMS_WAVES) render_strea
         a.planes.sc[pixel] = pixel_seed.c; a.planes.sctr[pixel] = pixel_seed.counter;
     }
     leave_sample_chunk<TILE_W>(a, wg, chunk);
-    if (TILE_W > 0) record_cost(a, quad, trips);
+    if (TILE_W > 0) {
+        if (a.first_position) {                               // the stream form's unit: the hits the tile's pixels shaded (record_item_cost)
+            const unsigned long long hits = wave_sum(live);
+            if (a.quad_cost && (threadIdx.x & 63) == 0) atomicAdd(a.quad_cost + quad, (unsigned int)hits);
+        } else {
+            record_cost(a, quad, trips);
+        }
+    }
     if (a.live_counter) {
         const unsigned long long total = wave_sum(live);
         if ((threadIdx.x & 63) == 0 && total) atomicAdd(a.live_counter + (size_t)(blockIdx.x & (kStatShards - 1)) * kStatStride, total);
@@ -1917,8 +1928,9 @@ __global__ void __launch_bounds__(256) streams_primary_kernel(const RenderArgs a
 // primary hit do): `draws` draws each.  The pixels with start hits are streams_pixels_kernel's.  Same pixel mapping as the
 // primary kernel, whose missed[] masks (one per region) say which lanes have work.
 template <bool TILES>
-__global__ void __launch_bounds__(256) streams_advance_missed_kernel(const RenderArgs a, const HitList hits, int draws)
+__global__ void __launch_bounds__(256) streams_advance_missed_kernel(const RenderArgs a, const HitList hits, int draws, const unsigned int *tail_start)
 {
+    if (tail_start && blockIdx.x >= *tail_start) return;      // (the per-pixel tail renders those positions whole)
     unsigned int quad, region; long long pixel;
     const bool valid = primary_pixel<TILES>(a, quad, region, pixel);
     const unsigned long long missed = hits.missed[region];
@@ -1941,6 +1953,7 @@ struct ChunkCursor {
     unsigned int taken, len, first, pass;    // of the chunk in hand: records handed out, records, first slot, pass
     unsigned int region;                     // ... its region
     unsigned int home, tries;                // the wave's XCD; queues found exhausted (8: nothing is left)
+    unsigned int n_positions;                // dispatch positions the kernel works on (the first ones of the order)
     bool ready;                              // (ordered passes) the chunk's previous pass has been published and acquired
 };
 __device__ __forceinline__ unsigned int xcc_id()
@@ -1955,7 +1968,7 @@ __device__ __forceinline__ void next_chunk(ChunkCursor &c, const ItemArgs &it)
     while (c.tries < 8u) {
         const unsigned int q = (c.home + c.tries) & 7u;
         // positions in queue q: p = 8 s + q < n_positions
-        const unsigned int n_pos = it.n_positions > q ? (it.n_positions - q - 1u) / 8u + 1u : 0u;
+        const unsigned int n_pos = c.n_positions > q ? (c.n_positions - q - 1u) / 8u + 1u : 0u;
         const unsigned int n = n_pos * 4u * per;
         unsigned int j = 0;
         if ((threadIdx.x & 63) == 0) j = atomicAdd(it.chunk_cursor + (size_t)q * kCounterStride, 1u);
@@ -2030,6 +2043,10 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
     Sfc32 hit_seed; hit_seed.a = hit_seed.b = hit_seed.c = hit_seed.counter = 0;
 
     ChunkCursor cur; cur.home = xcc_id(); cur.tries = 0;
+    // (the positions from *tail_start on -- the cheapest quads -- are the per-pixel kernel's, whose waves fill the slots this launch's
+    // waves leave as they end: ptmi_api.cpp)
+    cur.n_positions = it.n_positions;
+    if (it.tail_start) { const unsigned int t = *it.tail_start; cur.n_positions = t < it.n_positions ? t : it.n_positions; }
     next_chunk(cur, it);
 #ifdef PTMI_TAIL_STATS
     const unsigned long long t_start = __builtin_readcyclecounter();
@@ -2260,7 +2277,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
     auto put = [&](int k, float v) { mine[k * kRenderBlock] = v; };
     auto get = [&](int k) { return mine[k * kRenderBlock]; };
 
-    ChunkCursor cur; cur.home = xcc_id(); cur.tries = 0;
+    ChunkCursor cur; cur.home = xcc_id(); cur.tries = 0; cur.n_positions = it.n_positions;
     next_chunk(cur, it);
     unsigned int ring_head = 0, ring_n = 0;                   // wave-uniform
     unsigned int spill_head = 0, spill_n = 0;                 // wave-uniform: the wave's spill queue, records [w kSpill, (w + 1) kSpill) of it.spill
@@ -2892,10 +2909,14 @@ namespace {
 // Quads by decreasing recorded cost, in 256 cost classes (order inside a class does not matter): one workgroup,
 // LDS histogram, scan, scatter.  n is a few thousand to a few ten thousand.  Every cost is read ONCE and its class
 // kept in `cls`, so the result is a permutation even if somebody were still adding to the costs.
-__global__ void __launch_bounds__(1024) quad_order_kernel(const unsigned int *cost, unsigned int *order, unsigned int *cls, unsigned int n)
+// tail_start (optional): the first position of the order's TAIL -- the cheapest classes that together hold at most tail_permille
+// thousandths of the recorded cost (the quads without any cost among them), rounded up to a multiple of 8 positions.
+__global__ void __launch_bounds__(1024) quad_order_kernel(const unsigned int *cost, unsigned int *order, unsigned int *cls, unsigned int n,
+                                                          unsigned int *tail_start, unsigned int tail_permille)
 {
     __shared__ unsigned int hist[256], start[256], top;
-    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+    __shared__ unsigned long long class_cost[256];
+    if (threadIdx.x < 256) { hist[threadIdx.x] = 0; class_cost[threadIdx.x] = 0ull; }
     if (threadIdx.x == 0) top = 1;
     __syncthreads();
     unsigned int mine = 0;
@@ -2904,24 +2925,36 @@ __global__ void __launch_bounds__(1024) quad_order_kernel(const unsigned int *co
     __syncthreads();
     const unsigned long long scale = top;
     for (unsigned int i = threadIdx.x; i < n; i += 1024) {                 // a thread revisits only its own elements
-        const unsigned int b = 255u - (unsigned int)(((unsigned long long)cls[i] * 255ull) / scale);   // 0 = most expensive
+        const unsigned int c = cls[i];
+        const unsigned int b = 255u - (unsigned int)(((unsigned long long)c * 255ull) / scale);   // 0 = most expensive
         cls[i] = b;
         atomicAdd(&hist[b], 1u);
+        if (tail_start && c) atomicAdd(&class_cost[b], (unsigned long long)c);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int run = 0;
         for (int b = 0; b < 256; ++b) { start[b] = run; run += hist[b]; }
+        if (tail_start) {
+            unsigned long long total = 0, tail = 0;
+            for (int b = 0; b < 256; ++b) total += class_cost[b];
+            int cut = 256;                                     // classes cut .. 255 are the tail
+            while (cut > 0 && (tail + class_cost[cut - 1]) * 1000ull <= total * (unsigned long long)tail_permille) { --cut; tail += class_cost[cut]; }
+            unsigned int t = (cut < 256 && total) ? start[cut] : n;
+            t = (t + 7u) & ~7u;
+            *tail_start = t < n ? t : n;
+        }
     }
     __syncthreads();
     for (unsigned int i = threadIdx.x; i < n; i += 1024) order[atomicAdd(&start[cls[i]], 1u)] = i;
 }
 }  // namespace
 
-hipError_t launch_quad_order(const unsigned int *cost, unsigned int *order, unsigned int *cls, unsigned int n, hipStream_t stream)
+hipError_t launch_quad_order(const unsigned int *cost, unsigned int *order, unsigned int *cls, unsigned int n, unsigned int *tail_start,
+                             unsigned int tail_permille, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(quad_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, cls, n);
+    hipLaunchKernelGGL(quad_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, cls, n, tail_start, tail_permille);
     return hipGetLastError();
 }
 
@@ -3073,6 +3106,20 @@ hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t s
     return hipGetLastError();
 }
 
+// The per-pixel chain kernel as the TAIL of a stream-form launch: a grid over every dispatch position whose workgroups start at
+// *first_position (RenderArgs.first_position); no sample chunks; stream_iterations is the stream form's to clear.
+hipError_t launch_render_streams_tail(const RenderArgs &a, const unsigned int *first_position, hipStream_t stream)
+{
+    if (!tiles_pay(a) || !first_position) return hipSuccess;
+    RenderArgs b = a;
+    b.spp_chunks = 1; b.first_position = first_position;
+    const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
+    const dim3 grid(tile_grid(a, 8)), block(kRenderBlock);
+    if (lds > kMaxSceneLds) hipLaunchKernelGGL((render_streams_kernel<false, 8>), grid, block, 0, stream, b);
+    else                    hipLaunchKernelGGL((render_streams_kernel<true, 8>), grid, block, lds, stream, b);
+    return hipGetLastError();
+}
+
 // workgroups (per copy of the grid) of the tree walk = records' worth of RenderArgs.tree_stack: x kTreeFastLevels x 64 lanes x 64 B
 unsigned int tree_workgroups(int width, int rows_local)
 {
@@ -3169,12 +3216,12 @@ hipError_t launch_streams_primary(const RenderArgs &a, HitList hits, unsigned in
     return hipGetLastError();
 }
 
-hipError_t launch_streams_advance_missed(const RenderArgs &a, HitList hits, int draws, hipStream_t stream)
+hipError_t launch_streams_advance_missed(const RenderArgs &a, HitList hits, int draws, const unsigned int *tail_start, hipStream_t stream)
 {
     if (hits.n_regions == 0 || draws <= 0) return hipSuccess;
     const dim3 g(hits.n_regions / 4u), b(256);
-    if (tiles_pay(a)) hipLaunchKernelGGL((streams_advance_missed_kernel<true>), g, b, 0, stream, a, hits, draws);
-    else              hipLaunchKernelGGL((streams_advance_missed_kernel<false>), g, b, 0, stream, a, hits, draws);
+    if (tiles_pay(a)) hipLaunchKernelGGL((streams_advance_missed_kernel<true>), g, b, 0, stream, a, hits, draws, tail_start);
+    else              hipLaunchKernelGGL((streams_advance_missed_kernel<false>), g, b, 0, stream, a, hits, draws, tail_start);
     return hipGetLastError();
 }
 
