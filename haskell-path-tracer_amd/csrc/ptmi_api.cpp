@@ -330,11 +330,13 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
         int passes = 1;
         if (c->opt_ordered_passes > 0) passes = c->opt_ordered_passes;
         else if (c->opt_batch > 0) passes = (n_spp + c->opt_batch - 1) / c->opt_batch;     // PTMI_OPT_STREAM_BATCH: samples per item
-        else if (n < 8ull * lanes && n_spp >= 256) passes = n_spp / 64 < 8 ? n_spp / 64 : 8;
+        else if (n < 3ull * lanes && n_spp >= 256) passes = n_spp / 64 < 8 ? n_spp / 64 : 8;
         // (few, LONG items per lane: items of >= 64 samples, at most 8 passes.  The kernel of the ordered passes is 3 % slower per trip
         // than the one-pass kernel, and an item costs its refill and its seven stores.  1080p, S16, ms with 1 / 2 / 4 / 8 / 16 / 32 passes:
         // 64 spp 4.46 / 4.62 / 4.63 / 4.84 / 4.83 / 4.86; 256 spp 17.49 / 17.24 / 16.99 / 17.11 / 17.70 / 18.96; 1024 spp 69.7 / 68.1 / 66.0 /
-        // 64.9 / 65.3 / 66.8.)
+        // 64.9 / 65.3 / 66.8.  With the per-pixel tail below, which only a one-pass launch has, the whole 1080p image -- 4.5 pixels per lane --
+        // is better off in one pass: 256 spp 16.60 against 17.19 ms with four passes, 512 spp 32.86 against 33.48, 1024 spp equal; one of 8
+        // parts of a 4K image -- 2.3 pixels per lane -- is not: 1024 spp 38.98 against 36.10 with eight passes.  Hence 3 pixels per lane.)
         if (passes > 64) passes = 64;
         const int most = n_spp / streams_min_pass_samples();   // a pass holds at least that many samples
         if (passes > most) passes = most;

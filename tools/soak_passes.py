@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """soak_passes.py [launches] -- the ordered passes of the stream form under load: C2's image (1920x1080, 64 spp, S16) rendered by
-the per-pixel chain kernel and, with the same seeds, by the stream form with the pixels' sample chains cut into 64, 32, 16, 8 and 4
-ordered passes in turn (items of 1, 2, 4, 8, 16 samples: up to 130 million hand-offs per launch, lane to lane through the planes,
-write-through stores + counter + sc1 loads), while a third context renders render Inline on a stream of its own beside them.
+the per-pixel chain kernel and, with the same seeds, by the stream form: in turn as whole sample chains (one pass, the cheap end of
+the dispatch order rendered by the chain kernel beside the persistent launch) and with the chains cut into 64, 32, 16, 8 and 4 ordered
+passes (items of 1, 2, 4, 8, 16 samples: up to 130 million hand-offs per launch, lane to lane through the planes, write-through stores
++ counter + sc1 loads), while a third context renders render Inline on a stream of its own beside them.
 Every launch: all seven planes of the two forms compared bit for bit.  Prints one JSON line."""
 import json
 import os
@@ -31,7 +32,7 @@ def main():
         stream.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
         hits = None
         for k in range(launches):
-            batch = (1, 2, 4, 8, 16)[k % 5]
+            batch = (0, 1, 2, 4, 8, 16)[k % 6]              # 0: whole sample chains, with the per-pixel tail beside the persistent launch
             stream.set_option(B.OPT_STREAM_BATCH, batch)
             noise.render(cam, 8, 64, pkg.INLINE)                  # asynchronous: runs beside the two below
             chain.render(cam, 8, 64, pkg.STREAMS)
@@ -44,10 +45,10 @@ def main():
                     sys.exit(1)
             if hits is None:
                 hits = int(np.count_nonzero(np.asarray(a[0]) != 0.0))   # a lower bound of the pixels with a start hit: those whose colour is not zero after one launch
-            handoffs += hits * (64 // batch - 1)
+            handoffs += hits * (64 // batch - 1) if batch else 0
             if k % 10 == 9:
                 print("launch %d ok" % (k + 1), file=sys.stderr, flush=True)
-    print(json.dumps({"ok": True, "launches": launches, "image": "1920x1080, 64 spp, S16", "samples_per_item_cycle": [1, 2, 4, 8, 16],
+    print(json.dumps({"ok": True, "launches": launches, "image": "1920x1080, 64 spp, S16", "samples_per_item_cycle": ["all (one pass, per-pixel tail)", 1, 2, 4, 8, 16],
                       "handoffs_between_lanes_at_least": handoffs, "compared": "all seven planes, bit for bit, against the per-pixel chain kernel, every launch",
                       "beside": "a third context rendering render Inline on its own stream"}))
 
