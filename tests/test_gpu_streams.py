@@ -218,15 +218,17 @@ def test_stream_iterations_is_per_launch(ctx, pkg, ora, stream_form):
     assert deep > 200 and 1 <= shallow < 64
 
 
-def test_stream_form_with_ordered_passes_on_the_parts_of_a_striped_image(pkg):
+@pytest.mark.parametrize("spp", [256, 32])
+def test_stream_form_on_the_parts_of_a_striped_image(pkg, spp):
     """What one rank of a multi-GPU job renders through the stream form: a part of a row-striped image (8 parts, 10-row
-    stripes) at a sample count where the form cuts the pixels' sample chains into ordered passes by itself (few, long items per
-    lane: 256 spp -> 4 passes).  Every part: all seven planes bit-identical to the per-pixel chain kernel on the same part, which
+    stripes) -- at 256 spp, where the form cuts the pixels' sample chains into ordered passes by itself (few, long items per lane:
+    4 passes), and at 32 spp, where a pixel's chain is one item and the second launch leaves the cheap end of the part's dispatch
+    order to the per-pixel kernel.  Every part: all seven planes bit-identical to the per-pixel chain kernel on the same part, which
     the oracle pins; the parts together hold every row of the image once."""
     B = pkg.binding
     sp, pl = pkg.world.scene16()
     cam = pkg.world.initial_camera()
-    w, h, spp, n_parts, stripe = 1280, 720, 256, 8, 10
+    w, h, n_parts, stripe = 1280, 720, 8, 10
     rows_seen = 0
     for part in (0, 3, 7):
         with pkg.Context(0) as chain, pkg.Context(0) as stream:
@@ -237,10 +239,10 @@ def test_stream_form_with_ordered_passes_on_the_parts_of_a_striped_image(pkg):
                 c.init_output(0xC0FFEE)
             stream.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
             assert chain.local_rows == stream.local_rows == h // n_parts
-            for launch in range(2):
+            for launch in range(3):
                 chain.render(cam, 8, spp, pkg.STREAMS)
                 stream.render(cam, 8, spp, pkg.STREAMS)
-                assert_planes_equal(stream.download_state(), chain.download_state(), "part %d of %d, launch %d" % (part, n_parts, launch))
+                assert_planes_equal(stream.download_state(), chain.download_state(), "part %d of %d, %d spp, launch %d" % (part, n_parts, spp, launch))
             assert stream.stats()["live_bounces"] == chain.stats()["live_bounces"]
             rows_seen += stream.local_rows
     assert rows_seen == 3 * (h // n_parts)
