@@ -54,7 +54,7 @@ struct ptmi_ctx {
     hipStream_t tail_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned int *d_tail_start = nullptr;
-    int opt_tail_permille = 150;               // thousandths of the recorded cost the tail may hold (PTMI_STREAM_TAIL in the environment; 0 = no tail)
+    int opt_tail_permille = -1;                // thousandths of the recorded cost the tail may hold (PTMI_STREAM_TAIL in the environment; 0 = no tail; -1 = automatic)
     bool ev_valid = false;
     int variant = 0;
     Stager stager;                          // pinned ring + worker threads for host-buffer entry points (ptmi_stage.h)
@@ -350,7 +350,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
         // by the same arithmetic: no result depends on where the boundary lies.
         // (Only while a pixel's samples are ONE item: where they are cut into ordered passes the end of the launch is short already, and a
         // tail wave would render its tile's many samples in one piece -- 1080p / 256 spp: 16.99 ms with four passes, 17.86 with a tail beside them.)
-        const unsigned int *tail = (passes == 1 && c->opt_tail_permille > 0 && a.quad_order && c->d_tail_start && quad_positions(a.width, a.rows_local) > 0) ? c->d_tail_start : nullptr;
+        const unsigned int *tail = (passes == 1 && c->opt_tail_permille != 0 && a.quad_order && c->d_tail_start && quad_positions(a.width, a.rows_local) > 0) ? c->d_tail_start : nullptr;
         if (tail && !c->tail_stream) {
             int least = 0, greatest = 0;
             PTMI_HIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -555,9 +555,14 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
             PTMI_HIP(c, hipMemsetAsync(c->d_quad_cost, 0, n_quads * sizeof(unsigned int), c->stream));
             PTMI_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->d_tail_start), (int)n_quads, 1, c->stream));   // no tail yet
         } else if ((launches & (launches - 1)) == 0 && launches < (1 << 20)) {
-            // (the stream form: the order kernel also says where the order's cheap end begins -- render_streams_wavefront)
+            // (the stream form: the order kernel also says where the order's cheap end begins -- render_streams_wavefront.  How much of the
+            // recorded cost that end may hold: 15 % where a lane sees four pixels or more, 40 % where it sees fewer -- 1280x720 / 64 spp: 2.34 ms
+            // with 15 %, 2.16 with 40 %, chain kernel 1.96; 1080p: 4.24 / 4.21.)
+            const unsigned long long lanes_full = 64ull * (unsigned long long)(c->cus > 0 ? c->cus : 256) * 4ull * (unsigned long long)streams_pixels_waves();
+            const unsigned int tail_permille = c->opt_tail_permille >= 0 ? (unsigned int)c->opt_tail_permille
+                                             : ((unsigned long long)width * (unsigned long long)rows_local < 4ull * lanes_full ? 400u : 150u);
             PTMI_HIP(c, launch_quad_order(c->d_quad_cost, c->d_quad_order, c->d_quad_class, n_quads, stream_form ? c->d_tail_start : nullptr,
-                                          (unsigned int)(c->opt_tail_permille > 0 ? c->opt_tail_permille : 0), c->stream));
+                                          tail_permille, c->stream));
             ++c->order_generation;
         }
         if (launches > 0) a.quad_order = c->d_quad_order;
