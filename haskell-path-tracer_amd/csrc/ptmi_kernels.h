@@ -1,4 +1,4 @@
-// ptmi_kernels.h -- launch interface between the C ABI (ptmi_api.cpp) and the gfx950 kernels.
+// ptmi_kernels.h -- launch interface between the C ABI (ptmi_api.cpp) and the gfx950 kernels (ptmi_*.hip, one unit per kernel family).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -166,10 +166,20 @@ unsigned int streams_first_block();   // output slots every wave of a level owns
 
 hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t stream);
 bool variant_available(int variant);     // ablation variants exist only in builds with -DPTMI_ABLATIONS
+hipError_t launch_render_inline_ablation(const RenderArgs &a, int variant, bool big_scene, hipStream_t stream);   // ptmi_inline_ablations.hip (-DPTMI_ABLATIONS)
 hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t stream);
 hipError_t launch_render_streams_tree(const RenderArgs &a, int variant, hipStream_t stream);   // scenes with GLASS: per-pixel tree walk
 unsigned int tree_workgroups(int width, int rows_local);   // workgroups per copy of its grid (RenderArgs.tree_stack holds kTreeFastLevels x 64 records of 64 B for each)
-unsigned int quad_positions(int width, int rows_local);                    // entries of quad_order / quad_cost (0 = tiles not used)
+// 8x8 tiles leave lanes idle on the right and bottom edges; rows of 64 leave them idle at the end only
+inline bool tiles_pay_dims(int width, int rows_local) { return width >= 64 && rows_local >= 16; }
+inline bool tiles_pay(const RenderArgs &a) { return tiles_pay_dims(a.width, a.rows_local); }
+// entries of quad_order / quad_cost (0 = tiles not used): the tile grid padded to a multiple of 32 (lane_pixel), four tiles to a quad
+inline unsigned int quad_positions(int width, int rows_local)
+{
+    if (!tiles_pay_dims(width, rows_local)) return 0;
+    const unsigned int tiles = (unsigned int)(((width + 7) / 8) * ((rows_local + 7) / 8));
+    return ((tiles + 31u) & ~31u) / 4u;
+}
 hipError_t launch_quad_order(const unsigned int *cost, unsigned int *order, unsigned int *cls, unsigned int n, unsigned int *tail_start,
                              unsigned int tail_permille, hipStream_t stream);
 bool uses_quad_order(const RenderArgs &a, int algorithm_inline, int variant);

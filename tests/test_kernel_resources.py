@@ -20,8 +20,8 @@ def resources(tmp_path_factory):
 # kernel -> (VGPRs for its waves per SIMD, scratch bytes, static LDS bytes, scratch loads, scratch stores).  The few scratch
 # instructions allowed are spills AROUND a render loop and around the rare call of the literal fold (check_hit_exact).
 BUDGETS = {
-    "render_inline_kernel<true, 0, 8>": (72, 32, 2560, 4, 4),          # 7 waves/SIMD
-    "render_inline_kernel<false, 0, 8>": (72, 32, 2560, 6, 6),         # scene through scalar loads (big scenes)
+    "render_inline_kernel<true, 8>": (72, 32, 2560, 4, 4),          # 7 waves/SIMD
+    "render_inline_kernel<false, 8>": (72, 32, 2560, 6, 6),         # scene through scalar loads (big scenes)
     "render_streams_kernel<true, 8>": (72, 32, 2816, 3, 3),            # 7 waves/SIMD
     "render_streams_kernel<false, 8>": (72, 32, 2816, 3, 3),
     "render_streams_tree_kernel<true, 8>": (80, 12 * 14 * 4 + 64, 5120, 8, 12),   # 6 waves/SIMD; waiting children: the first 4 per lane as global 64-byte records, the rest in scratch (12 entries x 14 words); three values spilled around the shade

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""isa_spills.py KERNEL_SUBSTRING [N] -- after tools/kernel_resources.py has written build/isa/kernels.s: where the N-th kernel
-whose mangled name contains the substring touches scratch memory (line within the kernel, basic block, instruction)."""
+"""isa_spills.py KERNEL_SUBSTRING [N] -- after tools/kernel_resources.py has written build/isa/*.s (one per unit): where the N-th
+kernel whose mangled name contains the substring touches scratch memory (line within the kernel, basic block, instruction)."""
 import os
 import re
 import sys
@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def body_of(sub, nth=0):
-    t = open(os.path.join(ROOT, "build", "isa", "kernels.s")).read().split("\n")
+    import glob
+    t = "\n".join(open(f).read() for f in sorted(glob.glob(os.path.join(ROOT, "build", "isa", "*.s")))).split("\n")
     starts = [i for i, l in enumerate(t) if l.startswith("_ZN") and sub in l and l.split(":")[0].endswith("E") and ":" in l and not l.startswith("\t")]
     start = starts[nth]
     end = next(i for i in range(start, len(t)) if "s_endpgm" in t[i])
