@@ -14,6 +14,7 @@ from . import _build
 from .world import CAMERA_DTYPE, PLANE_DTYPE, SPHERE_DTYPE, INLINE, STREAMS
 
 OPT_STREAMS_SEED_RULE, OPT_STREAM_STEP_CAP, OPT_STREAM_CAPACITY, OPT_STREAMS_FORM, OPT_STREAM_BATCH, OPT_SPP_CHUNKS, OPT_ARITHMETIC = 1, 2, 3, 4, 5, 6, 7
+OPT_STREAM_TAIL, OPT_ORDERED_PASSES, OPT_GLASS_BATCH, OPT_STREAM_GRADED = 8, 9, 10, 11
 ARITH_EXACT, ARITH_CONTRACTED = 0, 1
 SEED_KEEP_ACCUMULATOR, SEED_FROM_RESULT, SEED_AUTO = 0, 1, 2
 FORM_AUTO, FORM_STREAM = 0, 1
@@ -81,6 +82,8 @@ SYMBOLS = {
     "ptmi_partition_global_row": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ptmi_reset_stats": (C.c_int, [_vp]),
     "ptmi_debug_counters": (C.c_int, [_vp, _vp]),
+    "ptmi_order_schedule": (C.c_int, [C.c_int, C.c_int, _i32p, _i32p]),
+    "ptmi_stream_schedule": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, _vp, C.c_int]),
     "ptmi_eval_distance_to_sphere": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "ptmi_eval_distance_to_plane": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "ptmi_eval_sincos": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
@@ -115,6 +118,15 @@ def load_library(path=None):
         return _lib
     _lib = open_library(path or _build.LIB)
     return _lib
+
+
+def stream_schedule(n_spp, n_pixels, lanes, batch=0, graded=True):
+    """ptmi_stream_schedule: the first sample of every pass of the stream form's split kernel, and n_spp behind them (host arithmetic)."""
+    first = np.zeros(65, np.int32)
+    passes = load_library().ptmi_stream_schedule(int(n_spp), int(n_pixels), int(lanes), int(batch), 1 if graded else 0, _ptr(first), 65)
+    if passes < 0:
+        raise PtmiError(passes, "ptmi_stream_schedule")
+    return [int(v) for v in first[:passes + 1]]
 
 
 def _ptr(a):
@@ -307,7 +319,7 @@ class Context:
         return {f: getattr(st, f) for f, _ in Stats._fields_}
 
     def debug_counters(self):
-        out = np.zeros(64, np.uint32)
+        out = np.zeros(256, np.uint32)
         self._check(self._lib.ptmi_debug_counters(self._h, _ptr(out)))
         return out
 

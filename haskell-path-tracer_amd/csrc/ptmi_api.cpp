@@ -54,7 +54,7 @@ struct ptmi_ctx {
     hipStream_t tail_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned int *d_tail_start = nullptr;
-    int opt_tail_permille = -1;                // thousandths of the recorded cost the tail may hold (PTMI_STREAM_TAIL in the environment; 0 = no tail; -1 = automatic)
+    int opt_tail_permille = -1;                // PTMI_OPT_STREAM_TAIL: thousandths of the recorded cost the tail may hold (0 = no tail; -1 = automatic; PTMI_STREAM_TAIL in the environment overrides at creation)
     bool ev_valid = false;
     int variant = 0;
     Stager stager;                          // pinned ring + worker threads for host-buffer entry points (ptmi_stage.h)
@@ -91,11 +91,14 @@ struct ptmi_ctx {
     void *d_snapshots = nullptr;     // stream form, split kernel: the seed every item starts from
     size_t snapshot_bytes = 0;
     int cus = 0;                     // compute units of the device (persistent grids)
+    size_t device_memory = (size_t)64 << 30;   // bytes of the device (budget of the stream form's seed snapshots)
     void *tree_stack = nullptr;      // tree walk: the lanes' first waiting children (RenderArgs.tree_stack)
     size_t tree_stack_bytes = 0;
     unsigned int *d_region_done = nullptr;   // stream form, ordered passes: items published per region
     unsigned int region_done_words = 0;
-    int opt_ordered_passes = 0;      // 0 = automatic (experiments: PTMI_ORDERED_PASSES in the environment)
+    int opt_ordered_passes = 0;      // PTMI_OPT_ORDERED_PASSES: 0 = automatic, 1 = off, k = k passes (PTMI_ORDERED_PASSES in the environment overrides at creation)
+    int *d_pass_first = nullptr;     // stream form, split kernel: the samples of every pass (ItemArgs.pass_first), kMaxStreamPasses + 1 entries
+    std::vector<int> pass_first_host;   // ... what the device block holds
     unsigned int *d_qcount = nullptr;
     uint64_t rays_dropped = 0;
     uint64_t rays_truncated = 0;
@@ -114,6 +117,8 @@ struct ptmi_ctx {
     int opt_batch = 0;
     int opt_spp_chunks = 0;                    // 0 = automatic
     int opt_arithmetic = PTMI_ARITH_EXACT;
+    int opt_glass_batch = 0;                   // PTMI_OPT_GLASS_BATCH: 0 = automatic, 1 = off, k = GLASS hits wait until k are pending in their wave
+    int opt_graded = 1;                        // PTMI_OPT_STREAM_GRADED: the split kernel's passes shrink towards the end of the launch
 };
 
 namespace {
@@ -252,6 +257,7 @@ void pack_scene(const ptmi_sphere *sph, int ns, const ptmi_plane *pl, int np, st
 }
 
 constexpr size_t kLiveBytes = (size_t)kStatShards * kStatStride * sizeof(unsigned long long);     // sharded statistics (ptmi_kernels.h)
+constexpr int kGlassBatchDefault = 1;      // PTMI_OPT_GLASS_BATCH = 0 (automatic): parking off -- see the measurements in DESIGN.md 5.5
 constexpr size_t kItersBytes = (size_t)kStatShards * 2 * kStatStride * sizeof(unsigned int);
 
 RayQueue carve_queue(void *block, size_t capacity, int which)
@@ -260,6 +266,64 @@ RayQueue carve_queue(void *block, size_t capacity, int which)
     q.base = static_cast<uint32_t *>(block) + (size_t)which * kRayQueueWords * capacity;
     q.capacity = (unsigned int)capacity;
     return q;
+}
+
+// The schedule of the cost-ordered dispatch: `launches` = launches made so far with one (camera, scene, shape, limit, algorithm).
+// Every launch below the limit RECORDS its costs (the sums stay far from 2^32); the order is REBUILT from them before launch 1, 2, 4,
+// 8, ... -- and never again once the limit is reached: the state stops there, it is a power of two itself, and a rebuild bumps the
+// order's generation, which would make the stream form re-run its primary kernel on every later call of a standing camera.
+int order_schedule(int launches, int stream_form, int *rebuild, int *record)
+{
+    const int limit = stream_form ? (1 << 11) : (1 << 20);
+    const bool below = launches >= 0 && launches < limit;
+    if (rebuild) *rebuild = (below && launches > 0 && (launches & (launches - 1)) == 0) ? 1 : 0;
+    if (record) *record = below ? 1 : 0;
+    return below ? launches + 1 : limit;
+}
+
+// The passes of the stream form's split kernel: which samples of its pixels pass p renders (first[p] .. first[p + 1]).
+// A pass is one item per start hit, taken by whatever lane is free, and the launch ends as its LAST items do: with uniform
+// passes of 16 samples the waves of a 1080p / 64-spp glass launch ended anywhere between 75 % and 98 % of it (a wave holds 64
+// items of very different weight when the tickets run out) -- an eighth of the chip's wave-time idle.  So the passes are GRADED
+// (guided self-scheduling): at most `per_item` samples -- the size that gives a lane its ~16 items -- and never more than a
+// fraction of what is still to come, chosen so that an item five times the mean weight, taken when its pass begins, is over
+// before the remaining passes are: the last passes are single samples, and the end of the launch is as long as one sample's tree.
+// Which sample belongs to which pass changes no seed (snapshots) and no ray; only the order of a pixel's float additions,
+// which the stream form with GLASS does not define anyway.  Returns the number of passes (<= kMaxStreamPasses).
+constexpr int kMaxStreamPasses = 64;
+int stream_schedule(int n_spp, unsigned long long n_px, unsigned long long lanes, int batch, bool graded, int first[kMaxStreamPasses + 1])
+{
+    first[0] = 0;
+    if (n_spp <= 0 || n_px == 0 || lanes == 0) { first[1] = n_spp > 0 ? n_spp : 0; return 1; }
+    int per_item = batch;
+    if (per_item <= 0) {                                      // a lane should see ~16 items
+        const double items_wanted = 16.0 * (double)lanes;
+        int passes = (int)(items_wanted / (double)n_px + 0.999);
+        if (passes < 1) passes = 1;
+        if (passes > kMaxStreamPasses) passes = kMaxStreamPasses;
+        per_item = (n_spp + passes - 1) / passes;
+        if (per_item < 8) per_item = n_spp < 8 ? n_spp : 8;
+    }
+    if (per_item > n_spp) per_item = n_spp;
+    if ((n_spp + per_item - 1) / per_item > kMaxStreamPasses) per_item = (n_spp + kMaxStreamPasses - 1) / kMaxStreamPasses;
+    int passes = 0, done = 0;
+    if (!graded) {
+        while (done < n_spp) { done = done + per_item < n_spp ? done + per_item : n_spp; first[++passes] = done; }
+        return passes;
+    }
+    const double f = ((double)n_px / (double)lanes) / 5.0;     // items per lane and pass / the weight of a heavy item
+    double frac = f / (1.0 + f);
+    frac = frac < 0.2 ? 0.2 : (frac > 0.5 ? 0.5 : frac);
+    while (done < n_spp) {
+        const int left = n_spp - done;
+        int size = (int)((double)left * frac + 0.999999);
+        if (size > per_item) size = per_item;
+        const int passes_left = kMaxStreamPasses - passes;     // never more than kMaxStreamPasses passes: a pass takes at least its share of what is left
+        const int share = (left + passes_left - 1) / passes_left;
+        if (size < share) size = share;
+        done += size; first[++passes] = done;
+    }
+    return passes;
 }
 
 // `render Streams` as a stream ("wavefront" form, ptmi_kernels.hip).  Every sample of a pixel shoots the same primary ray: its
@@ -328,7 +392,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
         const unsigned int grid_full = (unsigned int)(cus * 4 * streams_pixels_waves());
         const unsigned long long lanes = 64ull * grid_full;
         int passes = 1;
-        if (c->opt_ordered_passes > 0) passes = c->opt_ordered_passes;
+        if (c->opt_ordered_passes > 0) passes = c->opt_ordered_passes;    // (1 = off: one pass, no hand-off between waves inside the launch)
         else if (c->opt_batch > 0) passes = (n_spp + c->opt_batch - 1) / c->opt_batch;     // PTMI_OPT_STREAM_BATCH: samples per item
         else if (n < 3ull * lanes && n_spp >= 256) passes = n_spp / 64 < 8 ? n_spp / 64 : 8;
         // (few, LONG items per lane: items of >= 64 samples, at most 8 passes.  The kernel of the ordered passes is 3 % slower per trip
@@ -389,20 +453,16 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
     }
 
     // ---- rays may split, or the samples of a pixel run as unordered items
+    if (quad_positions(a.width, a.rows_local) > (1u << 21)) a.quad_cost = nullptr;      // (the item record keeps the quad in 21 bits: no costs beyond 2^29 pixels)
     unsigned int grid = (unsigned int)(cus * 4 * streams_split_waves());
-    // samples per item: a pixel's samples are cut into items so that a lane sees ~16 of them (the end of the launch is as
-    // long as the last items); PTMI_OPT_STREAM_BATCH sets the figure
-    int per_item = c->opt_batch;
-    if (per_item <= 0) {
-        const double items_wanted = 16.0 * 64.0 * (double)grid;
-        int passes = (int)(items_wanted / (double)n + 0.999);
-        if (passes < 1) passes = 1;
-        if (passes > 64) passes = 64;
-        per_item = (n_spp + passes - 1) / passes;
-        if (per_item < 8) per_item = n_spp < 8 ? n_spp : 8;
+    // the passes: graded items, long first and single samples last (stream_schedule above); PTMI_OPT_STREAM_BATCH caps an item's samples
+    int first[kMaxStreamPasses + 1];
+    int passes = stream_schedule(n_spp, n, 64ull * grid, c->opt_batch, c->opt_graded != 0, first);
+    {   // the seed snapshots are passes x pixels x 16 bytes: within an eighth of the device's memory, merging the LAST passes if need be
+        const size_t budget = c->device_memory / 8;
+        while (passes > 1 && (size_t)passes * n * sizeof(uint4) > budget) { --passes; first[passes] = n_spp; }
+        if ((size_t)passes * n * sizeof(uint4) > budget) return fail(c, PTMI_ELIMIT, "seed snapshots of the stream form would exceed an eighth of the device's memory");
     }
-    if (per_item > n_spp) per_item = n_spp;
-    const int passes = (n_spp + per_item - 1) / per_item;
     const unsigned long long n_tickets = (unsigned long long)n_regions * (region_slots / 64u) * (unsigned long long)passes;
     if (n_tickets > 0x7fffffffull) return fail(c, PTMI_ELIMIT, "too many items for the stream form of Streams");
     if (grid > n_tickets) grid = (unsigned int)n_tickets;
@@ -437,8 +497,19 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
     }
     std::vector<unsigned int> base((size_t)kLvMaxLevels, 0u);   // per level (mod kLvMaxLevels): where its reserved blocks start
 
-    PTMI_HIP(c, launch_streams_seeds(a.planes, static_cast<uint4 *>(c->d_snapshots), (long long)n, passes, per_item, n_spp, c->stream));
-    it.passes = passes; it.samples_per_pass = per_item;
+    {   // the pass table on the device: rewritten only when the schedule changes
+        const std::vector<int> table(first, first + passes + 1);
+        if (!c->d_pass_first) PTMI_HIP(c, hipMalloc(&c->d_pass_first, (size_t)(kMaxStreamPasses + 1) * sizeof(int)));
+        if (table != c->pass_first_host) {
+            PTMI_HIP(c, hipStreamSynchronize(c->stream));      // (an earlier launch may still be reading the old table)
+            PTMI_HIP(c, hipMemcpy(c->d_pass_first, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice));
+            c->pass_first_host = table;
+        }
+    }
+    PTMI_HIP(c, launch_streams_seeds(a.planes, static_cast<uint4 *>(c->d_snapshots), (long long)n, passes, c->d_pass_first, c->stream));
+    it.passes = passes; it.pass_first = c->d_pass_first;
+    // GLASS hits wait in their lanes until that many are pending in the wave (measured: DESIGN.md 5.5); nothing to wait for without GLASS
+    it.glass_batch = !c->has_glass ? 0 : (c->opt_glass_batch > 0 ? c->opt_glass_batch : kGlassBatchDefault);
     it.chunk_cursor = tickets_of(0);
     it.seed_snapshots = static_cast<const uint4 *>(c->d_snapshots);
     it.spill = carve_queue(c->spill_block, c->spill_capacity, 0);
@@ -550,11 +621,13 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
         // order_state counts the launches made with this key.  Every launch adds its costs (a 1-spp launch says little
         // on its own: the compat entry renders one sample per call); the order is rebuilt before launch 1, 2, 4, 8, ...
         const int launches = c->order_state;
+        int rebuild = 0, record = 0;
+        const int state_after = order_schedule(launches, stream_form ? 1 : 0, &rebuild, &record);
         if (!c->d_tail_start) PTMI_HIP(c, hipMalloc(&c->d_tail_start, 64));
         if (launches == 0) {
             PTMI_HIP(c, hipMemsetAsync(c->d_quad_cost, 0, n_quads * sizeof(unsigned int), c->stream));
             PTMI_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->d_tail_start), (int)n_quads, 1, c->stream));   // no tail yet
-        } else if ((launches & (launches - 1)) == 0 && launches < (1 << 20)) {
+        } else if (rebuild) {
             // (the stream form: the order kernel also says where the order's cheap end begins -- render_streams_wavefront.  How much of the
             // recorded cost that end may hold: 15 % where a lane sees four pixels or more, 40 % where it sees fewer -- 1280x720 / 64 spp: 2.34 ms
             // with 15 %, 2.16 with 40 %, chain kernel 1.96; 1080p: 4.24 / 4.21.)
@@ -566,7 +639,7 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
             ++c->order_generation;
         }
         if (launches > 0) a.quad_order = c->d_quad_order;
-        if (launches < (stream_form ? (1 << 11) : (1 << 20))) { a.quad_cost = c->d_quad_cost; next_order_state = launches + 1; }   // the sums stay far from 2^32
+        if (record) { a.quad_cost = c->d_quad_cost; next_order_state = state_after; }
     }
     if (per_pixel_kernel) {
         // one word per tile workgroup for the sample chunks of the tiled per-pixel kernels (ptmi_kernels.hip)
@@ -662,8 +735,10 @@ int ptmi_create(ptmi_ctx **out, int device)
     ptmi_ctx *c = new (std::nothrow) ptmi_ctx;
     if (!c) return fail(nullptr, PTMI_ENOMEM, "host allocation failed");
     c->device = device;
-    if (const char *e = std::getenv("PTMI_ORDERED_PASSES")) c->opt_ordered_passes = std::atoi(e);
-    if (const char *e = std::getenv("PTMI_STREAM_TAIL")) c->opt_tail_permille = std::atoi(e);     // thousandths of the cost; 0 = no tail
+    // Two environment OVERRIDES of options (PTMI_OPT_ORDERED_PASSES, PTMI_OPT_STREAM_TAIL), read once here, for experiments on a host
+    // program that cannot be rebuilt; values outside the options' ranges are ignored.  ptmi_get_option shows what is in force.
+    if (const char *e = std::getenv("PTMI_ORDERED_PASSES")) { const int v = std::atoi(e); if (v >= 0 && v <= 64) c->opt_ordered_passes = v; }
+    if (const char *e = std::getenv("PTMI_STREAM_TAIL")) { const int v = std::atoi(e); if (v >= -1 && v <= 1000) c->opt_tail_permille = v; }
     auto bail = [&](hipError_t err, const char *what) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);
         ptmi_destroy(c);
@@ -671,19 +746,23 @@ int ptmi_create(ptmi_ctx **out, int device)
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
     if ((e = hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return bail(e, "hipDeviceGetAttribute");
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) c->device_memory = total_b;
+    }
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     c->stream = c->own_stream;
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreateWithFlags(&c->ev_snap, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc(&c->d_live, kLiveBytes)) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipMalloc(&c->d_work, 64 * sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc(&c->d_work, kWorkWords * sizeof(unsigned int))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc(&c->d_iters, kItersBytes)) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc(&c->d_stream_counters, kScWords * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMemsetAsync(c->d_stream_counters, 0, kScWords * sizeof(unsigned long long), c->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
     // stream-ordered fills: the context's stream is non-blocking, so a NULL-stream hipMemset would race with it
     if ((e = hipMemsetAsync(c->d_live, 0, kLiveBytes, c->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
-    if ((e = hipMemsetAsync(c->d_work, 0, 64 * sizeof(unsigned int), c->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
+    if ((e = hipMemsetAsync(c->d_work, 0, kWorkWords * sizeof(unsigned int), c->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
     if ((e = hipMemsetAsync(c->d_iters, 0, kItersBytes, c->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
     *out = c;
@@ -699,6 +778,7 @@ void ptmi_destroy(ptmi_ctx *c)
     if (c->d_scene) (void)hipFree(c->d_scene);
     if (c->d_live) (void)hipFree(c->d_live);
     if (c->d_work) (void)hipFree(c->d_work);
+    if (c->d_pass_first) (void)hipFree(c->d_pass_first);
     if (c->d_iters) (void)hipFree(c->d_iters);
     if (c->d_stream_counters) (void)hipFree(c->d_stream_counters);
     if (c->scratch) (void)hipFree(c->scratch);
@@ -862,6 +942,21 @@ int ptmi_set_variant(ptmi_ctx *c, int variant)
     return PTMI_OK;
 }
 
+int ptmi_order_schedule(int launches, int stream_form, int *rebuild, int *record)
+{
+    return order_schedule(launches, stream_form, rebuild, record);
+}
+
+int ptmi_stream_schedule(int n_spp, uint64_t n_pixels, uint64_t lanes, int batch, int graded, int32_t *first, int capacity)
+{
+    if (n_spp < 0 || !first || capacity < 2) return PTMI_EINVAL;
+    int table[kMaxStreamPasses + 1];
+    const int passes = stream_schedule(n_spp, n_pixels, lanes, batch, graded != 0, table);
+    if (passes + 1 > capacity) return PTMI_ELIMIT;
+    for (int k = 0; k <= passes; ++k) first[k] = table[k];
+    return passes;
+}
+
 int ptmi_set_option(ptmi_ctx *c, int option, int64_t value)
 {
     if (!c) return PTMI_EINVAL;
@@ -888,6 +983,18 @@ int ptmi_set_option(ptmi_ctx *c, int option, int64_t value)
     case PTMI_OPT_ARITHMETIC:
         if (value != PTMI_ARITH_EXACT && value != PTMI_ARITH_CONTRACTED) return fail(c, PTMI_EINVAL, "unknown arithmetic mode");
         c->opt_arithmetic = (int)value; return PTMI_OK;
+    case PTMI_OPT_STREAM_TAIL:
+        if (value < -1 || value > 1000) return fail(c, PTMI_EINVAL, "stream tail must be -1 (automatic) or thousandths in [0, 1000]");
+        c->opt_tail_permille = (int)value; return PTMI_OK;
+    case PTMI_OPT_ORDERED_PASSES:
+        if (value < 0 || value > 64) return fail(c, PTMI_EINVAL, "ordered passes must be 0 (automatic), 1 (off) or k in [2, 64]");
+        c->opt_ordered_passes = (int)value; return PTMI_OK;
+    case PTMI_OPT_GLASS_BATCH:
+        if (value < 0 || value > 64) return fail(c, PTMI_EINVAL, "glass batch must be 0 (automatic), 1 (off) or k in [2, 64] lanes");
+        c->opt_glass_batch = (int)value; return PTMI_OK;
+    case PTMI_OPT_STREAM_GRADED:
+        if (value != 0 && value != 1) return fail(c, PTMI_EINVAL, "graded passes are on (1) or off (0)");
+        c->opt_graded = (int)value; return PTMI_OK;
     default: return fail(c, PTMI_EINVAL, "unknown option");
     }
 }
@@ -905,6 +1012,10 @@ int ptmi_get_option(ptmi_ctx *c, int option, int64_t *value)
     case PTMI_OPT_STREAM_BATCH:      *value = c->opt_batch; return PTMI_OK;
     case PTMI_OPT_SPP_CHUNKS: *value = c->opt_spp_chunks; return PTMI_OK;
     case PTMI_OPT_ARITHMETIC: *value = c->opt_arithmetic; return PTMI_OK;
+    case PTMI_OPT_STREAM_TAIL: *value = c->opt_tail_permille; return PTMI_OK;
+    case PTMI_OPT_ORDERED_PASSES: *value = c->opt_ordered_passes; return PTMI_OK;
+    case PTMI_OPT_GLASS_BATCH: *value = c->opt_glass_batch; return PTMI_OK;
+    case PTMI_OPT_STREAM_GRADED: *value = c->opt_graded; return PTMI_OK;
     default: return fail(c, PTMI_EINVAL, "unknown option");
     }
 }
@@ -1136,13 +1247,13 @@ int ptmi_get_stats(ptmi_ctx *c, ptmi_stats *out)
     return PTMI_OK;
 }
 
-int ptmi_debug_counters(ptmi_ctx *c, uint32_t out[64])
+int ptmi_debug_counters(ptmi_ctx *c, uint32_t out[256])
 {
     if (!c) return PTMI_EINVAL;
     std::lock_guard<std::mutex> lock(c->mu);
     if (!out) return fail(c, PTMI_EINVAL, "out is NULL");
     PTMI_HIP(c, hipSetDevice(c->device));
-    PTMI_HIP(c, hipMemcpyAsync(out, c->d_work, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    PTMI_HIP(c, hipMemcpyAsync(out, c->d_work, kWorkWords * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
     return PTMI_OK;
 }
@@ -1155,7 +1266,7 @@ int ptmi_reset_stats(ptmi_ctx *c)
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
     PTMI_HIP(c, hipMemsetAsync(c->d_live, 0, kLiveBytes, c->stream));
     PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, kItersBytes, c->stream));
-    PTMI_HIP(c, hipMemsetAsync(c->d_work, 0, 64 * sizeof(unsigned int), c->stream));
+    PTMI_HIP(c, hipMemsetAsync(c->d_work, 0, kWorkWords * sizeof(unsigned int), c->stream));
     PTMI_HIP(c, hipMemsetAsync(c->d_stream_counters, 0, kScWords * sizeof(unsigned long long), c->stream));
     c->nominal = 0; c->samples = 0; c->rays_dropped = 0; c->rays_truncated = 0; c->rays_spilled = 0; c->rays_overflowed = 0; c->live_host = 0;
     return PTMI_OK;

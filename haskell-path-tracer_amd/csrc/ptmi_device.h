@@ -477,6 +477,31 @@ __device__ __forceinline__ void glass_children(V3 color, GlassConstants gc, V3 p
     s_out[1] = seed;
 }
 
+// The REFRACTION child of a GLASS hit alone, for kernels that let the reflection child travel through the ordinary shade (the
+// stream form's split kernel): with ia = dot(d, n) and reflection = d - (2 ia) n in hand -- what the ordinary shade's bounce_axis
+// computes by the same operations -- and the seed already past genVec's three draws, this is glass_children's k, Schlick weight R,
+// refraction direction and second child (origin, direction, throughput throughput * (color ^* (1 - R)), seed one draw further),
+// operation for operation; the first child is (p + reflection ^* epsilon, reflection, throughput * (color ^* R), seed), which is
+// what the ordinary path makes of `next = reflection` and the factor R.  sqrt_rn == IEEE sqrtf.
+__device__ __forceinline__ float glass_refraction_child(V3 color, GlassConstants gc, V3 p, V3 n, V3 d, float ia, V3 reflection, V3 throughput, Sfc32 seed,
+                                                        V3 &o1, V3 &d1, V3 &t1, Sfc32 &s1)
+{
+    const float cosi = -ia;
+    const float eta = gc.eta;
+    const float k = 1.0f - (eta * eta) * (1.0f - cosi * cosi);
+    const float r0 = gc.r0;
+    const float mm = 1.0f - cosi;
+    float R = r0 + (1.0f - r0) * (((mm * mm) * (mm * mm)) * mm);
+    V3 refraction;
+    if (k < 0.0f) { R = 1.0f; refraction = reflection; }
+    else refraction = scale_l(eta, d) + scale_l(eta * cosi - sqrt_rn(k), n);
+    o1 = p + scale_r(refraction, kEpsilon); d1 = refraction;
+    t1 = throughput * scale_r(color, 1.0f - R);
+    (void)random_float(seed);
+    s1 = seed;
+    return R;
+}
+
 inline unsigned int blocks_for(long long n, int block = kBlock) { return (unsigned int)((n + block - 1) / block); }
 
 // Sample chunks (render_inline_kernel): only when the launch has few rounds of waves and every copy keeps >= 64 samples

@@ -20,6 +20,9 @@ namespace {
 namespace diag {
 
 #define PTMI_PROBE __device__ __forceinline__
+#ifndef PTMI_SPLIT_HIST_SHIFT
+#define PTMI_SPLIT_HIST_SHIFT 13       // bins of 82 us
+#endif
 
 PTMI_PROBE unsigned int lanes(bool on) { return (unsigned int)__builtin_popcountll(__ballot(on)); }
 PTMI_PROBE bool first_active_lane() { return (threadIdx.x & 63) == (int)__builtin_ctzll(__ballot(1)); }
@@ -168,14 +171,20 @@ struct TailProbe {
 // one from the ring, [5] ... that started a sample of their item, [6] ... whose item ended, [7] refill blocks run, [8] hits shaded,
 // [9] ... of which GLASS, [10] rays traced, [11] lanes holding an item, [12] sum and [14] maximum of the waves' durations (u64),
 // [16] waves, [17] GLASS hits parked for a later trip, [18] trips that ran the glass block, [19] lanes in it,
-// [20] children taken from the XCD's shared queue, [21] ... given to it; per XCD x: [24+x] waves, [32+x] sum of durations >> 12,
+// [20] children taken from the XCD's shared queue, [21] ... given to it, [22] the first wave's start (u64, negated); per XCD x: [24+x] waves, [32+x] sum of durations >> 12,
 // [40+x] longest >> 12, [48+x] trips
 struct SplitProbe {
 #ifdef PTMI_SPLIT_STATS
     unsigned int n_trips = 0, n_dead = 0, n_free = 0, n_ring = 0, n_start = 0, n_end = 0, n_refill = 0, n_shade = 0, n_glass = 0, n_trace = 0, n_busy = 0;
     unsigned int n_parked = 0, n_glass_trips = 0, n_glass_lanes = 0, n_stolen = 0, n_shared = 0;
-    unsigned long long t_start = 0;
-    PTMI_PROBE void begin() { t_start = __builtin_readcyclecounter(); }
+    unsigned long long t_start = 0, t_start_real = 0;
+    PTMI_PROBE void begin(unsigned int *wc)
+    {
+        t_start = __builtin_readcyclecounter();
+        // (the shader-clock counter is not one clock across the chip: launch-wide times come from the 100-MHz s_memrealtime)
+        t_start_real = __builtin_amdgcn_s_memrealtime();
+        if ((threadIdx.x & 63) == 0 && wc) atomicMax(reinterpret_cast<unsigned long long *>(wc + 22), ~t_start_real);     // (the first start, negated)
+    }
     PTMI_PROBE void trip(bool dead, bool busy) { ++n_trips; n_dead += lanes(dead); n_busy += lanes(busy); }
     PTMI_PROBE void refill() { ++n_refill; }
     PTMI_PROBE void next_ray(unsigned long long free_m, unsigned int ring_n, bool starts, bool ends)
@@ -189,13 +198,29 @@ struct SplitProbe {
     PTMI_PROBE void stolen(unsigned int n) { n_stolen += n; }
     PTMI_PROBE void shared(unsigned int n) { n_shared += n; }
     PTMI_PROBE void trace(bool has_ray) { n_trace += lanes(has_ray); }
+    // what the wave still holds when it finds the last queue exhausted: [56] lanes with an item, [57] their samples left, [58] spill records,
+    // [59] ring records, [60] the trips it makes after that (sum over the waves), [61] the most of any wave
+    unsigned int at_end_busy = 0, at_end_samples = 0, at_end_spill = 0, at_end_ring = 0, trips_at_end = 0;
+    bool ended = false;
+    PTMI_PROBE void tickets(bool left, bool busy, int samples_left, unsigned int spill_n, unsigned int ring_n)
+    {
+        if (left || ended) return;
+        ended = true; trips_at_end = n_trips;
+        at_end_busy = lanes(busy);
+        unsigned int s = busy && samples_left > 0 ? (unsigned int)samples_left : 0u;
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        at_end_samples = s; at_end_spill = spill_n; at_end_ring = ring_n;
+    }
     PTMI_PROBE void flush(unsigned int *wc, unsigned int xcd)
     {
         if ((threadIdx.x & 63) != 0 || !wc) return;
+        const unsigned long long t_end_real = __builtin_amdgcn_s_memrealtime();    // BEFORE the atomics below: 6 144 waves x 40 atomics on the same few lines take milliseconds
+        const unsigned long long dur = __builtin_readcyclecounter() - t_start;
+        atomicAdd(wc + 56, at_end_busy); atomicAdd(wc + 57, at_end_samples); atomicAdd(wc + 58, at_end_spill); atomicAdd(wc + 59, at_end_ring);
+        atomicAdd(wc + 60, n_trips - trips_at_end); atomicMax(wc + 61, n_trips - trips_at_end);
         atomicAdd(wc + 1, n_trips); atomicAdd(wc + 2, n_dead); atomicAdd(wc + 3, n_free); atomicAdd(wc + 4, n_ring);
         atomicAdd(wc + 5, n_start); atomicAdd(wc + 6, n_end); atomicAdd(wc + 7, n_refill); atomicAdd(wc + 8, n_shade);
         atomicAdd(wc + 9, n_glass); atomicAdd(wc + 10, n_trace); atomicAdd(wc + 11, n_busy);
-        const unsigned long long dur = __builtin_readcyclecounter() - t_start;
         atomicAdd(reinterpret_cast<unsigned long long *>(wc + 12), dur);
         atomicMax(reinterpret_cast<unsigned long long *>(wc + 14), dur);
         atomicAdd(wc + 16, 1u);
@@ -203,9 +228,16 @@ struct SplitProbe {
         atomicAdd(wc + 20, n_stolen); atomicAdd(wc + 21, n_shared);
         atomicAdd(wc + 24 + xcd, 1u); atomicAdd(wc + 32 + xcd, (unsigned int)(dur >> 12)); atomicMax(wc + 40 + xcd, (unsigned int)(dur >> 12));
         atomicAdd(wc + 48 + xcd, n_trips);
+        // [64, 96): the waves by the time they START, [96, 160): by the time they END (from bin 32 on), [160, 224): the trips of the waves that
+        // ended in the bin (did the late waves do more, or did they run slower?) -- times from the first wave's start, bins of 2^PTMI_SPLIT_HIST_SHIFT ticks of 10 ns
+        const unsigned long long t0 = ~__hip_atomic_load(reinterpret_cast<unsigned long long *>(wc + 22), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long bs = (t_start_real - t0) >> PTMI_SPLIT_HIST_SHIFT, be = (t_end_real - t0) >> PTMI_SPLIT_HIST_SHIFT;
+        const unsigned int bin = be < 32ull ? 0u : (be < 95ull ? (unsigned int)be - 32u : 63u);
+        atomicAdd(wc + 64 + (bs < 31ull ? (unsigned int)bs : 31u), 1u);
+        atomicAdd(wc + 96 + bin, 1u); atomicAdd(wc + 160 + bin, n_trips);
     }
 #else
-    PTMI_PROBE static void begin() {}
+    PTMI_PROBE static void begin(unsigned int *) {}
     PTMI_PROBE static void trip(bool, bool) {}
     PTMI_PROBE static void refill() {}
     PTMI_PROBE static void next_ray(unsigned long long, unsigned int, bool, bool) {}
@@ -215,6 +247,7 @@ struct SplitProbe {
     PTMI_PROBE static void stolen(unsigned int) {}
     PTMI_PROBE static void shared(unsigned int) {}
     PTMI_PROBE static void trace(bool) {}
+    PTMI_PROBE static void tickets(bool, bool, int, unsigned int, unsigned int) {}
     PTMI_PROBE static void flush(unsigned int *, unsigned int) {}
 #endif
 };

@@ -63,6 +63,7 @@ struct RenderArgs {
     const unsigned int *first_position;
 };
 enum { kScTruncated = 0, kScDropped = 1, kScWords = 4 };
+constexpr int kWorkWords = 256;            // RenderArgs.work_counter: the hand-out counter in [0], the diagnostic builds' counters behind it (ptmi_diag.h; ptmi_debug_counters)
 constexpr int kTreeStackDepth = 16;        // per-pixel tree walk: pending children a lane can hold (render_streams_tree_kernel)
 #ifndef PTMI_TREE_FAST_LEVELS
 #define PTMI_TREE_FAST_LEVELS 4
@@ -137,8 +138,10 @@ struct ItemArgs {
     unsigned int *region_done;      // streams_pixels_kernel, passes > 1: per region, the items published so far (zero at launch)
     unsigned int *chunk_cursor;     // device: the launch's eight ticket counters, kCounterStride words apart, zero at launch
     // streams_split_kernel only
-    int samples_per_pass;           // a pixel's samples are cut into `passes` items of this many samples (the last one shorter)
-    const uint4 *seed_snapshots;    // [passes][n_px]: the seed sample (pass * samples_per_pass) of a pixel starts from
+    const int *pass_first;          // device, passes + 1 entries: pass p renders samples [pass_first[p], pass_first[p + 1]) of its pixels -- long items first, short ones
+                                    // at the end of the launch, which is as long as its last items (stream_schedule in ptmi_api.cpp)
+    const uint4 *seed_snapshots;    // [passes][n_px]: the seed sample pass_first[pass] of a pixel starts from
+    int glass_batch;                // > 1: GLASS hits wait in their lanes until that many are pending in the wave (PTMI_OPT_GLASS_BATCH)
     unsigned int n_px;
     RayQueue spill;                 // the waves' own spill queues: streams_spill_records() records each, gridDim of them
     RayQueue out;                   // overflow stream: children that found ring and spill queue full
@@ -156,7 +159,7 @@ int streams_min_pass_samples();      // ordered passes: a pass must hold at leas
 int streams_split_waves();
 unsigned int streams_spill_records();   // records of a wave's spill queue in HBM
 unsigned int streams_regions(int width, int rows_local);    // regions of the start-hit list
-hipError_t launch_streams_seeds(Planes p, uint4 *snapshots, long long n, int passes, int samples_per_pass, int draws, hipStream_t stream);
+hipError_t launch_streams_seeds(Planes p, uint4 *snapshots, long long n, int passes, const int *pass_first, hipStream_t stream);   // pass_first: device, passes + 1 entries
 hipError_t launch_streams_level(const RenderArgs &a, const LevelArgs &lv, unsigned int grid, hipStream_t stream);
 hipError_t launch_streams_primary(const RenderArgs &a, HitList hits, unsigned int *counters, hipStream_t stream);
 // updateSeeds for the pixels without start hits (the ordered item kernel advances the others itself)

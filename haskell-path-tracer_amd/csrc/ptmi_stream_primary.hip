@@ -100,9 +100,9 @@ __global__ void __launch_bounds__(256) streams_advance_missed_kernel(const Rende
     a.planes.sa[pixel] = sd.a; a.planes.sb[pixel] = sd.b; a.planes.sc[pixel] = sd.c; a.planes.sctr[pixel] = sd.counter;
 }
 
-// updateSeed (Trace.hs:190-191) for every sample of the call: `draws` draws per pixel, and on the way the seed each of the
-// `passes` items of the pixel starts from (snapshots[pass][pixel]: the pixel's seed after pass * samples_per_pass draws).
-__global__ void __launch_bounds__(kBlock) streams_seeds_kernel(Planes p, uint4 *snapshots, long long n, int passes, int samples_per_pass, int draws)
+// updateSeed (Trace.hs:190-191) for every sample of the call: pass_first[passes] draws per pixel, and on the way the seed each of the
+// `passes` items of the pixel starts from (snapshots[pass][pixel]: the pixel's seed after pass_first[pass] draws).
+__global__ void __launch_bounds__(kBlock) streams_seeds_kernel(Planes p, uint4 *snapshots, long long n, int passes, const int *pass_first)
 {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -110,10 +110,8 @@ __global__ void __launch_bounds__(kBlock) streams_seeds_kernel(Planes p, uint4 *
     int done = 0;
     for (int k = 0; k < passes; ++k) {
         snapshots[(size_t)k * (size_t)n + (size_t)i] = uint4{s.a, s.b, s.c, s.counter};
-        const int upto = (k + 1) * samples_per_pass < draws ? (k + 1) * samples_per_pass : draws;
-        for (; done < upto; ++done) (void)random_float(s);
+        for (const int upto = pass_first[k + 1]; done < upto; ++done) (void)random_float(s);
     }
-    for (; done < draws; ++done) (void)random_float(s);
     p.sa[i] = s.a; p.sb[i] = s.b; p.sc[i] = s.c; p.sctr[i] = s.counter;
 }
 
@@ -146,10 +144,10 @@ hipError_t launch_streams_advance_missed(const RenderArgs &a, HitList hits, int 
     return hipGetLastError();
 }
 
-hipError_t launch_streams_seeds(Planes p, uint4 *snapshots, long long n, int passes, int samples_per_pass, int draws, hipStream_t stream)
+hipError_t launch_streams_seeds(Planes p, uint4 *snapshots, long long n, int passes, const int *pass_first, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(streams_seeds_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, p, snapshots, n, passes, samples_per_pass, draws);
+    hipLaunchKernelGGL(streams_seeds_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, p, snapshots, n, passes, pass_first);
     return hipGetLastError();
 }
 

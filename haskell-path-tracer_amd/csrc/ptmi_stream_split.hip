@@ -45,7 +45,10 @@ template <bool LDS_SCENE, bool TILES>
 __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_kernel(const RenderArgs a, const ItemArgs it)
 {
     // the lane's own item: 0-2 position of the start hit, 3-5 normal, 6-8 incoming direction, 9-11 throughput,
-    // 12 primitive | meta << 16, 13 pixel, 14-17 the seed the ray of its next sample carries
+    // 12 primitive (10 bits) | step index of the start hit (0 or 1) << 10 | the pixel's quad << 11 (where the item's cost goes), 13 pixel,
+    // 14-17 the seed the ray of its next sample carries.  (Eighteen words and no more: with the ring and a 16-primitive scene a workgroup needs
+    // 6 368 bytes of LDS, five of the 1 280-byte granules gfx950 allocates, and 24 workgroups -- six waves per SIMD -- fit a CU; a nineteenth
+    // word is a sixth granule and 21 workgroups: measured, the launch ran 4 % longer with an eighth of its waves starting when the others ended.)
     __shared__ float item_rec[18][kRenderBlock];
     __shared__ uint32_t ring[15][kRing];                      // children waiting for a lane: RayQueue's record, word by word (15 words)
     extern __shared__ float4 lds_scene[];
@@ -79,7 +82,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
     uint32_t pixel = 0, depth = 0;                            // depth: step index of the lane's current ray
     int idx = 0, samples_left = 0;
     unsigned int deepest = 0, item_trips = 0;                 // item_trips: loop trips since the lane took its item (its cost, for later launches' dispatch order)
-    unsigned int live_w = 0, cut_w = 0, dropped_w = 0, stored_w = 0, spilled_w = 0;   // wave-uniform statistics
+    unsigned int live_w = 0, cut_w = 0, spilled_w = 0;        // wave-uniform statistics
 
     // computeResult + permute (+) (Trace.hs:179-184, :318-323); adding an exact zero changes nothing
     auto add_colour = [&](V3 c) __attribute__((always_inline)) {
@@ -92,7 +95,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
         }
     };
 
-    diag::SplitProbe probe; probe.begin();                    // (diagnostic builds: ptmi_diag.h)
+    diag::SplitProbe probe; probe.begin(a.work_counter);                   // (diagnostic builds: ptmi_diag.h)
     for (;;) {
         probe.trip(pending && near_zero(throughput), busy);
         // ---- a hit whose ray arrived with near-zero throughput (numNewRays = 0, Trace.hs:329-331) adds its emittance and nothing
@@ -114,7 +117,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                 const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
                 const uint32_t px = f2u(r3.y);
                 // initialState (Trace.hs:158-162) one step on: the cached start hit; the item's first sample starts from the
-                // pixel's seed advanced by (pass * samples_per_pass) draws, which is what that many updateSeeds leave
+                // pixel's seed advanced by pass_first[pass] draws, which is what that many updateSeeds leave
                 // ... and, for a child of a cached glass primary hit, by the 3 or 4 raw draws its ancestors made: the item keeps the
                 // seed its next sample's RAY carries, which updateSeed moves on by one like the pixel's own
                 const uint4 snap = it.seed_snapshots[(size_t)cur.pass * it.n_px + px];
@@ -122,16 +125,16 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                 for (uint32_t q = 0; q < (f2u(r3.z) >> 8); ++q) (void)sfc32_next(s0);
                 put(0, r0.x); put(1, r0.y); put(2, r0.z); put(3, r0.w); put(4, r1.x); put(5, r1.y);
                 put(6, r1.z); put(7, r1.w); put(8, r2.x); put(9, r2.y); put(10, r2.z); put(11, r2.w);
-                put(12, u2f(f2u(r3.x) | (f2u(r3.z) << 16))); put(13, r3.y);
+                put(12, u2f(f2u(r3.x) | ((f2u(r3.z) & 1u) << 10) | (f2u(r3.w) << 11))); put(13, r3.y);
                 put(14, u2f(s0.a)); put(15, u2f(s0.b)); put(16, u2f(s0.c)); put(17, u2f(s0.counter));
                 item_trips = 0;
-                const int first_sample = (int)cur.pass * it.samples_per_pass;
-                samples_left = a.n_spp - first_sample < it.samples_per_pass ? a.n_spp - first_sample : it.samples_per_pass;
+                samples_left = it.pass_first[cur.pass + 1u] - it.pass_first[cur.pass];      // the samples of this pass (ItemArgs.pass_first)
                 busy = true;
             }
             cur.taken += take;
             if (cur.taken >= cur.len) next_chunk(cur, it);
         }
+        probe.tickets(chunks_left(cur), busy, samples_left, spill_n, ring_n);
         // ---- the next ray of every lane that holds neither a ray nor a hit: a child from the wave's ring first ...
         const bool free_lane = !pending && !has_ray;
         const unsigned long long free_m = __ballot(free_lane);
@@ -182,13 +185,13 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                 d = mk(get(6), get(7), get(8));
                 throughput = mk(get(9), get(10), get(11));
                 const uint32_t pm = f2u(get(12));
-                idx = (int)(pm & 0xffffu);
+                idx = (int)(pm & 0x3ffu);
                 pixel = f2u(get(13));
                 Sfc32 ss; ss.a = f2u(get(14)); ss.b = f2u(get(15)); ss.c = f2u(get(16)); ss.counter = f2u(get(17));
                 seed = ss;                                     // (already past the draws its ray's ancestors made)
                 (void)sfc32_next(ss);                          // updateSeed (Trace.hs:190-191): the next sample starts one draw further
                 put(14, u2f(ss.a)); put(15, u2f(ss.b)); put(16, u2f(ss.c)); put(17, u2f(ss.counter));
-                depth = (pm >> 16) & 0xffu;
+                depth = (pm >> 10) & 1u;
                 deepest = deepest > 1u ? deepest : 1u;        // the primary ray's traceStep
                 pending = true; foreign = false;              // (a start hit of a dead ray -- a reflection of weight ~0 -- waits for the next trip's first block)
             } else {
@@ -197,11 +200,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                 if (own_acc.y != 0.0f) atomicAdd(&plane_at(a.planes.g, px << 2), own_acc.y);
                 if (own_acc.z != 0.0f) atomicAdd(&plane_at(a.planes.b, px << 2), own_acc.z);
                 own_acc = mk(0.0f, 0.0f, 0.0f);
-                if (TILES && a.quad_cost) {
-                    const unsigned int y = px / (unsigned int)a.width, x = px - y * (unsigned int)a.width;
-                    const unsigned int tile = (y >> 3) * (unsigned int)((a.width + 7) / 8) + (x >> 3);
-                    record_item_cost(a, tile >> 2, item_trips);
-                }
+                if (TILES) record_item_cost(a, f2u(get(12)) >> 11, item_trips);     // (the quad travels with the start hit: no division here, where two lanes of 64 are active)
                 busy = false;
             }
         }
@@ -211,27 +210,55 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
         if (!__any(has_ray || pending) && !chunks_left(cur) && !__any(busy) && ring_n == 0 && spill_n == 0) break;
         item_trips += busy ? 1u : 0u;
 
-        // ---- shade round, for the hits of rays that are alive (a dead one just fetched waits for the next trip's first block)
+        // ---- shade round, for the hits of rays that are alive (a dead one just fetched waits for the next trip's first block).
+        // GLASS is an ARM of the one shade, not a second shade: genVec's three draws come before the match for every material
+        // (Trace.hs:394-405), ia = dir . n and the mirror direction are what Glossy computes too, and the reflection child is what the
+        // common tail makes of `next = reflection` and the factor R instead of brdf * prob -- p + next ^* epsilon, throughput * (color ^* f),
+        // the seed after the three draws.  What only GLASS needs -- Schlick's R, the refraction direction, the SECOND child -- is the small
+        // divergent block in the middle (it used to be the whole of glass_children, wave-wide for three lanes in nearly every trip).
+        // PARKING (it.glass_batch > 1): a GLASS hit waits in its lane until that many of the wave's lanes hold one -- or the wave has
+        // nothing else to shade or trace -- so that the block and the expand behind it run for >= glass_batch lanes at a time.
         bool emits = false;
         V3 ko = o, kd = o, kt = o; Sfc32 ks = seed;
+        const float4 mb = M[2 * idx + 1];
         const bool alive = pending && !near_zero(throughput);
-        live_w += (unsigned int)__builtin_popcountll(__ballot(alive));        // one child per shaded hit ...
-        probe.shade(alive, alive && f2u(M[2 * idx + 1].x) == 2u);
-        if (alive) {
-            const float4 ma = M[2 * idx], mb = M[2 * idx + 1];
-            V3 contribution;
-            if (f2u(mb.x) == 2u) {                            // GLASS (extension): reflection stays, refraction is emitted
-                contribution = scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput;
-                V3 co[2], cd[2], ct[2]; Sfc32 cs[2];
-                glass_children(mk(ma.x, ma.y, ma.z), glass_constants_of<LDS_SCENE>(mb), o, normal, d, throughput, seed, co, cd, ct, cs);
-                o = co[0]; d = cd[0]; throughput = ct[0]; seed = cs[0];
-                ko = co[1]; kd = cd[1]; kt = ct[1]; ks = cs[1];
+        const bool glass = alive && f2u(mb.x) == 2u;
+        bool shade_now = alive;
+        if (it.glass_batch > 1) {                                 // wave-uniform
+            const unsigned long long gm = __ballot(glass);
+            const bool hold = gm != 0ull && (unsigned int)__builtin_popcountll(gm) < (unsigned int)it.glass_batch && __any((alive && !glass) || has_ray);
+            if (hold) { shade_now = alive && !glass; probe.parked((unsigned int)__builtin_popcountll(gm)); }
+        }
+        live_w += (unsigned int)__builtin_popcountll(__ballot(shade_now));    // one child per shaded hit ...
+        probe.shade(shade_now, shade_now && glass);
+        if (shade_now) {
+            const float4 ma = M[2 * idx];
+            const V3 color = mk(ma.x, ma.y, ma.z);
+            V3 rv;                                                // genVec (Util.hs:114-118)
+            rv.x = gen_component(seed); rv.y = gen_component(seed); rv.z = gen_component(seed);
+            const bool matte = f2u(mb.x) == 0u;
+            const float ia = dot(d, normal);
+            const V3 reflection = d - scale_l(2.0f * ia, normal);
+            float glass_R = 0.0f;
+            if (glass) {                                          // the refraction child (extension; spec = the oracle's glass_children)
+                probe.glass_block(diag::lanes(true));
+                glass_R = glass_refraction_child(color, glass_constants_of<LDS_SCENE>(mb), o, normal, d, ia, reflection, throughput, seed, ko, kd, kt, ks);
                 emits = true;
-            } else {
-                contribution = mk(0.0f, 0.0f, 0.0f);
-                shade(M, idx, o, normal, o, d, throughput, contribution, seed);   // contribution = 0 + emittance * throughput
             }
-            add_colour(contribution);
+            // Matte: rotate (anglesToQuaternion $ pi *^ rv) iNormal | Glossy: rotate (anglesToQuaternion $ (1 - p) *^ rv) reflection
+            const V3 axis = matte ? normal : reflection;
+            const float hk = matte ? 0.5f * kPi : mb.w;
+            const V3 rotated = rotate(quaternion_from_half_angles(hk * rv.x, hk * rv.y, hk * rv.z), axis);
+            const float nd = dot(rotated, axis);
+            const float brdf = matte ? mb.z * nd : __builtin_fmaxf(0.0f, nd);
+            constexpr float next_ray_prob = 1.0f / (kPi * 2.0f);
+            const float factor = glass ? glass_R : brdf * next_ray_prob;
+            const V3 next = mk(glass ? reflection.x : rotated.x, glass ? reflection.y : rotated.y, glass ? reflection.z : rotated.z);   // (component selects: a select between two structs went through scratch memory)
+            // computeResult for EVERY hit (Trace.hs:318-323), then the child in the lane (0 + e * t: an exact zero either way is skipped or changes nothing)
+            add_colour(mk(0.0f, 0.0f, 0.0f) + (scale_r(color, ma.w) * throughput));
+            o = o + scale_r(next, kEpsilon);
+            d = next;
+            throughput = throughput * scale_r(color, factor);
             ++depth; pending = false; has_ray = true;          // the child: next traceStep, same lane
         }
         // ---- expand: compaction of the emitted children into the wave's ring; what the ring cannot hold goes to the wave's spill
@@ -275,8 +302,14 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                         blk += cnt2;
                     }
                     const unsigned int lost = (unsigned int)__builtin_popcountll(__ballot(spills && slot >= it.out.capacity));
-                    stored_w += cnt2 - lost; dropped_w += lost;
                     if (spills && slot < it.out.capacity) queue_store(it.out, slot, ko, kd, kt, pixel, ks, depth);   // depth: the child's step index
+                    if (lane == 0) {                          // practically never: counted where it happens, not in registers carried round the loop
+                        if (cnt2 > lost) {
+                            atomicAdd(it.emitted + (size_t)(w & (unsigned int)(kLvEmitShards - 1)) * kCounterStride, cnt2 - lost);
+                            atomicAdd(it.stats + kLvSpilled * kCounterStride, cnt2 - lost);
+                        }
+                        if (lost) atomicAdd(it.stats + kLvDropped * kCounterStride, lost);
+                    }
                 }
             }
         }
@@ -310,12 +343,10 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
     if (lane == 0) {
         unsigned int *st = it.stats;
         if (live_w) atomicAdd(st + (kLvLive + (w & (unsigned int)(kLvLiveShards - 1))) * kCounterStride, live_w);
-        if (stored_w) atomicAdd(it.emitted + (size_t)(w & (unsigned int)(kLvEmitShards - 1)) * kCounterStride, stored_w);
         // a maximum: most waves find it already there (a plain load first; the atomic only when it would raise the word)
         if (deep > __hip_atomic_load(st + kLvDeepest * kCounterStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(st + kLvDeepest * kCounterStride, deep);
         if (cut_w) atomicAdd(st + kLvCut * kCounterStride, cut_w);
-        if (dropped_w) atomicAdd(st + kLvDropped * kCounterStride, dropped_w);
-        if (spilled_w + stored_w) atomicAdd(st + kLvSpilled * kCounterStride, spilled_w + stored_w);
+        if (spilled_w) atomicAdd(st + kLvSpilled * kCounterStride, spilled_w);
     }
 }
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PTMI_VERSION 300   /* 0.3.0: ptmi_stats.stream_rays_spilled, PTMI_SEED_AUTO (the default), group options */
+#define PTMI_VERSION 400   /* 0.4.0: options 8-11 (the stream form's scheduling knobs, formerly environment variables), ptmi_stream_schedule, 256 debug counters */
 
 /* ---- error codes ------------------------------------------------------------ */
 enum {
@@ -142,7 +142,7 @@ int ptmi_set_timing(ptmi_ctx *ctx, int enabled);
 /* Kernel variant selection for measurements: 0 = default.  See DESIGN.md "kernel variants". */
 int ptmi_set_variant(ptmi_ctx *ctx, int variant);
 
-/* Options.  1-5 concern `render Streams` (src/Scene/Trace.hs:141-191) and never change `render Inline`; 6 is a
+/* Options.  1-5 and 8-11 concern `render Streams` (src/Scene/Trace.hs:141-191) and never change `render Inline`; 6 is a
  * scheduling knob of the per-pixel kernels that changes no result; 7 is a labelled measurement mode of `render Inline`. */
 enum {
     /* Which seed a pixel carries out of `combine` (Trace.hs:179-184): the combination function keeps the seed of its
@@ -188,12 +188,45 @@ enum {
      * with -ffp-contract=fast, or Accelerate's fast-math LLVM backends, may do to the reference's source.  Its planes are NOT
      * the oracle's (the RNG planes still are: integer arithmetic); DESIGN.md reports how far they are and what the literal
      * reading -- every operation rounded on its own, PTMI_ARITH_EXACT -- costs.  Variants and Streams ignore it. */
-    PTMI_OPT_ARITHMETIC = 7
+    PTMI_OPT_ARITHMETIC = 7,
+    /* 8-11: scheduling knobs of the stream form of Streams.  None changes a ray, a seed or (without GLASS) a bit of the planes.
+     *
+     * PTMI_OPT_STREAM_TAIL: scenes without GLASS, one-pass launches: the cheapest quads of the dispatch order -- the cheapest classes
+     * that together hold at most this many THOUSANDTHS of the recorded cost -- are rendered by the per-pixel chain kernel on a
+     * low-priority stream beside the persistent launch, whose waves' slots it fills as they end.  -1 (default) = automatic (150, or 400
+     * where a lane sees fewer than four pixels), 0 = no tail.  (Environment override at creation: PTMI_STREAM_TAIL.) */
+    PTMI_OPT_STREAM_TAIL = 8,
+    /* PTMI_OPT_ORDERED_PASSES: scenes without GLASS: a pixel's samples cut into this many ORDERED passes inside the one launch; the pixel's
+     * seven words are handed from the lane that rendered pass p to whichever lane -- of any wave, on any XCD -- takes pass p + 1, through
+     * write-through (sc1) stores, a counter that moves after the storing wave's vmcnt(0), and sc1 loads after the poll.  That hand-off
+     * uses NO FENCE: it is the "valid form" of MI355X_MICROARCH.md, MEASURED valid on gfx950 (3 billion hand-offs compared bit for bit,
+     * profiles/r03_soak_ordered_passes.json) -- not a promise of the HSA memory model.  0 (default) = automatic (only for parts of an
+     * image at >= 256 spp, where it is worth 5-8 %), 1 = OFF: one pass per launch, no hand-off between waves at all -- what a caller
+     * who wants only architecturally guaranteed synchronisation sets -- k in [2, 64] = k passes.  1 also overrides PTMI_OPT_STREAM_BATCH
+     * for scenes without GLASS.  (Environment override at creation: PTMI_ORDERED_PASSES.) */
+    PTMI_OPT_ORDERED_PASSES = 9,
+    /* PTMI_OPT_GLASS_BATCH: scenes with GLASS: a GLASS hit waits in its lane until this many lanes of its wave hold one (or the wave has
+     * nothing else to shade or trace), so that the refraction block runs for that many lanes at a time.  0 (default) = automatic,
+     * 1 = off, k in [2, 64]. */
+    PTMI_OPT_GLASS_BATCH = 10,
+    /* PTMI_OPT_STREAM_GRADED: scenes with GLASS (or unordered items): 1 (default) = a pixel's samples are cut into GRADED passes -- long
+     * items first, single samples last (ptmi_stream_schedule) -- so that the launch does not end with long items in few lanes;
+     * 0 = uniform passes (round 3). */
+    PTMI_OPT_STREAM_GRADED = 11
 };
 enum { PTMI_ARITH_EXACT = 0, PTMI_ARITH_CONTRACTED = 1 };
 enum { PTMI_SEED_KEEP_ACCUMULATOR = 0, PTMI_SEED_FROM_RESULT = 1, PTMI_SEED_AUTO = 2 };
 enum { PTMI_FORM_AUTO = 0, PTMI_FORM_STREAM = 1 };
 int ptmi_set_option(ptmi_ctx *ctx, int option, int64_t value);
+/* The passes the stream form's split kernel (GLASS, or PTMI_OPT_STREAM_BATCH under PTMI_SEED_KEEP_ACCUMULATOR) cuts n_spp samples into
+ * for n_pixels held pixels on `lanes` persistent lanes (64 x 4 x 6 x compute units): pass p renders samples [first[p], first[p + 1]).
+ * batch = PTMI_OPT_STREAM_BATCH, graded = PTMI_OPT_STREAM_GRADED.  Pure host arithmetic (no device needed).  Returns the number of
+ * passes (first[] receives passes + 1 entries), PTMI_ELIMIT if `capacity` entries do not hold them (65 always do). */
+int ptmi_stream_schedule(int n_spp, uint64_t n_pixels, uint64_t lanes, int batch, int graded, int32_t *first, int capacity);
+/* The schedule of the cost-ordered dispatch, host arithmetic: given the launches made so far with one (camera, scene,
+ * shape, limit, algorithm), does the next launch rebuild the order from the recorded costs (before launch 1, 2, 4, 8, ...; never once
+ * the recording limit -- 2^20 launches, 2^11 for the stream form -- is reached) and does it record its costs?  Returns the state after it. */
+int ptmi_order_schedule(int launches, int stream_form, int *rebuild, int *record);
 int ptmi_get_option(ptmi_ctx *ctx, int option, int64_t *value);
 
 /* ---- state: initialOutput / genSeeds / reseed -------------------------------- */
@@ -257,9 +290,10 @@ int ptmi_snapshot_color(ptmi_ctx *ctx, float *dst_device, void *hip_stream);
 
 int ptmi_get_stats(ptmi_ctx *ctx, ptmi_stats *out);   /* synchronises the launch stream */
 int ptmi_reset_stats(ptmi_ctx *ctx);
-/* Diagnostics: the 64 raw device counters (hand-out counter in [0]; a -DPTMI_PHASE_STATS build of the kernels
- * adds round statistics, see tools/phase_stats.py).  Synchronises the launch stream. */
-int ptmi_debug_counters(ptmi_ctx *ctx, uint32_t out[64]);
+/* Diagnostics: the 256 raw device counters (hand-out counter in [0]; the diagnostic builds of the kernels --
+ * -DPTMI_PHASE_STATS and the others listed in csrc/ptmi_diag.h -- add their statistics, see tools/phase_stats.py).
+ * Synchronises the launch stream. */
+int ptmi_debug_counters(ptmi_ctx *ctx, uint32_t out[256]);
 
 /* ---- groups: the GPUs of one node behind ONE host process ------------------------ */
 /* The reference's host is a single process holding one compiled function (app/Main.hs:188-191); a group lets that

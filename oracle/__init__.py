@@ -50,7 +50,7 @@ class _Sfc(C.Structure):
 
 
 class _Opts(C.Structure):
-    _fields_ = [("rows", C.c_void_p), ("n_rows", C.c_int), ("streams_seed_rule", C.c_int)]
+    _fields_ = [("rows", C.c_void_p), ("n_rows", C.c_int), ("streams_seed_rule", C.c_int), ("n_threads", C.c_int)]
 
 
 SEED_KEEP_ACCUMULATOR, SEED_FROM_RESULT = 0, 1        # ORA_SEED_* (assumption A5, pt_oracle.h)
@@ -201,9 +201,9 @@ def sfc32_seed3(a, b, c):
     return (s.a, s.b, s.c, s.counter)
 
 
-def _opts(rows, seed_rule):
+def _opts(rows, seed_rule, n_threads=1):
     """-> (_Opts, keep-alive) for the *_ex functions; rows = image row of every held row (a partition) or None."""
-    o = _Opts(None, 0, int(seed_rule))
+    o = _Opts(None, 0, int(seed_rule), int(n_threads))
     keep = None
     if rows is not None:
         keep = np.ascontiguousarray(rows, np.int32)
@@ -234,11 +234,11 @@ def render_inline(spheres, planes, camera, width, height, bounce_limit, n_spp, p
 
 
 def render_streams(spheres, planes, camera, width, height, max_iterations, n_spp, planes_in,
-                   rows=None, seed_rule=None, want_truncated=False):
-    """seed_rule None = the library's default (default_seed_rule)."""
+                   rows=None, seed_rule=None, want_truncated=False, n_threads=1):
+    """seed_rule None = the library's default (default_seed_rule); n_threads > 1: OpenMP over rows (pixels are independent)."""
     sc, keep = _scene(spheres, planes)
     cam = np.ascontiguousarray(camera, CAMERA_DTYPE)
-    o, keep_rows = _opts(rows, default_seed_rule(spheres, planes) if seed_rule is None else seed_rule)
+    o, keep_rows = _opts(rows, default_seed_rule(spheres, planes) if seed_rule is None else seed_rule, n_threads)
     outs = _copies(planes_in, height if rows is None else len(rows), width)
     truncated = C.c_int64(0)
     live = lib().ora_render_streams_ex(C.byref(sc), _p(cam), width, height, max_iterations, n_spp,
@@ -265,18 +265,34 @@ def render_streams_wavefront(spheres, planes, camera, width, height, hard_cap, n
     return tuple(outs), int(live), int(dropped.value), int(steps.value)
 
 
-def render_streams_tree(spheres, planes, camera, width, height, hard_cap, n_spp, planes_in, stack_depth=16, rows=None):
-    """Streams with ray splitting visited per pixel, depth first (the device's tree-walk order).
+def render_streams_tree(spheres, planes, camera, width, height, hard_cap, n_spp, planes_in, stack_depth=16, rows=None, n_threads=1):
+    """Streams with ray splitting visited per pixel, depth first (the device's tree-walk order); n_threads > 1: OpenMP over rows.
     -> (planes, live, dropped, longest_lineage, truncated)"""
     sc, keep = _scene(spheres, planes)
     cam = np.ascontiguousarray(camera, CAMERA_DTYPE)
-    o, keep_rows = _opts(rows, 0)
+    o, keep_rows = _opts(rows, 0, n_threads)
     outs = _copies(planes_in, height if rows is None else len(rows), width)
     dropped, longest, truncated = C.c_int64(0), C.c_int(0), C.c_int64(0)
     live = lib().ora_render_streams_tree(C.byref(sc), _p(cam), width, height, hard_cap, n_spp, stack_depth,
                                          *[_p(a) for a in outs], C.byref(dropped), C.byref(longest),
                                          C.byref(o), C.byref(truncated))
     return tuple(outs), int(live), int(dropped.value), int(longest.value), int(truncated.value)
+
+
+def render_streams_wavefront_rows(spheres, planes, camera, width, height, hard_cap, n_spp, planes_in, rows, capacity_factor=8, n_threads=1):
+    """ora_render_streams_wavefront over the image rows `rows` (planes_in: their 7 planes, [len(rows)][width]), one row per call and
+    the calls on n_threads threads: the stream order of a pixel's additions does not depend on which other pixels share the stream,
+    so this equals one call over all the rows -- and finishes in seconds where that takes minutes.  -> (planes, live, dropped)"""
+    from concurrent.futures import ThreadPoolExecutor
+    rows = [int(v) for v in rows]
+
+    def one(k):
+        start = [np.asarray(a)[k:k + 1] for a in planes_in]
+        return render_streams_wavefront(spheres, planes, camera, width, height, hard_cap, n_spp, start, capacity_factor=capacity_factor, rows=[rows[k]])
+    with ThreadPoolExecutor(max(1, int(n_threads))) as pool:
+        res = list(pool.map(one, range(len(rows))))
+    outs = tuple(np.concatenate([r[0][p] for r in res], axis=0) for p in range(7))
+    return outs, sum(r[1] for r in res), sum(r[2] for r in res)
 
 
 def max_threads():

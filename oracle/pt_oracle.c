@@ -588,6 +588,11 @@ int64_t ora_render_streams_ex(const ora_scene *scene, const ora_camera *cam,
     int64_t live_total = 0, n_truncated = 0;
     const int n_rows = held_rows(opts, height);
     const int from_result = opts && opts->streams_seed_rule == ORA_SEED_FROM_RESULT;
+    const int n_threads = opts && opts->n_threads > 1 ? opts->n_threads : 1;
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) reduction(+:live_total, n_truncated) num_threads(n_threads)
+#endif
     for (int row = 0; row < n_rows; ++row) {
         for (int col = 0; col < width; ++col) {
             int64_t i = (int64_t)row * width + col;
@@ -767,10 +772,15 @@ int64_t ora_render_streams_tree(const ora_scene *scene, const ora_camera *cam,
     typedef struct { ora_ray_state rs; int steps; } waiting;
     const int n_rows = held_rows(opts, height);
     ora_primary_uniforms u = ora_primary_setup(cam, width, height);
-    waiting *stack = malloc(sizeof *stack * (size_t)(stack_depth > 0 ? stack_depth : 1));
     int64_t live_total = 0, n_dropped = 0, n_truncated = 0;
     int longest = 0;
+    const int n_threads = opts && opts->n_threads > 1 ? opts->n_threads : 1;
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) reduction(+:live_total, n_dropped, n_truncated) reduction(max:longest) num_threads(n_threads)
+#endif
     for (int row = 0; row < n_rows; ++row) {
+        waiting *stack = malloc(sizeof *stack * (size_t)(stack_depth > 0 ? stack_depth : 1));     /* (per row: the rows run on several threads) */
         for (int col = 0; col < width; ++col) {
             int64_t i = (int64_t)row * width + col;
             ora_ray primary = ora_primary_ray(&u, col, image_row(opts, row), width, height);
@@ -823,8 +833,8 @@ int64_t ora_render_streams_tree(const ora_scene *scene, const ora_camera *cam,
             r[i] = acc.x; g[i] = acc.y; b[i] = acc.z;
             sa[i] = pixel_seed.a; sb[i] = pixel_seed.b; sc[i] = pixel_seed.c; sctr[i] = pixel_seed.counter;
         }
+        free(stack);
     }
-    free(stack);
     if (dropped) *dropped = n_dropped;
     if (longest_lineage) *longest_lineage = longest;
     if (truncated) *truncated = n_truncated;

@@ -146,6 +146,8 @@ typedef struct {
     const int32_t *rows;      /* image row of each row the planes hold (a partition); NULL = rows 0..height-1 */
     int n_rows;               /* number of held rows when rows != NULL */
     int streams_seed_rule;    /* ORA_SEED_* */
+    int n_threads;            /* ora_render_streams_ex / ora_render_streams_tree: > 1 = OpenMP over rows (pixels are independent); the stream-order
+                               * function ora_render_streams_wavefront_ex stays serial -- run it on disjoint row windows from several threads instead */
 } ora_opts;
 
 /* One call of `render Inline` (Trace.hs:193-200) repeated n_spp times on the same

@@ -35,7 +35,7 @@ def test_binding_covers_exactly_the_header(pkg):
 
 def test_version_and_strerror(pkg):
     lib = pkg.load_library()
-    assert lib.ptmi_version() == 300
+    assert lib.ptmi_version() == 400
     assert lib.ptmi_strerror(0) == b"ok" and lib.ptmi_strerror(-2) == b"no usable HIP device"
 
 

@@ -132,20 +132,40 @@ def _c4_whole(pkg):
     return _C4_WHOLE["planes"]
 
 
-@pytest.mark.parametrize("form", ["tree_walk", "stream"])
-def test_c5_glass_4k_512spp_one_part_of_8(pkg, ora, form):
-    """configs[4] at full size on one of its 8 parts: the glass scene (build-defined GLASS extension: no reference
+def _rows_through_the_glass_spheres(pkg, ora, rows, n=4):
+    """Local indices of the `n` rows of the part whose rays split most: every 6th row is traced once by the oracle with the glass
+    scene and once with its spheres opaque (scene S16); the rows with the largest excess of rays are the ones that look through glass."""
+    sp, pl = pkg.world.glass_scene()
+    cam = pkg.world.initial_camera()
+    cand = list(range(0, len(rows), 6))
+    window = initial_rows(ora, W4K, rows[cand])
+    threads = min(ora.max_threads(), 16)
+    excess = []
+    for k in range(len(cand)):
+        one = [a[k:k + 1] for a in window]
+        glass = ora.render_streams_tree(sp, pl, cam, W4K, H4K, 1 << 16, 1, one, rows=[int(rows[cand[k]])], n_threads=threads)[1]
+        plain = ora.render_streams(pkg.world.scene16()[0], pl, cam, W4K, H4K, 1 << 16, 1, one, rows=[int(rows[cand[k]])], n_threads=threads)[1]
+        excess.append(glass - plain)
+    best = sorted(np.argsort(excess)[-n:])
+    assert min(excess[k] for k in best) > W4K // 4              # hundreds of split children per row at ONE sample
+    return [cand[k] for k in best]
+
+
+@pytest.mark.parametrize("form,part", [("tree_walk", 5), ("stream", 5), ("stream", 0), ("stream", 7), ("tree_walk", 0), ("tree_walk", 7)])
+def test_c5_glass_4k_512spp_one_part_of_8(pkg, ora, form, part):
+    """configs[4] at full size on three of its 8 parts: the glass scene (build-defined GLASS extension: no reference
     semantics, the repo's oracle is the definition), 3840x2160, 512 spp, `render Streams` -- through the per-pixel tree walk
-    (the default with GLASS) and through the stream ("wavefront") form BASELINE.json names: start hits in regions, child rings,
-    spill queues.  No child ray may be dropped or cut, the RNG planes are exact (updateSeed: 512 draws per pixel), and a
-    two-row window of the part equals the oracle's stream order within north_star's 1e-4 (the order of a pixel's additions is
-    undefined, as in Accelerate's permute).  The tolerance is relative to max(|sum|, 1e-3 per sample): throughputs can be
+    (the default with GLASS) and through the stream ("wavefront") form BASELINE.json names: start hits in regions, graded passes,
+    child rings, spill queues.  No child ray may be dropped or cut, the RNG planes are exact (updateSeed: 512 draws per pixel), and
+    a window of four rows through the glass spheres equals the oracle's stream order within north_star's 1e-4 (the order of a
+    pixel's additions is undefined, as in Accelerate's permute) -- round 3 looked at two rows of one part; the oracle's stream runs
+    one row per thread now.  The tolerance is relative to max(|sum|, 1e-3 per sample): throughputs can be
     negative (Matte's factor is not clamped, Trace.hs:411), sums can cancel, so a sum below 1e-3 of white per sample -- 1e-7 of
     white in the presented image at 1e-4 -- is compared absolutely."""
     B = pkg.binding
     sp, pl = pkg.world.glass_scene()
     cam = pkg.world.initial_camera()
-    spp, part = 512, 5
+    spp = 512
     with pkg.Context(0) as c:
         c.set_scene(sp, pl)
         c.set_partition(10, 8, part)
@@ -165,15 +185,65 @@ def test_c5_glass_4k_512spp_one_part_of_8(pkg, ora, form):
         assert st["stream_rays_overflowed"] * 10000 < st["live_bounces"]     # ... the waves' own spill queues; next to nothing needs an overflow launch
     for a, b in zip(got[3:], sfc32_advance(start[3:], spp)):
         assert np.array_equal(a, b)
-    pick = [len(rows) // 2, len(rows) // 2 + 1]                 # two rows through the glass spheres
+    pick = _rows_through_the_glass_spheres(pkg, ora, rows)
+    assert len(pick) == 4
     window = initial_rows(ora, W4K, rows[pick])
     for a, b in zip(window[3:], start[3:]):
         assert np.array_equal(a, b[pick])                        # the device seeded these rows from the global pixel index
-    want, live = ora.render_streams_wavefront(sp, pl, cam, W4K, H4K, 1 << 16, spp, window, capacity_factor=8, rows=rows[pick])[:2]
+    want, live, dropped = ora.render_streams_wavefront_rows(sp, pl, cam, W4K, H4K, 1 << 16, spp, window, rows[pick], n_threads=min(ora.max_threads(), 16))
+    assert dropped == 0
     for a, b in zip(got[:3], want[:3]):
         scale = np.maximum(np.abs(b), 1e-3 * spp)
         assert np.max(np.abs(a[pick] - b) / scale) <= 1e-4
     assert not np.array_equal(want[0], np.zeros_like(want[0]))
+
+
+def test_c2_streams_against_the_oracle_at_full_size_in_both_forms(pkg, ora):
+    """`render Streams` on C2's image -- 1920x1080, scene S16, PTMI_SEED_AUTO (the result's seed) -- at 2 spp: the per-pixel chain
+    kernel AND the stream form (start-hit regions, ticket queues, lanes that refill, the per-pixel tail beside it) against the ORACLE,
+    all seven planes bit for bit, two launches each (the second in the recorded dispatch order).  Round 3 compared the stream form with
+    the chain kernel at this size -- HIP against HIP -- because only the Inline oracle ran on several threads."""
+    B = pkg.binding
+    sp, pl = pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    start = initial_planes(ora, W, H)
+    threads = min(ora.max_threads(), 16)
+    want1, live1 = ora.render_streams(sp, pl, cam, W, H, 1 << 16, 2, start, n_threads=threads)
+    want2, live2 = ora.render_streams(sp, pl, cam, W, H, 1 << 16, 2, want1, n_threads=threads)
+    for form in (B.FORM_AUTO, B.FORM_STREAM):
+        with pkg.Context(0) as c:
+            c.set_scene(sp, pl)
+            c.resize(W, H)
+            c.set_option(B.OPT_STREAMS_FORM, form)
+            c.upload_state(*start)
+            c.render(cam, 8, 2, pkg.STREAMS)
+            assert_planes_equal(c.download_state(), want1, "C2 Streams @ 2 spp, form %d, first launch" % form)
+            c.render(cam, 8, 2, pkg.STREAMS)
+            assert_planes_equal(c.download_state(), want2, "C2 Streams @ 2 spp, form %d, second launch" % form)
+            assert c.stats()["live_bounces"] == live1 + live2
+
+
+def test_glass_scene_tree_walk_against_the_oracle_at_1080p(pkg, ora):
+    """The per-pixel tree walk (the default with GLASS) on the whole 1080p glass image at 1 spp and again at 2 spp on top: equal to
+    ora_render_streams_tree BIT FOR BIT on all seven planes, counts included (round 3: 128x72)."""
+    sp, pl = pkg.world.glass_scene()
+    cam = pkg.world.initial_camera()
+    start = initial_planes(ora, W, H)
+    threads = min(ora.max_threads(), 16)
+    want1, live1, dropped1, longest1, cut1 = ora.render_streams_tree(sp, pl, cam, W, H, 1 << 16, 1, start, n_threads=threads)
+    want2, live2, dropped2, longest2, cut2 = ora.render_streams_tree(sp, pl, cam, W, H, 1 << 16, 2, want1, n_threads=threads)
+    assert dropped1 == dropped2 == cut1 == cut2 == 0
+    with pkg.Context(0) as c:
+        c.set_scene(sp, pl)
+        c.resize(W, H)
+        c.upload_state(*start)
+        c.render(cam, 8, 1, pkg.STREAMS)
+        assert_planes_equal(c.download_state(), want1, "glass scene, tree walk, 1080p, 1 spp")
+        assert c.stats()["stream_iterations"] == longest1
+        c.render(cam, 8, 2, pkg.STREAMS)
+        assert_planes_equal(c.download_state(), want2, "glass scene, tree walk, 1080p, 2 more spp")
+        st = c.stats()
+    assert st["live_bounces"] == live1 + live2 and st["stream_rays_dropped"] == 0 and st["stream_rays_truncated"] == 0
 
 
 def test_c2_stream_form_equals_the_per_pixel_kernel_at_full_size(pkg):
@@ -198,3 +268,32 @@ def test_c2_stream_form_equals_the_per_pixel_kernel_at_full_size(pkg):
             assert_planes_equal(stream.download_state(), chain.download_state(),
                                 "C2 through the stream form, launch %d (items of %s samples)" % (k, batch or "all"))
         assert stream.stats()["live_bounces"] == chain.stats()["live_bounces"]
+
+
+def test_ordered_passes_off_equals_ordered_passes_on_for_a_striped_4k_part_at_256_spp(pkg):
+    """PTMI_OPT_ORDERED_PASSES: one of 8 parts (10-row stripes) of a 4K image at 256 spp through the stream form of Streams is where the
+    ordered passes are chosen automatically (fewer than 3 pixels per lane, >= 256 spp): a pixel's seven words are handed from lane to
+    lane, across waves and XCDs, by the fence-free write-through / poll / sc1-load hand-off -- MEASURED valid on gfx950, not an
+    architectural promise (include/ptmi.h).  A caller who wants none of it sets the option to 1 (off: one pass, no hand-off inside the
+    launch): all seven planes must be the same, bit for bit, as with the automatic choice and as with 8 forced passes."""
+    B = pkg.binding
+    sp, pl = pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    planes = {}
+    for setting in (0, 1, 8):
+        with pkg.Context(0) as c:
+            c.set_scene(sp, pl)
+            c.set_partition(10, 8, 3)
+            c.resize(W4K, H4K)
+            c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+            c.set_option(B.OPT_ORDERED_PASSES, setting)
+            c.init_output(0x5EED1234)
+            for _ in range(2):                                   # (the second launch runs in the recorded dispatch order)
+                c.render(cam, 8, 256, pkg.STREAMS)
+            planes[setting] = c.download_state()
+            live = c.stats()["live_bounces"]
+        if setting:
+            assert_planes_equal(planes[setting], planes[0], "ordered passes = %d against automatic" % setting)
+            assert live == live0
+        else:
+            live0 = live

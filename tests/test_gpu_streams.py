@@ -251,7 +251,7 @@ def test_stream_form_on_the_parts_of_a_striped_image(pkg, spp):
 def test_the_stream_forms_per_pixel_tail_changes_no_bit(pkg):
     """Without GLASS the stream form leaves the cheap end of its dispatch order to the per-pixel chain kernel, launched beside the
     persistent kernel (its waves fill the slots that the persistent waves leave as they end).  Where the boundary lies --
-    PTMI_STREAM_TAIL thousandths of the recorded cost: none, the default, nearly everything -- must change no bit: four launches
+    PTMI_OPT_STREAM_TAIL thousandths of the recorded cost: none, the default, nearly everything -- must change no bit: four launches
     each (the order and the boundary are rebuilt before the second and the third), whole pixel chains and ordered passes of 4
     samples, all seven planes against the chain kernel."""
     B = pkg.binding
@@ -267,19 +267,17 @@ def test_the_stream_forms_per_pixel_tail_changes_no_bit(pkg):
             chain.render(cam, 8, spp, pkg.STREAMS)
             want.append(chain.download_state())
         live = chain.stats()["live_bounces"]
-    for tail in ("0", "150", "950"):
+    for tail in (0, 150, 950):
         for batch in (0, 4):
-            os.environ["PTMI_STREAM_TAIL"] = tail
-            try:
-                with pkg.Context(0) as c:
-                    c.set_scene(sp, pl)
-                    c.resize(w, h)
-                    c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
-                    c.set_option(B.OPT_STREAM_BATCH, batch)
-                    c.init_output(0xABCDEF)
-                    for k in range(4):
-                        c.render(cam, 8, spp, pkg.STREAMS)
-                        assert_planes_equal(c.download_state(), want[k], "tail %s, items of %s samples, launch %d" % (tail, batch or "all", k))
-                    assert c.stats()["live_bounces"] == live
-            finally:
-                os.environ.pop("PTMI_STREAM_TAIL", None)
+            with pkg.Context(0) as c:
+                c.set_scene(sp, pl)
+                c.resize(w, h)
+                c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+                c.set_option(B.OPT_STREAM_BATCH, batch)
+                c.set_option(B.OPT_STREAM_TAIL, tail)
+                assert c.get_option(B.OPT_STREAM_TAIL) == tail
+                c.init_output(0xABCDEF)
+                for k in range(4):
+                    c.render(cam, 8, spp, pkg.STREAMS)
+                    assert_planes_equal(c.download_state(), want[k], "tail %s, items of %s samples, launch %d" % (tail, batch or "all", k))
+                assert c.stats()["live_bounces"] == live

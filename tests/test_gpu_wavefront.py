@@ -166,22 +166,18 @@ def test_ordered_passes_inside_one_launch_are_bit_exact(ctx, pkg, ora, rule):
         seed_rule = ora.SEED_KEEP_ACCUMULATOR if rule == "keep" else None
         want, live = ora.render_streams(scene[0], scene[1], cam, w, h, CAP, spp, start, seed_rule=seed_rule)
         for batch in (16, 32):
-            if rule == "keep" and batch:                         # (under the keep rule a batch selects the unordered split kernel instead)
-                os.environ["PTMI_ORDERED_PASSES"] = str(spp // batch)
-            try:
-                with pkg.Context(0) as c:
-                    c.set_scene(*scene)
-                    c.resize(w, h)
-                    c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
-                    if rule == "keep":
-                        c.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_KEEP_ACCUMULATOR)
-                    else:
-                        c.set_option(B.OPT_STREAM_BATCH, batch)
-                    c.upload_state(*start)
-                    c.render(cam, 15, spp, pkg.STREAMS)
-                    got, st = c.download_state(), c.stats()
-            finally:
-                os.environ.pop("PTMI_ORDERED_PASSES", None)
+            with pkg.Context(0) as c:
+                c.set_scene(*scene)
+                c.resize(w, h)
+                c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+                if rule == "keep":                               # (under the keep rule a batch selects the unordered split kernel instead)
+                    c.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_KEEP_ACCUMULATOR)
+                    c.set_option(B.OPT_ORDERED_PASSES, spp // batch)
+                else:
+                    c.set_option(B.OPT_STREAM_BATCH, batch)
+                c.upload_state(*start)
+                c.render(cam, 15, spp, pkg.STREAMS)
+                got, st = c.download_state(), c.stats()
             assert_planes_equal(got, want, "ordered passes of %d samples, %dx%d, %s" % (batch, w, h, rule))
             assert st["live_bounces"] == live
 
@@ -221,3 +217,44 @@ def test_stream_form_with_a_scene_too_big_for_lds(ctx, pkg, ora):
     assert st["live_bounces"] == live and st["stream_rays_dropped"] == 0 and st["stream_rays_truncated"] == cut
     for a, b in zip(got[:3], want[:3]):
         assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3 + 1e-4 * np.max(np.abs(b)))) <= REL_TOL
+
+
+@pytest.mark.parametrize("graded,glass_batch", [(1, 0), (0, 0), (1, 4), (1, 16), (0, 64)])
+def test_the_split_kernels_scheduling_knobs_change_no_ray_and_no_seed(ctx, pkg, ora, graded, glass_batch):
+    """PTMI_OPT_STREAM_GRADED (passes that shrink towards the end of the launch, the default, or round 3's uniform ones) and
+    PTMI_OPT_GLASS_BATCH (GLASS hits parked in their lanes until that many are pending in the wave) decide WHEN a ray is traced and
+    by which lane, never WHICH rays exist: counts and RNG planes equal the oracle's exactly, colours within the tolerance of the
+    undefined order of a pixel's additions.  13 samples: graded passes of 4, 3, 2, 2, 1, 1 at this size."""
+    B = pkg.binding
+    scene = pkg.world.glass_scene()
+    cam = pkg.world.initial_camera()
+    w, h, spp = 128, 72, 13
+    start = initial_planes(ora, w, h)
+    ctx.set_option(B.OPT_STREAM_GRADED, graded)
+    ctx.set_option(B.OPT_GLASS_BATCH, glass_batch)
+    try:
+        assert ctx.get_option(B.OPT_STREAM_GRADED) == graded and ctx.get_option(B.OPT_GLASS_BATCH) == glass_batch
+        got, st = render(ctx, pkg, scene, cam, w, h, spp, start, stream_form=True)
+    finally:
+        ctx.set_option(B.OPT_STREAM_GRADED, 1)
+        ctx.set_option(B.OPT_GLASS_BATCH, 0)
+    want, live, dropped, steps = ora.render_streams_wavefront(scene[0], scene[1], cam, w, h, CAP, spp, start)
+    for a, b in zip(got[3:], want[3:]):
+        assert np.array_equal(a, b)
+    assert st["live_bounces"] == live and st["stream_rays_dropped"] == dropped == 0 and st["stream_iterations"] == steps
+    for a, b in zip(got[:3], want[:3]):
+        assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) <= REL_TOL
+
+
+def test_options_of_the_stream_form_are_range_checked_and_visible(pkg):
+    B = pkg.binding
+    with pkg.Context(0) as c:
+        defaults = {B.OPT_STREAM_TAIL: -1, B.OPT_ORDERED_PASSES: 0, B.OPT_GLASS_BATCH: 0, B.OPT_STREAM_GRADED: 1}
+        for opt, value in defaults.items():
+            assert c.get_option(opt) == value
+        for opt, bad in ((B.OPT_STREAM_TAIL, -2), (B.OPT_STREAM_TAIL, 1001), (B.OPT_ORDERED_PASSES, -1), (B.OPT_ORDERED_PASSES, 65),
+                         (B.OPT_GLASS_BATCH, 65), (B.OPT_STREAM_GRADED, 2)):
+            with pytest.raises(pkg.PtmiError) as e:
+                c.set_option(opt, bad)
+            assert e.value.code == B.PTMI_EINVAL
+            assert c.get_option(opt) == defaults[opt]

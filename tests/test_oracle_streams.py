@@ -102,3 +102,27 @@ def test_tree_order_equals_stream_order_up_to_rounding(ora, pkg):
     sp16, _ = pkg.world.scene16()
     assert_planes_equal(ora.render_streams_tree(sp16, pl, cam, W, H, 1 << 16, 2, start)[0],
                         ora.render_streams(sp16, pl, cam, W, H, 1 << 16, 2, start, seed_rule=ora.SEED_KEEP_ACCUMULATOR)[0], "tree without glass")
+
+
+def test_the_threaded_streams_oracles_equal_the_serial_ones(pkg, ora):
+    """ora_render_streams_ex and ora_render_streams_tree over rows on several threads (pixels are independent) -- what lets the
+    full-size GPU tests compare against them -- and the row-per-thread wrapper of the stream-order oracle: same planes, same counts."""
+    cam = pkg.world.initial_camera()
+    w, h, spp = 96, 54, 3
+    seeds = ora.gen_seeds(0x5EED1234, 0, w * h)
+    start = [np.zeros((h, w), np.float32) for _ in range(3)] + [s.reshape(h, w) for s in seeds]
+    sp, pl = pkg.world.scene16()
+    for rule in (ora.SEED_KEEP_ACCUMULATOR, ora.SEED_FROM_RESULT):
+        one = ora.render_streams(sp, pl, cam, w, h, 1 << 16, spp, start, seed_rule=rule, want_truncated=True)
+        many = ora.render_streams(sp, pl, cam, w, h, 1 << 16, spp, start, seed_rule=rule, want_truncated=True, n_threads=4)
+        assert one[1:] == many[1:] and all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(one[0], many[0]))
+    gs, gp = pkg.world.glass_scene()
+    one = ora.render_streams_tree(gs, gp, cam, w, h, 1 << 16, spp, start, stack_depth=3)
+    many = ora.render_streams_tree(gs, gp, cam, w, h, 1 << 16, spp, start, stack_depth=3, n_threads=4)
+    assert one[1:] == many[1:] and all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(one[0], many[0]))
+    rows = [5, 6, 30, 31, 53]
+    window = [a[rows] for a in start]
+    whole = ora.render_streams_wavefront(gs, gp, cam, w, h, 1 << 16, spp, window, capacity_factor=8, rows=rows)
+    split = ora.render_streams_wavefront_rows(gs, gp, cam, w, h, 1 << 16, spp, window, rows, n_threads=3)
+    assert whole[1] == split[1] and whole[2] == split[2] == 0
+    assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(whole[0], split[0]))

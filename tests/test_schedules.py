@@ -1,0 +1,65 @@
+"""Host arithmetic of the two schedules the C ABI exposes (no GPU): the passes the stream form's split kernel cuts a pixel's samples
+into (ptmi_stream_schedule) and the rebuild / record schedule of the cost-ordered dispatch (ptmi_order_schedule)."""
+import ctypes as C
+
+import pytest
+
+LANES = 64 * 4 * 6 * 256        # the persistent grid of the split kernel on an MI355X
+
+
+def test_graded_passes_cover_every_sample_once_and_shrink_towards_the_end(pkg):
+    S = pkg.binding.stream_schedule
+    for n_spp in (1, 2, 3, 7, 8, 16, 63, 64, 65, 256, 512, 1024, 4096):
+        for n_px in (1, 100, 1920 * 1080, 3840 * 270, 3840 * 2160, 10 ** 8):
+            for batch in (0, 1, 4, 16, 64):
+                for graded in (True, False):
+                    first = S(n_spp, n_px, LANES, batch, graded)
+                    assert first[0] == 0 and first[-1] == n_spp and len(first) - 1 <= 64
+                    sizes = [b - a for a, b in zip(first, first[1:])]
+                    assert all(s >= 1 for s in sizes), (n_spp, n_px, batch, graded, first)
+                    if batch:
+                        assert max(sizes) <= max(batch, (n_spp + 63) // 64)      # (64 passes at most: a batch below n_spp / 64 is raised)
+                    if graded and len(sizes) < 64:
+                        assert all(a >= b for a, b in zip(sizes, sizes[1:])), first       # long items first
+                        assert sizes[-1] <= max(1, n_spp // 8) or n_spp <= 2             # the launch ends with short items
+                    if not graded:
+                        assert len(set(sizes[:-1])) <= 1 and sizes[-1] <= sizes[0]      # uniform, the last one shorter
+
+
+def test_the_two_configurations_the_bench_runs(pkg):
+    S = pkg.binding.stream_schedule
+    assert S(64, 1920 * 1080, LANES) == [0, 16, 32, 48, 56, 60, 62, 63, 64]              # glass scene, 1080p / 64 spp
+    assert S(64, 1920 * 1080, LANES, graded=False) == [0, 16, 32, 48, 64]                # round 3's passes
+    c5 = S(512, 3840 * 270, LANES)                                                     # C5, one part of 8
+    assert c5[:6] == [0, 74, 148, 222, 296, 370] and c5[-3:] == [509, 511, 512]
+
+
+def test_schedule_refuses_bad_arguments(pkg):
+    lib = pkg.load_library()
+    buf = (C.c_int32 * 65)()
+    assert lib.ptmi_stream_schedule(-1, 10, 10, 0, 1, buf, 65) == pkg.binding.PTMI_EINVAL
+    assert lib.ptmi_stream_schedule(64, 10, 10, 0, 1, None, 65) == pkg.binding.PTMI_EINVAL
+    assert lib.ptmi_stream_schedule(64, 1920 * 1080, LANES, 0, 1, buf, 4) == pkg.binding.PTMI_ELIMIT
+    assert lib.ptmi_stream_schedule(0, 10, 10, 0, 1, buf, 65) == 1 and buf[1] == 0
+
+
+@pytest.mark.parametrize("stream_form,limit", [(0, 1 << 20), (1, 1 << 11)])
+def test_the_dispatch_order_is_rebuilt_before_launch_1_2_4_8_and_never_after_the_limit(pkg, stream_form, limit):
+    """Round 3's advisor finding: the stream form's launch counter stopped at 2^11 -- a power of two -- while the rebuild test was
+    "a power of two below 2^20", so every call after the 2048th rebuilt the order, bumped its generation and made the primary
+    kernel run again.  The schedule is one function now; walk it."""
+    lib = pkg.load_library()
+    rebuild, record = C.c_int32(0), C.c_int32(0)
+    state, rebuilds = 0, []
+    for call in range(limit + 50 if stream_form else 5000):
+        nxt = lib.ptmi_order_schedule(state, stream_form, C.byref(rebuild), C.byref(record))
+        if rebuild.value:
+            rebuilds.append(state)
+        assert record.value == (1 if state < limit else 0)
+        assert nxt == min(state + 1, limit)
+        state = nxt
+    powers = [1 << k for k in range(21) if (1 << k) < min(limit, 5000 if not stream_form else limit)]
+    assert rebuilds == powers
+    for state in (limit, limit + 1, 1 << 30, -5):                      # at and beyond the limit (and nonsense): nothing happens any more
+        nxt = lib.ptmi_order_schedule(state, stream_form, C.byref(rebuild), C.byref(record))
+        assert (rebuild.value, record.value, nxt) == (0, 0, limit)

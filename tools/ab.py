@@ -5,7 +5,9 @@
     python tools/ab.py run [--workloads c2,glass_tree] [build/ab/*.so]    # on the GPU box: one subprocess per library
 
 Workloads (1080p, 64 spp, ms per launch, best of N after warm-up): c2 (render Inline, scene S16), streams (per-pixel
-Streams, S16), s16_stream (stream form, S16), glass_tree (per-pixel tree walk, glass scene), glass_stream (stream form)."""
+Streams, S16), s16_stream (stream form, S16), glass_tree (per-pixel tree walk, glass scene), glass_stream (stream form); c5_tree /
+c5_stream: one of 8 parts of the 4K / 512-spp glass image; suffixes _uniform (PTMI_OPT_STREAM_GRADED = 0), _gK (PTMI_OPT_GLASS_BATCH = K),
+_bK (PTMI_OPT_STREAM_BATCH = K)."""
 import glob
 import json
 import os
@@ -17,13 +19,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
+# name -> (scene, algorithm, form, options {PTMI_OPT_* name without the prefix: value}, shape or None = 1080p / 64 spp whole image)
+C5_PART = (3840, 2160, 512, 8)      # one of 8 parts (10-row stripes) of BASELINE configs[4]
 WORKLOADS = {
-    "c2": ("s16", "inline", "auto"), "streams": ("s16", "streams", "auto"), "s16_stream": ("s16", "streams", "stream"),
-    "glass_tree": ("glass", "streams", "auto"), "glass_stream": ("glass", "streams", "stream"),
-    "s16_stream_b16": ("s16", "streams", "stream16"), "glass_stream_b8": ("glass", "streams", "stream8"),
-    "glass_stream_b32": ("glass", "streams", "stream32"), "glass_stream_b16": ("glass", "streams", "stream16"),
-    "glass_stream_b64": ("glass", "streams", "stream64"), "glass_stream_b4": ("glass", "streams", "stream4"),
+    "c2": ("s16", "inline", "auto", {}, None), "streams": ("s16", "streams", "auto", {}, None), "s16_stream": ("s16", "streams", "stream", {}, None),
+    "glass_tree": ("glass", "streams", "auto", {}, None), "glass_stream": ("glass", "streams", "stream", {}, None),
+    "glass_stream_uniform": ("glass", "streams", "stream", {"STREAM_GRADED": 0}, None),
+    "c5_tree": ("glass", "streams", "auto", {}, C5_PART), "c5_stream": ("glass", "streams", "stream", {}, C5_PART),
+    "c5_stream_uniform": ("glass", "streams", "stream", {"STREAM_GRADED": 0}, C5_PART),
 }
+for _k in (2, 4, 8, 16, 32):
+    WORKLOADS["glass_stream_g%d" % _k] = ("glass", "streams", "stream", {"GLASS_BATCH": _k}, None)
+    WORKLOADS["c5_stream_g%d" % _k] = ("glass", "streams", "stream", {"GLASS_BATCH": _k}, C5_PART)
+for _k in (4, 8, 16, 32, 64):
+    WORKLOADS["glass_stream_b%d" % _k] = ("glass", "streams", "stream", {"STREAM_BATCH": _k}, None)
+    WORKLOADS["s16_stream_b%d" % _k] = ("s16", "streams", "stream", {"STREAM_BATCH": _k}, None)
 
 
 def one(lib, names, width=1920, height=1080, spp=64, repeats=7):
@@ -35,34 +45,38 @@ def one(lib, names, width=1920, height=1080, spp=64, repeats=7):
         pkg.binding.load_library(lib)
     else:
         pkg._build.build_lib()
+    B = pkg.binding
     cam = pkg.world.initial_camera()
     out = {}
     for name in names:
-        scene, alg, form = WORKLOADS[name]
+        scene, alg, form, options, shape = WORKLOADS[name]
+        w, h, n_spp, parts = shape if shape else (width, height, spp, 1)
         sp, pl = {"s16": pkg.world.scene16, "glass": pkg.world.glass_scene}[scene]()
         with pkg.Context(0) as c:
             c.set_scene(sp, pl)
-            c.resize(width, height)
-            c.set_option(pkg.binding.OPT_STREAMS_FORM, pkg.binding.FORM_STREAM if form.startswith("stream") else pkg.binding.FORM_AUTO)
-            if form.startswith("stream") and form[6:]:
-                c.set_option(pkg.binding.OPT_STREAM_BATCH, int(form[6:]))
+            if parts > 1:
+                c.set_partition(10, parts, 0)
+            c.resize(w, h)
+            c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM if form == "stream" else B.FORM_AUTO)
+            for opt, value in options.items():
+                c.set_option(getattr(B, "OPT_" + opt), value)
             c.init_output(0x5EED1234)
             algorithm = pkg.INLINE if alg == "inline" else pkg.STREAMS
             t_end = time.perf_counter() + 0.25
             while time.perf_counter() < t_end:                       # clock ramp + cost order
-                c.render(cam, 8, spp, algorithm)
+                c.render(cam, 8, n_spp, algorithm)
                 c.synchronize()
             times = []
             for _ in range(repeats):
                 c.synchronize()
                 t0 = time.perf_counter()
-                c.render(cam, 8, spp, algorithm)
+                c.render(cam, 8, n_spp, algorithm)
                 c.synchronize()
                 times.append((time.perf_counter() - t0) * 1e3)
             out[name] = round(min(times), 3)
-            if form.startswith("stream"):
+            if form == "stream":
                 c.reset_stats()
-                c.render(cam, 8, spp, algorithm)
+                c.render(cam, 8, n_spp, algorithm)
                 st = c.stats()
                 if st["stream_rays_spilled"] or st["stream_rays_dropped"]:
                     out[name + "_spilled/overflowed/dropped"] = [st["stream_rays_spilled"], st["stream_rays_overflowed"], st["stream_rays_dropped"]]

@@ -54,7 +54,11 @@ def main():
                 "waves": waves, "mean_wave_cycles": round(total / waves), "longest_wave_cycles": longest,
                 "mean_over_longest": round(total / waves / max(longest, 1), 4), "spilled": st["stream_rays_spilled"], "live": st["live_bounces"],
                 "per_xcd": {"waves": wc[24:32], "mean_wave_kcycles": [round(wc[32 + x] * 4.096 / max(wc[24 + x], 1)) for x in range(8)],
-                            "longest_wave_kcycles": [round(wc[40 + x] * 4.096) for x in range(8)], "trips_per_wave": [round(wc[48 + x] / max(wc[24 + x], 1)) for x in range(8)]}}
+                            "longest_wave_kcycles": [round(wc[40 + x] * 4.096) for x in range(8)], "trips_per_wave": [round(wc[48 + x] / max(wc[24 + x], 1)) for x in range(8)]},
+                "when_the_tickets_ran_out_per_wave": {"lanes_with_an_item": round(wc[56] / waves, 1), "their_samples_left": round(wc[57] / waves, 1),
+                                                      "spill_records": round(wc[58] / waves, 1), "ring_records": round(wc[59] / waves, 1),
+                                                      "trips_after_that": round(wc[60] / waves, 1), "most_trips_after_that": wc[61]},
+                "waves_starting_per_82us_bin": wc[64:96], "waves_ending_per_82us_bin_from_32": wc[96:160], "their_mean_trips": [round(t / max(n, 1)) for n, t in zip(wc[96:160], wc[160:224])]}
     print(json.dumps(out))
 
 
