@@ -21,7 +21,7 @@
 --
 -- > cabal run ptmi-dump -- ptmi_dump.bin          # ~70 MB: 800x600, the reference's own size and iteration limit
 --
--- What is written, and which assumption it settles (A1-A7 as in DESIGN.md section 2 / oracle/pt_oracle.h):
+-- What is written, and which assumption it settles (A1-A7 as in DESIGN.md section 2 of the MI355X repository):
 --
 --   * @words@         the three seed words per pixel handed to 'createWith' (a fixed function of the pixel index)
 --   * @created@       @run (createWith (use words))@, every plane of its representation in 'toVectors' order
