@@ -123,7 +123,7 @@ def valu_accounting(pkg, kernel_ms):
     changed since the profile was taken (source_hash); implied_clock_ghz = the shader clock this run's launch time implies
     for the same cycle count -- outside 2.1-2.5 GHz the profile no longer describes the binary."""
     d, name = None, None
-    for tag in ("r03", "r02"):
+    for tag in ("r04", "r03", "r02"):
         d = load_json("%s_valu_roofline.json" % tag)
         if d:
             name = "profiles/%s_valu_roofline.json" % tag
@@ -150,6 +150,21 @@ def valu_accounting(pkg, kernel_ms):
         return None
 
 
+def streams_rooflines(pkg):
+    """{workload key: the VALU issue accounting of its kernel} from the newest profiles/rNN_valu_roofline_streams.json
+    (tools/valu_roofline.py streams TAG: the accounting of `roofline.valu`, for the Streams kernels), with `stale` by the same hash rule."""
+    for tag in ("r04", "r03"):
+        d = load_json("%s_valu_roofline_streams.json" % tag)
+        if d:
+            now = pkg._build.source_hash()
+            return {key: {"kernel": a["kernel"], "valu_issue_frac": a["frac_in_profile"], "valu_issue_frac_priced_with_measured_opcode_costs": a["priced_with_measured_rates"]["frac"],
+                          "active_lane_frac": a["active_lane_frac"], "simd_cycles_per_valu_instr": a["measured_simd_cycles_per_instr"],
+                          "valu_wave_instr_per_call": round(a["valu_wave_instr_per_launch"]), "hbm_MB_per_call": a.get("hbm_MB_per_call"),
+                          "kernel_us_in_profile": a["kernel_us_in_profile"], "source": a["source"], "profile_source_hash": a.get("source_hash"),
+                          "stale": a.get("source_hash") != now} for key, a in d.items()}
+    return {}
+
+
 def also_measurements(pkg, torch):
     """The other BASELINE.json configs and the Streams forms, on this GPU, after the headline: 3 timed steps each behind a
     short warm-up (clock ramp, recorded dispatch order: it is rebuilt before launch 1, 2, 4, 8, ... of a context, so nine warm-up
@@ -159,8 +174,9 @@ def also_measurements(pkg, torch):
     cam = pkg.world.initial_camera()
     scenes = {"s16": pkg.world.scene16(), "main": pkg.world.main_scene(), "glass": pkg.world.glass_scene()}
     out = []
+    rooflines = streams_rooflines(pkg)
 
-    def run(name, scene, width, height, spp, limit, algorithm, part_of=0, stripe=10, stream_form=False, warm=3, steps=3, note=None):
+    def run(name, scene, width, height, spp, limit, algorithm, part_of=0, stripe=10, stream_form=False, warm=3, steps=3, note=None, profile=None):
         sp, pl = scenes[scene]
         with pkg.Context(0) as c:
             c.set_scene(sp, pl)
@@ -189,6 +205,8 @@ def also_measurements(pkg, torch):
             rec["Msamples_per_s"] = round(rows * width * spp * limit / (ms * 1e-3) / 1e6, 1)
         if note:
             rec["note"] = note
+        if profile and profile in rooflines:                 # the kernel's real bound, from the committed PMC profile of this workload
+            rec["roofline"] = dict(rooflines[profile], bound="valu issue")
         out.append(rec)
 
     run("C0: 800x600, mainScene, limit 15, render Inline, 1 spp per call (the reference's own configuration; compileFor's closure)", "main", 800, 600, 1, 15, pkg.INLINE, warm=40, steps=20)
@@ -196,12 +214,12 @@ def also_measurements(pkg, torch):
     run("C3: 3840x2160, 256 spp, limit 8, S16, render Inline", "s16", 3840, 2160, 256, BOUNCE_LIMIT, pkg.INLINE)
     run("C4: 3840x2160, 1024 spp, limit 8, S16, render Inline, the whole image on one GPU", "s16", 3840, 2160, 1024, BOUNCE_LIMIT, pkg.INLINE, warm=2)
     run("C4, one part of 8 (10-row stripes): what one rank of the 8-GPU job renders", "s16", 3840, 2160, 1024, BOUNCE_LIMIT, pkg.INLINE, part_of=8)
-    run("C5, one part of 8: glass scene, 3840x2160, 512 spp, render Streams, per-pixel tree walk (the default with GLASS)", "glass", 3840, 2160, 512, BOUNCE_LIMIT, pkg.STREAMS, part_of=8)
-    run("C5, one part of 8, stream ('wavefront') form: start-hit regions, child rings (BASELINE configs[4]'s path)", "glass", 3840, 2160, 512, BOUNCE_LIMIT, pkg.STREAMS, part_of=8, stream_form=True)
-    run("C2 through render Streams, per-pixel chain", "s16", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, warm=9)
-    run("C2 through render Streams, stream form", "s16", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, stream_form=True, warm=9)
-    run("glass scene, 1920x1080, 64 spp, render Streams, tree walk", "glass", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, warm=9)
-    run("glass scene, 1920x1080, 64 spp, render Streams, stream form", "glass", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, stream_form=True, warm=9)
+    run("C5, one part of 8: glass scene, 3840x2160, 512 spp, render Streams, per-pixel tree walk (the default with GLASS)", "glass", 3840, 2160, 512, BOUNCE_LIMIT, pkg.STREAMS, part_of=8, profile="c5_tree")
+    run("C5, one part of 8, stream ('wavefront') form: start-hit regions, graded passes, child rings (BASELINE configs[4]'s path)", "glass", 3840, 2160, 512, BOUNCE_LIMIT, pkg.STREAMS, part_of=8, stream_form=True, profile="c5_stream")
+    run("C2 through render Streams, per-pixel chain", "s16", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, warm=9, profile="streams")
+    run("C2 through render Streams, stream form", "s16", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, stream_form=True, warm=9, profile="s16_stream")
+    run("glass scene, 1920x1080, 64 spp, render Streams, tree walk", "glass", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, warm=9, profile="glass_tree")
+    run("glass scene, 1920x1080, 64 spp, render Streams, stream form", "glass", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, stream_form=True, warm=9, profile="glass_stream")
     return out
 
 
@@ -224,6 +242,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check-image", action="store_true",
                     help="N > 1: after the timed steps rank 0 renders the same samples in ONE context and compares the gathered image bit for bit")
+    ap.add_argument("--no-precheck", action="store_true",
+                    help="N > 1: skip the check BEFORE the timed steps (stripes rendered at a reduced sample count, gathered without overlap and "
+                         "compared on rank 0 with one context's image, bit for bit) and the timing of that one gather")
     ap.add_argument("--no-also", action="store_true", help="skip the `also` block (the other BASELINE configs after the headline, ~4 s)")
     ap.add_argument("--no-n1-reference", action="store_true", help="strong scaling: skip the one-GPU timing of the same image on rank 0")
     ap.add_argument("--stripe-rows", type=int, default=0, help="0 = a stripe that deals every rank the same number of rows")
@@ -338,6 +359,51 @@ def main():
     if world > 1:
         gather.overlapped(color)                     # first collective = communicator set-up; not a warm-up step
         gather.wait()
+    # N > 1, before anything is timed: does the job produce the right image, and did RCCL see N ranks on N devices?  The stripes at a
+    # reduced sample count, ONE gather that overlaps nothing (timed on its own: what xGMI delivers per peer), and on rank 0 the same
+    # samples rendered by one context, compared bit for bit.
+    collective = None
+    if world > 1:
+        ctx.init_output(SEED0)
+        spp_check = min(spp, 16)
+        ctx.render(cam, BOUNCE_LIMIT, spp_check, algorithm)
+        fence()
+        t_g = time.perf_counter()
+        checked = gather(color)                      # on the render stream, nothing beside it
+        fence()
+        t_gather = time.perf_counter() - t_g
+        tg = torch.tensor([t_gather], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
+        mine = {"rank": rank, "cuda_device": int(torch.cuda.current_device()), "name": props.name,
+                "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")), "rows": int(ctx.local_rows)}
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        bytes_per_rank = 3 * part.max_rows() * width * 4
+        collective = {"backend": dist.get_backend(), "world_size": int(dist.get_world_size()),
+                      "distinct_devices": len({(d["cuda_device"], d["pci_bus_id"], d["uuid"]) for d in seen}),
+                      "devices": seen, "collective": "torch.distributed.gather of the three colour planes to rank 0 (RCCL: every peer sends over its own xGMI link)",
+                      "bytes_per_rank": bytes_per_rank, "gather_ms_not_overlapped": round(float(tg[0]) * 1e3, 4),
+                      "GBps_per_peer": round(bytes_per_rank / float(tg[0]) / 1e9, 2) if float(tg[0]) > 0 else None,
+                      "GBps_into_root": round(bytes_per_rank * (world - 1) / float(tg[0]) / 1e9, 2) if float(tg[0]) > 0 else None,
+                      "note": "the timed steps overlap this gather with the next step's render; this figure is one gather alone (stitch into [3][H][W] on rank 0 included)"}
+        if not args.no_precheck:
+            ok = None
+            if rank == 0:
+                import numpy as np
+                with pkg.Context(local_rank) as whole:
+                    whole.set_scene(spheres, planes)
+                    whole.resize(width, height)
+                    whole.init_output(SEED0)
+                    whole.render(cam, BOUNCE_LIMIT, spp_check, algorithm)
+                    want = whole.download_color()
+                got = checked.cpu().numpy()
+                ok = all(np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)) for k in range(3))
+            flag = [ok]
+            dist.broadcast_object_list(flag, src=0)
+            collective["gathered_image_equals_one_context_at_%d_spp" % spp_check] = bool(flag[0])
+            if not flag[0]:
+                raise SystemExit("bench.py: the gathered image of %d ranks differs from one context's image: nothing is timed" % world)
     ctx.init_output(SEED0)
     for _ in range(args.warmup):
         step()
@@ -465,6 +531,8 @@ def main():
             "live_Mbounces_per_s": round(live_total / elapsed / 1e6, 1),
             "roofline": roofline,
         }
+        if collective is not None:
+            out["collective"] = collective
         if image_equal is not None:
             out["gathered_image_equals_one_context"] = bool(image_equal)
         if n1_ms is not None:

@@ -153,3 +153,45 @@ def test_group_of_8_in_the_8_gpu_shape(pkg):
         st = g.stats()
     assert_planes_equal(got, want, "group of 8, 10-row stripes, 4K")
     assert st["live_bounces"] == live and st["samples"] == w * h * spp
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_device_count() < 2, reason="needs two physical GPUs: arms itself on the first multi-GPU box the suite meets")
+@pytest.mark.parametrize("root", [0, 1])
+def test_group_gathers_between_two_physical_devices(pkg, root):
+    """ptmi_group_gather_color between REAL devices (ptmi_group.cpp: ncclCommInitAll over the members' devices, grouped ncclSend /
+    ncclRecv on per-member streams over xGMI, the stitch kernel on the root) -- never run before round 4's boxes: every earlier test shared
+    one device.  As many members as the box has devices (at most 8), 4K in 10-row stripes; the gathered planes on either root, and the
+    host read-out, equal one context's image bit for bit."""
+    n = min(_device_count(), 8)
+    sp, pl = pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    w, h, spp = 3840, 2160, 2
+    with pkg.Context(0) as c:
+        c.set_scene(sp, pl)
+        c.resize(w, h)
+        c.init_output(0x5EED1234)
+        c.render(cam, 8, spp)
+        want = c.download_color()
+        live = c.stats()["live_bounces"]
+    with pkg.Group(list(range(n)), 10) as g:
+        g.set_scene(sp, pl)
+        g.resize(w, h)
+        g.init_output(0x5EED1234)
+        g.render(cam, 8, spp)
+        g.synchronize()
+        assert_planes_equal(g.download_color(), want, "group of %d devices, host read-out" % n)
+        assert g.stats()["live_bounces"] == live
+        with pkg.Context(root) as out:                  # the destination planes live on the root member's device
+            out.resize(w, h)
+            out.upload_state(*[np.full((h, w), -1.0, np.float32)] * 3)
+            r, gp, b = out.device_planes()[:3]
+            for _ in range(2):                           # the second gather reuses the communicator
+                g.gather_color(root, r, gp, b)
+            got = out.download_color()
+    assert_planes_equal(got, want, "group of %d devices, RCCL gather to member %d" % (n, root))

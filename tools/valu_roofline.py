@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""valu_roofline.py PMC_SUMMARY VALU_RATES [TAG] -- the VALU issue roofline of the C2 launch (profiles/<TAG>_valu_roofline.json).
+"""valu_roofline.py PMC_SUMMARY VALU_RATES [TAG] -- the VALU issue roofline of the C2 launch (profiles/<TAG>_valu_roofline.json);
+valu_roofline.py streams TAG -- the same accounting for the Streams kernels (profiles/<TAG>_valu_roofline_streams.json).
 
 The kernel's bound is VALU issue, not HBM (its physical traffic is 0.4 % of the HBM peak).  A SIMD issues one wave64
 vector instruction per 2 cycles at best (32 lanes per cycle), one per 4 for half-rate instructions (v_fma_f32, every
@@ -30,17 +31,13 @@ MEASURED_OP = {"ADD_F32": "v_add_f32", "MUL_F32": "v_mul_f32", "FMA_F32": "v_fma
                "ADD_F64": "v_add_f64", "MUL_F64": "v_mul_f64", "FMA_F64": "v_fma_f64", "TRANS_F64": "v_sqrt_f32", "OTHER": "v_mov_b32"}
 
 
-def main():
-    summary = json.load(open(sys.argv[1]))
-    rates = json.load(open(sys.argv[2]))
-    tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
-    name, rec = next((k, v) for k, v in summary.items() if "render_inline_kernel" in k)
+def account(name, rec, ops8):
+    """The VALU issue accounting of one kernel of a pmc_summary (see the module docstring)."""
     c, calls = rec["counters_total"], rec["calls"]
     per = {k: v / calls for k, v in c.items()}
     mix = {k.replace("SQ_INSTS_VALU_", ""): per[k] for k in per if k.startswith("SQ_INSTS_VALU_")}
     total = per["SQ_INSTS_VALU"]
     mix["OTHER"] = total - sum(mix.values())
-    ops8 = rates["results"]["waves_per_simd_8"]["ops"]
     nominal = sum(mix[k] * NOMINAL[k] for k in mix)
     # the one class whose price is in doubt: v_fma_f32 -- 2 cycles in the microarchitecture guide's table, 3.6 measured here
     # (build/valu_rates); NOMINAL takes 4 (the class of the other half-rate instructions)
@@ -52,9 +49,8 @@ def main():
     kernel_us = rec["avg_us"]
     clock_ghz = cycles_per_xcd / (kernel_us * 1e3)
     measured_cycles = n_simds * cycles_per_xcd
-    out = {
-        "kernel": name, "workload": summary.get("_bench", {}).get("workload"),
-        "source": "rocprofv3 --pmc passes of tools/pmc_kernels.sh c2 (means over all launches of the run) + build/valu_rates",
+    return {
+        "kernel": name,
         "n_simds": n_simds, "clock_ghz": round(clock_ghz, 4), "kernel_us_in_profile": kernel_us,
         "valu_wave_instr_per_launch": total,
         "mix_wave_instr_per_launch": {k: round(v) for k, v in sorted(mix.items())},
@@ -63,8 +59,6 @@ def main():
         "frac_in_profile": round(nominal / measured_cycles, 4),
         "frac_with_v_fma_f32_at_2_cycles": round(fma2 / measured_cycles, 4),
         "frac_with_v_fma_f32_as_measured": round(fma36 / measured_cycles, 4), "v_fma_f32_cycles_measured": ops8["v_fma_f32"]["cycles"],
-        # of the sources the PROFILED binary was built from (tools/profile_round.sh records it on the GPU box)
-        "source_hash": os.environ.get("PTMI_PROFILE_SOURCE_HASH") or graft.load_package()._build.source_hash(),
         "avg_issue_cycles_per_instr": round(nominal / total, 4),
         "measured_simd_cycles_per_instr": round(measured_cycles / total, 4),
         "priced_with_measured_rates": {"issue_cycles": measured_price, "frac": round(measured_price / measured_cycles, 4),
@@ -74,7 +68,70 @@ def main():
                                  max(v["cycles"] for k, v in ops8.items() if k.startswith("v_"))],
         "active_lane_frac": round(per["SQ_THREAD_CYCLES_VALU"] / total / 64.0, 4),
         "wave_cycles_waiting_for_issue_share": rec.get("wave_cycles_waiting_share"),
+        "hbm_MB_per_call": round(rec.get("hbm_read_MB_per_call", 0.0) + rec.get("hbm_write_MB_per_call", 0.0), 1) if "hbm_read_MB_per_call" in rec else None,
     }
+
+
+# the Streams kernels: which kernel of which PMC summary (profiles/<tag>_pmc_<key>.json) stands for which workload of bench.py's `also` block
+STREAMS = {"streams": "render_streams_kernel", "s16_stream": "streams_pixels_kernel", "glass_tree": "render_streams_tree_kernel",
+           "glass_stream": "streams_split_kernel", "c5_tree": "render_streams_tree_kernel", "c5_stream": "streams_split_kernel"}
+
+
+def streams(tag):
+    """valu_roofline.py streams TAG -> profiles/<TAG>_valu_roofline_streams.json: the same accounting for the Streams kernels."""
+    rates = json.load(open(os.path.join(ROOT, "profiles", "%s_valu_rates.json" % tag)))
+    ops8 = rates["results"]["waves_per_simd_8"]["ops"]
+    source_hash = os.environ.get("PTMI_PROFILE_SOURCE_HASH") or graft.load_package()._build.source_hash()
+    out = {}
+    for key, kernel in STREAMS.items():
+        path = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (tag, key))
+        if not os.path.exists(path):
+            continue
+        summary = json.load(open(path))
+        found = [(k, v) for k, v in summary.items() if kernel in k and "counters_total" in v and "SQ_INSTS_VALU" in v["counters_total"]]
+        if not found:
+            continue
+        name, rec = max(found, key=lambda kv: kv[1]["total_ms"])
+        if key == "s16_stream":
+            # Two kernels share the chip in this call: the persistent streams_pixels_kernel and, beside it on a low-priority stream, the
+            # per-pixel chain kernel that renders the cheap end of the dispatch order (the TAIL).  Neither kernel's own duration is the
+            # time its instructions had the SIMDs to themselves, so the accounting is of the CALL: both kernels' instructions over the
+            # span from their common start to the end of the later one (the tail kernel's duration: it is enqueued at the fork).
+            tail = [(k, v) for k, v in summary.items() if "render_streams_kernel" in k and "counters_total" in v and "SQ_INSTS_VALU" in v["counters_total"]]
+            if tail:
+                tname, trec = tail[0]
+                both = {"calls": rec["calls"], "avg_us": max(rec["avg_us"], trec["avg_us"]), "counters_total": {}}
+                for cname, value in rec["counters_total"].items():
+                    both["counters_total"][cname] = value + trec["counters_total"].get(cname, 0.0) * rec["calls"] / trec["calls"]
+                span_cycles = rec["counters_total"]["GRBM_GUI_ACTIVE"] / rec["avg_us"] * both["avg_us"]     # the same clock over the longer span
+                both["counters_total"]["GRBM_GUI_ACTIVE"] = span_cycles
+                for k2 in ("hbm_read_MB_per_call", "hbm_write_MB_per_call"):
+                    if k2 in rec:
+                        both[k2] = rec[k2] + trec.get(k2, 0.0)
+                name, rec = name + " + " + tname + " (the tail beside it)", both
+        a = account(name, rec, ops8)
+        a.update({"workload": summary.get("_bench", {}).get("workload"), "source": "profiles/%s_pmc_%s.json + profiles/%s_valu_rates.json" % (tag, key, tag),
+                  "source_hash": source_hash})
+        out[key] = a
+    json.dump(out, open(os.path.join(ROOT, "profiles", "%s_valu_roofline_streams.json" % tag), "w"), indent=1)
+    for key, a in out.items():
+        print("%-13s %-40s issue frac %.3f  active lanes %.3f  cycles / instr %.3f  HBM MB / call %s" % (
+            key, a["kernel"][:40], a["frac_in_profile"], a["active_lane_frac"], a["measured_simd_cycles_per_instr"], a["hbm_MB_per_call"]))
+
+
+def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "streams":
+        return streams(sys.argv[2])
+    summary = json.load(open(sys.argv[1]))
+    rates = json.load(open(sys.argv[2]))
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
+    name, rec = next((k, v) for k, v in summary.items() if "render_inline_kernel" in k)
+    ops8 = rates["results"]["waves_per_simd_8"]["ops"]
+    out = account(name, rec, ops8)
+    out.update({"workload": summary.get("_bench", {}).get("workload"),
+                "source": "rocprofv3 --pmc passes of tools/pmc_kernels.sh c2 (means over all launches of the run) + build/valu_rates",
+                # of the sources the PROFILED binary was built from (tools/profile_round.sh records it on the GPU box)
+                "source_hash": os.environ.get("PTMI_PROFILE_SOURCE_HASH") or graft.load_package()._build.source_hash()})
     path = os.path.join(ROOT, "profiles", "%s_valu_roofline.json" % tag)
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
