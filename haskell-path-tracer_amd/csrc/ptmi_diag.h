@@ -21,7 +21,7 @@ namespace diag {
 
 #define PTMI_PROBE __device__ __forceinline__
 #ifndef PTMI_SPLIT_HIST_SHIFT
-#define PTMI_SPLIT_HIST_SHIFT 13       // bins of 82 us
+#define PTMI_SPLIT_HIST_SHIFT 14       // bins of 164 us
 #endif
 
 PTMI_PROBE unsigned int lanes(bool on) { return (unsigned int)__builtin_popcountll(__ballot(on)); }

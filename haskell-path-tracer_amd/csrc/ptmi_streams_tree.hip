@@ -213,45 +213,62 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                 // instead cost 12 %.)
                 if (pending && !has_ray && !near_zero(throughput)) {   // alive
                     probe.shade();
+                    // GLASS is an ARM of the one shade (as in the stream form's split kernel, ptmi_stream_split.hip): genVec's three draws come
+                    // before the match for every material, ia = dir . n and the mirror direction are Glossy's too, and the reflection child is
+                    // what the common tail makes of `next = reflection` and the factor R; only Schlick's R, the refraction direction and the
+                    // SECOND child -- which waits on the lane's stack -- are a divergent block.  Operation for operation the oracle's
+                    // glass_children (glass_refraction_child, ptmi_device.h), so the planes stay bit-identical.
                     const float4 ma = M[2 * idx], mb = M[2 * idx + 1];
                     const bool capped = steps + 1u >= step_cap;
-                    if (f2u(mb.x) == 2u) {                        // GLASS: two children (extension; spec = the oracle's glass_children)
-                        acc = acc + (scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);
-                        ++steps;
-                        V3 ko[2], kd[2], kt[2]; Sfc32 ks[2];
-                        glass_children(mk(ma.x, ma.y, ma.z), glass_constants_of<LDS_SCENE>(mb), pos, normal, d, throughput, seed, ko, kd, kt, ks);
-                        live += 2u;
-                        if (capped) { cut += 2u; pending = false; ended = true; }
-                        else {
-                            // while the cached reflection's subtree is walked, the cached refraction "waits": one slot less
-                            if (sp < kTreeStackDepth - ((prefix && entry_i == 1 && first_is_reflection) ? 1 : 0)) {
-                                if (sp < kTreeFastLevels) {
-                                    float4 *r = fast + (size_t)sp * kRenderBlock * 4;
-                                    r[0] = float4{ko[1].x, ko[1].y, ko[1].z, kd[1].x};
-                                    r[1] = float4{kd[1].y, kd[1].z, kt[1].x, kt[1].y};
-                                    r[2] = float4{kt[1].z, u2f(ks[1].a), u2f(ks[1].b), u2f(ks[1].c)};
-                                    r[3] = float4{u2f(ks[1].counter), u2f(steps), 0.0f, 0.0f};
-                                } else {
-                                    const uint32_t e[14] = {f2u(ko[1].x), f2u(ko[1].y), f2u(ko[1].z), f2u(kd[1].x), f2u(kd[1].y), f2u(kd[1].z),
-                                                            f2u(kt[1].x), f2u(kt[1].y), f2u(kt[1].z), ks[1].a, ks[1].b, ks[1].c, ks[1].counter, steps};
-                                    const int q0 = sp - kTreeFastLevels;
-                                    for (int q = 0; q < 14; ++q) stack_w[q0 < kTreeStackDepth - kTreeFastLevels ? q0 : 0][q] = e[q];
-                                }
-                                ++sp;
+                    const bool glass = f2u(mb.x) == 2u, matte = f2u(mb.x) == 0u;
+                    const V3 color = mk(ma.x, ma.y, ma.z);
+                    V3 rv;
+                    rv.x = gen_component(seed); rv.y = gen_component(seed); rv.z = gen_component(seed);
+                    const float ia = dot(d, normal);
+                    const V3 reflection = d - scale_l(2.0f * ia, normal);
+                    ++steps;
+                    float glass_R = 0.0f;
+                    if (glass) {                                  // the refraction child (extension; spec = the oracle's glass_children)
+                        V3 ko, kd, kt; Sfc32 ks;
+                        glass_R = glass_refraction_child(color, glass_constants_of<LDS_SCENE>(mb), pos, normal, d, ia, reflection, throughput, seed, ko, kd, kt, ks);
+                        // while the cached reflection's subtree is walked, the cached refraction "waits": one slot less
+                        if (capped) {
+                        } else if (sp < kTreeStackDepth - ((prefix && entry_i == 1 && first_is_reflection) ? 1 : 0)) {
+                            if (sp < kTreeFastLevels) {
+                                float4 *r = fast + (size_t)sp * kRenderBlock * 4;
+                                r[0] = float4{ko.x, ko.y, ko.z, kd.x};
+                                r[1] = float4{kd.y, kd.z, kt.x, kt.y};
+                                r[2] = float4{kt.z, u2f(ks.a), u2f(ks.b), u2f(ks.c)};
+                                r[3] = float4{u2f(ks.counter), u2f(steps), 0.0f, 0.0f};
                             } else {
-                                ++dropped;
+                                const uint32_t e[14] = {f2u(ko.x), f2u(ko.y), f2u(ko.z), f2u(kd.x), f2u(kd.y), f2u(kd.z),
+                                                        f2u(kt.x), f2u(kt.y), f2u(kt.z), ks.a, ks.b, ks.c, ks.counter, steps};
+                                const int q0 = sp - kTreeFastLevels;
+                                for (int q = 0; q < 14; ++q) stack_w[q0 < kTreeStackDepth - kTreeFastLevels ? q0 : 0][q] = e[q];
                             }
-                            pos = ko[0]; d = kd[0]; throughput = kt[0]; seed = ks[0];
-                            pending = false; has_ray = true;
+                            ++sp;
+                        } else {
+                            ++dropped;
                         }
-                    } else {
-                        // results: colour += emittance * throughput for EVERY hit; then the new ray
-                        shade(M, idx, pos, normal, pos, d, throughput, acc, seed);
-                        ++steps; ++live;
-                        pending = false;
-                        if (capped) { ++cut; ended = true; }
-                        else has_ray = true;
                     }
+                    // Matte: rotate (anglesToQuaternion $ pi *^ rv) iNormal | Glossy: rotate (anglesToQuaternion $ (1 - p) *^ rv) reflection
+                    const V3 axis = matte ? normal : reflection;
+                    const float hk = matte ? 0.5f * kPi : mb.w;
+                    const V3 rotated = rotate(quaternion_from_half_angles(hk * rv.x, hk * rv.y, hk * rv.z), axis);
+                    const float nd = dot(rotated, axis);
+                    const float brdf = matte ? mb.z * nd : __builtin_fmaxf(0.0f, nd);
+                    constexpr float next_ray_prob = 1.0f / (kPi * 2.0f);
+                    const float factor = glass ? glass_R : brdf * next_ray_prob;
+                    const V3 next = mk(glass ? reflection.x : rotated.x, glass ? reflection.y : rotated.y, glass ? reflection.z : rotated.z);
+                    // results: colour += emittance * throughput for EVERY hit (computeResult, Trace.hs:318-323); then the new ray
+                    acc = acc + (scale_r(color, ma.w) * throughput);
+                    pos = pos + scale_r(next, kEpsilon);
+                    d = next;
+                    throughput = throughput * scale_r(color, factor);
+                    live += glass ? 2u : 1u;
+                    pending = false;
+                    if (capped) { cut += glass ? 2u : 1u; ended = true; }
+                    else has_ray = true;
                 }
                 if (has_ray) {
                     probe.trace();

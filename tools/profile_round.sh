@@ -1,10 +1,10 @@
 #!/bin/bash
 # profile_round.sh -- the measurement pass behind profiles/<tag>_* (run ON the GPU box, from the repo root):
-#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/profile_round.sh r03'
-# then, back in the container:  bash tools/collect_profiles.sh r03   (copies the summaries into profiles/).
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/profile_round.sh r04'
+# then, back in the container:  bash tools/collect_profiles.sh r04   (copies the summaries into profiles/).
 # Counters are collected in their own passes (rocprofv3 --pmc with --kernel-trace only), the program itself after `--`.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -27,6 +27,8 @@ bash tools/pmc_kernels.sh streams --algorithm streams > "$OUT/pmc_streams.log" 2
 bash tools/pmc_kernels.sh glass_tree --scene glass --algorithm streams > "$OUT/pmc_glass_tree.log" 2>&1; echo "pmc glass tree rc=$?"
 bash tools/pmc_kernels.sh glass_stream --scene glass --algorithm streams --streams-form stream > "$OUT/pmc_glass_stream.log" 2>&1; echo "pmc glass stream rc=$?"
 bash tools/pmc_kernels.sh s16_stream --algorithm streams --streams-form stream > "$OUT/pmc_s16_stream.log" 2>&1; echo "pmc s16 stream rc=$?"
+bash tools/pmc_kernels.sh c5_tree --scene glass --algorithm streams --width 3840 --height 2160 --spp 512 --part-of 8 > "$OUT/pmc_c5_tree.log" 2>&1; echo "pmc c5 tree rc=$?"
+bash tools/pmc_kernels.sh c5_stream --scene glass --algorithm streams --streams-form stream --width 3840 --height 2160 --spp 512 --part-of 8 > "$OUT/pmc_c5_stream.log" 2>&1; echo "pmc c5 stream rc=$?"
 
 # 3. per-opcode VALU issue costs (shader-clock domain) -- with 2. the inputs of tools/valu_roofline.py
 if [ -x build/valu_rates ]; then timeout -k 10 600 build/valu_rates 1 2 6 8 > "$OUT/valu_rates.json" 2> "$OUT/valu_rates.err"; echo "valu_rates rc=$?"; fi
@@ -37,6 +39,8 @@ timeout -k 10 400 python3 tools/measure_extra.py > "$OUT/extra.json" 2> "$OUT/ex
 timeout -k 10 300 python3 tools/phase_stats.py > "$OUT/phase_stats.json" 2> "$OUT/phase_stats.log"; echo "phase rc=$?"
 # 5. the stream form: lane participation per block of the split kernel, the end of the pixels kernel's launch; the contracted-arithmetic report
 timeout -k 10 300 python3 tools/split_stats.py > "$OUT/split_stats.json" 2> "$OUT/split_stats.log"; echo "split stats rc=$?"
+timeout -k 10 300 python3 tools/tree_stats.py > "$OUT/tree_stats.json" 2> "$OUT/tree_stats.log"; echo "tree stats rc=$?"
+timeout -k 10 300 python3 tools/ab.py run --workloads glass_tree,glass_stream,glass_stream_uniform,glass_stream_g4,glass_stream_g8,glass_stream_g16,glass_stream_b8,glass_stream_b32,c5_tree,c5_stream,c5_stream_uniform,c5_stream_g8,streams,s16_stream default > "$OUT/ab_options.txt" 2>&1; echo "ab options rc=$?"
 timeout -k 10 300 python3 tools/tail_stats.py > "$OUT/tail_stats.json" 2> "$OUT/tail_stats.log"; echo "tail stats rc=$?"
 timeout -k 10 300 python3 tools/tail_stats.py phases > "$OUT/tail_phases.json" 2>> "$OUT/tail_stats.log"; echo "tail phases rc=$?"
 # 6. issue-side counters of the two forms of render Streams on S16 (branches, instruction fetch, scalar and LDS issue)

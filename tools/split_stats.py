@@ -58,7 +58,7 @@ def main():
                 "when_the_tickets_ran_out_per_wave": {"lanes_with_an_item": round(wc[56] / waves, 1), "their_samples_left": round(wc[57] / waves, 1),
                                                       "spill_records": round(wc[58] / waves, 1), "ring_records": round(wc[59] / waves, 1),
                                                       "trips_after_that": round(wc[60] / waves, 1), "most_trips_after_that": wc[61]},
-                "waves_starting_per_82us_bin": wc[64:96], "waves_ending_per_82us_bin_from_32": wc[96:160], "their_mean_trips": [round(t / max(n, 1)) for n, t in zip(wc[96:160], wc[160:224])]}
+                "waves_starting_per_164us_bin": wc[64:96], "waves_ending_per_164us_bin_from_32": wc[96:160], "their_mean_trips": [round(t / max(n, 1)) for n, t in zip(wc[96:160], wc[160:224])]}
     print(json.dumps(out))
 
 
