@@ -1,5 +1,5 @@
 // ptmi_api.cpp -- the C ABI of include/ptmi.h: context, device planes, scene packing, launches.
-// Compiled with hipcc together with ptmi_kernels.hip into libptmi.so.  There is no CPU
+// Compiled with hipcc together with the kernel units (ptmi_*.hip) into libptmi.so.  There is no CPU
 // fallback here: without a HIP device ptmi_create fails with PTMI_ENODEVICE.
 #include "../../include/ptmi.h"
 
@@ -19,7 +19,7 @@
 
 using namespace ptmi;
 
-// render Inline with contracted arithmetic: the second object made from ptmi_kernels.hip (see its last lines)
+// render Inline with contracted arithmetic: the second object made from ptmi_inline.hip (see its last lines)
 extern "C" int ptmi_contracted_launch_inline(const void *args, int variant, void *stream);
 
 struct ptmi_ctx {
@@ -326,7 +326,7 @@ int stream_schedule(int n_spp, unsigned long long n_px, unsigned long long lanes
     return passes;
 }
 
-// `render Streams` as a stream ("wavefront" form, ptmi_kernels.hip).  Every sample of a pixel shoots the same primary ray: its
+// `render Streams` as a stream ("wavefront" form, ptmi_stream_*.hip).  Every sample of a pixel shoots the same primary ray: its
 // hit is evaluated once per call into the start-hit list (regions in dispatch order), then ONE persistent launch renders all
 // samples of the call:
 //   * scenes whose rays never split (default batch): streams_pixels_kernel -- a lane owns a pixel for the launch, no atomics,
@@ -592,7 +592,7 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
     a.stream_step_cap = c->opt_step_cap; a.seed_from_result = effective_seed_rule(c) == PTMI_SEED_FROM_RESULT;
     a.stream_counters = c->d_stream_counters;
     const bool stream_form = algorithm == PTMI_STREAMS && (c->opt_form == PTMI_FORM_STREAM || c->variant == 9);
-    // Cost-ordered dispatch (ptmi_kernels.hip: lane_pixel): launches with one (camera, scene, shape, limit, algorithm)
+    // Cost-ordered dispatch (ptmi_device.h: lane_pixel): launches with one (camera, scene, shape, limit, algorithm)
     // record what every quad of tiles costs; later launches with the same key dispatch the most expensive quads first
     // (sorted on the device).  Everything is enqueued on the stream; results do not depend on it.
     const bool per_pixel_kernel = !stream_form;
@@ -642,7 +642,7 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
         if (record) { a.quad_cost = c->d_quad_cost; next_order_state = state_after; }
     }
     if (per_pixel_kernel) {
-        // one word per tile workgroup for the sample chunks of the tiled per-pixel kernels (ptmi_kernels.hip)
+        // one word per tile workgroup for the sample chunks of the tiled per-pixel kernels (ptmi_device.h: enter_sample_chunk)
         const unsigned int need = ((unsigned int)(((width + 7) / 8) * ((rows_local + 7) / 8)) + 31u) & ~31u;
         if (need > c->chunk_capacity) {
             if (c->d_chunk_done) { PTMI_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_chunk_done); c->d_chunk_done = nullptr; c->chunk_capacity = 0; }
@@ -660,7 +660,7 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
     } else if (stream_form) {                              // rays travel through streams in HBM (PTMI_OPT_STREAMS_FORM; variant 9)
         if (int rc = render_streams_wavefront(c, a, n_spp, *camera)) return rc;
     } else if (c->has_glass) {                             // rays may split: the per-pixel tree walk
-        // the first waiting children of every lane as 64-byte records in global memory (ptmi_kernels.hip): 16 KB per tile
+        // the first waiting children of every lane as 64-byte records in global memory (ptmi_streams_tree.hip): 16 KB per tile
         const size_t want = (size_t)tree_workgroups(width, rows_local) * kTreeFastLevels * 64 * 64;
         if (want > c->tree_stack_bytes) {
             PTMI_HIP(c, hipStreamSynchronize(c->stream));

@@ -10,6 +10,7 @@
 //   -DPTMI_TAIL_STATS    streams_pixels_kernel: when waves end, lanes with an item per trip      tools/tail_stats.py
 //   -DPTMI_TAIL_PHASES      ... cycles in the refill block and in the trips that end an item
 //   -DPTMI_SPLIT_STATS   streams_split_kernel: lane participation per round, wave durations      tools/split_stats.py
+//   -DPTMI_SPLIT_ENDS       ... only when its waves end (two atomics per wave)                    tools/split_stats.py ends
 // (-DPTMI_POOL_STATS belongs to an ablation kernel and lives beside it, ptmi_inline_ablations.hip.)
 #pragma once
 
@@ -22,6 +23,9 @@ namespace diag {
 #define PTMI_PROBE __device__ __forceinline__
 #ifndef PTMI_SPLIT_HIST_SHIFT
 #define PTMI_SPLIT_HIST_SHIFT 14       // bins of 164 us
+#endif
+#ifndef PTMI_SPLIT_HIST_FIRST
+#define PTMI_SPLIT_HIST_FIRST 32ull    // the first bin of the 64-bin window of end times
 #endif
 
 PTMI_PROBE unsigned int lanes(bool on) { return (unsigned int)__builtin_popcountll(__ballot(on)); }
@@ -174,7 +178,36 @@ struct TailProbe {
 // [20] children taken from the XCD's shared queue, [21] ... given to it, [22] the first wave's start (u64, negated); per XCD x: [24+x] waves, [32+x] sum of durations >> 12,
 // [40+x] longest >> 12, [48+x] trips
 struct SplitProbe {
-#ifdef PTMI_SPLIT_STATS
+#if defined(PTMI_SPLIT_ENDS) && !defined(PTMI_SPLIT_STATS)
+    // -DPTMI_SPLIT_ENDS: ONLY when the waves end -- two atomics per wave, so that the measurement does not make the tail it looks for (the
+    // full statistics' flush is 6 144 waves x 45 atomics on a dozen lines: milliseconds of atomics that the still-running waves' ticket
+    // atomics queue behind; round 3 read that as "waves end between 85 and 100 % of the launch").  [22] first start (u64, negated),
+    // [96, 160): waves by the time they end, bins of 2^PTMI_SPLIT_HIST_SHIFT ticks of 10 ns, a window of 64 bins from PTMI_SPLIT_HIST_FIRST on.
+    unsigned int *counters = nullptr;
+    PTMI_PROBE void begin(unsigned int *wc)
+    {
+        counters = wc;
+        if ((threadIdx.x & 63) == 0 && wc) atomicMax(reinterpret_cast<unsigned long long *>(wc + 22), ~__builtin_amdgcn_s_memrealtime());
+    }
+    PTMI_PROBE static void trip(bool, bool) {}
+    PTMI_PROBE static void refill() {}
+    PTMI_PROBE static void next_ray(unsigned long long, unsigned int, bool, bool) {}
+    PTMI_PROBE static void shade(bool, bool) {}
+    PTMI_PROBE static void parked(unsigned int) {}
+    PTMI_PROBE static void glass_block(unsigned int) {}
+    PTMI_PROBE static void stolen(unsigned int) {}
+    PTMI_PROBE static void shared(unsigned int) {}
+    PTMI_PROBE static void trace(bool) {}
+    PTMI_PROBE static void tickets(bool, bool, int, unsigned int, unsigned int) {}
+    PTMI_PROBE void flush(unsigned int *wc, unsigned int)
+    {
+        if ((threadIdx.x & 63) != 0 || !wc) return;
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long t0 = ~__hip_atomic_load(reinterpret_cast<unsigned long long *>(wc + 22), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long be = (t_end - t0) >> PTMI_SPLIT_HIST_SHIFT;
+        atomicAdd(wc + 96 + (be < PTMI_SPLIT_HIST_FIRST ? 0u : (be < PTMI_SPLIT_HIST_FIRST + 63ull ? (unsigned int)(be - PTMI_SPLIT_HIST_FIRST) : 63u)), 1u);
+    }
+#elif defined(PTMI_SPLIT_STATS)
     unsigned int n_trips = 0, n_dead = 0, n_free = 0, n_ring = 0, n_start = 0, n_end = 0, n_refill = 0, n_shade = 0, n_glass = 0, n_trace = 0, n_busy = 0;
     unsigned int n_parked = 0, n_glass_trips = 0, n_glass_lanes = 0, n_stolen = 0, n_shared = 0;
     unsigned long long t_start = 0, t_start_real = 0;
@@ -232,7 +265,7 @@ struct SplitProbe {
         // ended in the bin (did the late waves do more, or did they run slower?) -- times from the first wave's start, bins of 2^PTMI_SPLIT_HIST_SHIFT ticks of 10 ns
         const unsigned long long t0 = ~__hip_atomic_load(reinterpret_cast<unsigned long long *>(wc + 22), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long bs = (t_start_real - t0) >> PTMI_SPLIT_HIST_SHIFT, be = (t_end_real - t0) >> PTMI_SPLIT_HIST_SHIFT;
-        const unsigned int bin = be < 32ull ? 0u : (be < 95ull ? (unsigned int)be - 32u : 63u);
+        const unsigned int bin = be < PTMI_SPLIT_HIST_FIRST ? 0u : (be < PTMI_SPLIT_HIST_FIRST + 63ull ? (unsigned int)(be - PTMI_SPLIT_HIST_FIRST) : 63u);
         atomicAdd(wc + 64 + (bs < 31ull ? (unsigned int)bs : 31u), 1u);
         atomicAdd(wc + 96 + bin, 1u); atomicAdd(wc + 160 + bin, n_trips);
     }

@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(kRenderBlock, MODE == kCachedR1 ? 6 : 4) rende
 
 // ---------------------------------------------------------------------------------------
 // render Inline, pooled second shade round.  Same loop [shade A][shade B][trace C] and the same arithmetic as
-// kCached, but the B round -- lanes whose sample ended in A and whose next sample starts from the cached
+// render_inline_kernel, but the B round -- lanes whose sample ended in A and whose next sample starts from the cached
 // primary hit; only ~49 % of a wave's lanes -- is shared by the W waves of a workgroup: a restarting lane
 // posts (seed, owner) into an LDS pool (ballot + prefix inside the wave, one LDS atomic per wave for the base),
 // the pool's items are shaded densely by as many waves as it takes (the others skip the round), and the
@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(64 * W, 6) render_inline_pooled_kernel(const R
 }
 
 // ---------------------------------------------------------------------------------------
-// render Inline, persistent form (default).  Same per-pixel arithmetic as kCached above, but a lane
+// render Inline, persistent form (default).  Same per-pixel arithmetic as render_inline_kernel, but a lane
 // that finishes its pixel (all n_spp samples) takes the next unprocessed pixel from a global counter
 // instead of idling until the slowest of the wave's 64 pixels is done: the number of trace rounds a
 // pixel needs is a sum over its samples and varies by +-25 % inside a wave at 64 spp (measured:

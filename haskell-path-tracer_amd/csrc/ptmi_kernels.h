@@ -38,7 +38,7 @@ struct RenderArgs {
     unsigned long long *live_counter;     // += live bounces (the host sums the shards)
     unsigned int *work_counter;           // device counter for dynamic pixel hand-out (variants)
     unsigned int *stream_iterations;      // Streams: steps taken by the last sample (max over waves)
-    // Cost-ordered dispatch of the tiled kernels (see lane_pixel in ptmi_kernels.hip).  A "quad" is a run of four
+    // Cost-ordered dispatch of the tiled kernels (see lane_pixel in ptmi_device.h).  A "quad" is a run of four
     // x-adjacent 8x8 tiles.  quad_order: the quad each dispatch position works on (NULL = image order).
     // quad_cost: where each wave adds the loop trips it paid (NULL = do not record).
     const unsigned int *quad_order;
@@ -129,7 +129,7 @@ struct LevelArgs {
     int may_emit;                   // 0: the scene has no ray-splitting material -- nothing is ever written to `out`
 };
 // The item kernels of the stream form (streams_pixels_kernel, streams_split_kernel): persistent waves take the regions of the
-// start-hit list as chunks, by ticket, from eight queues (one per XCD; ChunkCursor in ptmi_kernels.hip).
+// start-hit list as chunks, by ticket, from eight queues (one per XCD; ChunkCursor in ptmi_stream_form.h).
 struct ItemArgs {
     HitList hits;
     unsigned int n_positions;       // groups of four regions (dispatch positions): hits.n_regions / 4
@@ -154,9 +154,9 @@ struct ItemArgs {
 
 hipError_t launch_streams_pixels(const RenderArgs &a, const ItemArgs &it, unsigned int grid, hipStream_t stream);
 hipError_t launch_streams_split(const RenderArgs &a, const ItemArgs &it, unsigned int grid, hipStream_t stream);
-int streams_pixels_waves();
-int streams_min_pass_samples();      // ordered passes: a pass must hold at least this many samples           // waves per SIMD the item kernels are built for (persistent grids)
+int streams_pixels_waves();           // waves per SIMD the item kernels are built for (persistent grids)
 int streams_split_waves();
+int streams_min_pass_samples();       // ordered passes: a pass must hold at least this many samples
 unsigned int streams_spill_records();   // records of a wave's spill queue in HBM
 unsigned int streams_regions(int width, int rows_local);    // regions of the start-hit list
 hipError_t launch_streams_seeds(Planes p, uint4 *snapshots, long long n, int passes, const int *pass_first, hipStream_t stream);   // pass_first: device, passes + 1 entries

@@ -84,6 +84,10 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
             unsigned int done = 0;
             if (lane == 0) done = __hip_atomic_load(it.region_done + cur.region, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             done = (unsigned int)__builtin_amdgcn_readfirstlane((int)done);
+            // (a compiler barrier, no instruction: the sc1 loads of the region's planes below are relaxed atomics to other addresses, and nothing
+            // but this keeps a future compiler from hoisting them above the poll they depend on -- the mirror of the storing side's asm memory
+            // clobber.  The hardware orders them: same wave, loads issued after the poll's value has returned.)
+            asm volatile("" ::: "memory");
             if (done >= cur.pass * cur.len) cur.ready = true;
             else { open = false; if (!__any(busy)) __builtin_amdgcn_s_sleep(8); }
         }

@@ -176,7 +176,9 @@ enum {
      * bit-identical); with GLASS, where the order of a pixel's additions is undefined anyway, items of a few dozen samples run in
      * whatever lanes take them.  k > 0: items of k samples -- under PTMI_SEED_FROM_RESULT (a pixel's samples are one serial chain)
      * as ordered passes, bit-identical; under PTMI_SEED_KEEP_ACCUMULATOR as unordered items: colours then agree to rounding only
-     * (Accelerate's `permute` does not define the order either); the RNG planes stay exact. */
+     * (Accelerate's `permute` does not define the order either); the RNG planes stay exact.  A launch holds at most 64 passes: where
+     * n_spp / k exceeds that, the samples are split evenly into 64 (ordered passes) or k is raised to n_spp / 64 (unordered items); with
+     * PTMI_OPT_STREAM_GRADED (the default) k is the LARGEST item of the unordered form -- the last items of a launch are shorter. */
     PTMI_OPT_STREAM_BATCH = 5,
     /* The per-pixel kernels of both algorithms, a scheduling knob that changes no result: a launch of few pixels and
      * many samples (one part of a multi-GPU image) is cut into this many chained copies of the tile grid, each rendering

@@ -120,7 +120,7 @@ def test_stream_batch_option_trades_order_for_shorter_items(ctx, pkg, ora):
 def test_overflow_levels_with_tiny_rings(pkg, ora, tmp_path_factory):
     """The rare path of the stream form: a child that finds its wave's ring AND its wave's spill queue full travels through the
     overflow stream and is traced by a later launch (streams_level_kernel), level after level.  With the product's sizes (16 ring
-    records, 256 spill records per wave) that practically never happens, so this test builds the library with a ring of 2 and a
+    records, 4 096 spill records per wave) that practically never happens, so this test builds the library with a ring of 2 and a
     spill queue of 4 records: same rays, same counts, same seeds, colours within the tolerance of the undefined addition order."""
     B = pkg.binding
     out = os.path.join(str(tmp_path_factory.mktemp("tinyrings")), "libptmi_tinyrings.so")

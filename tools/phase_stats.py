@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """phase_stats.py -- where do the lanes go?  Builds a -DPTMI_PHASE_STATS copy of libptmi (diagnostic,
-never the measured library), renders C2 once with the static kCached kernel and prints, per round of its
+never the measured library), renders C2 once with render_inline_kernel and prints, per round of its
 [shade A][shade B][trace C] loop, the fraction of lane-slots that did work, plus the wave-tail factor
 (lane-iterations the waves paid for / lane-iterations needed)."""
 import json

@@ -7,7 +7,7 @@ set -o pipefail
 TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
-rm -rf "$OUT"; mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"   # (locally, delete gpurun_out/pmc_* and gpurun_out/prof_<tag> of earlier runs first: gpurun MERGES what comes back into what is there)
 cd /tmp; export TMPDIR=/tmp; cd "$ROOT"
 
 # 0. what this profile is a profile OF: the hash of kernel sources, headers and flags (bench.py says `stale` when they have moved on)

@@ -10,8 +10,50 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 
+ENDS_FIRST = 160          # 41-us bins: the window is 6.55 .. 9.2 ms after the first wave's start (the launch takes ~8.2 ms)
+
+
+def ends(pkg):
+    """split_stats.py ends -- only WHEN the waves of the split kernel end (-DPTMI_SPLIT_ENDS with 41-us bins: two atomics per wave, the kernel
+    otherwise the product's), glass scene, 1080p / 64 spp: does the launch have a tail?"""
+    lib = os.path.join(ROOT, "build", "ab", "splitends.so")
+    if not os.path.exists(lib):
+        os.makedirs(os.path.dirname(lib), exist_ok=True)
+        pkg._build.build_lib(out=lib, extra_flags=["-DPTMI_SPLIT_ENDS", "-DPTMI_SPLIT_HIST_SHIFT=12", "-DPTMI_SPLIT_HIST_FIRST=%dull" % ENDS_FIRST])
+    if "build" in sys.argv:
+        return
+    pkg.binding._lib = None
+    pkg.binding.load_library(lib)
+    B = pkg.binding
+    sp, pl = pkg.world.glass_scene()
+    out = {}
+    for graded in (1, 0):
+        with pkg.Context(0) as c:
+            c.set_scene(sp, pl)
+            c.resize(1920, 1080)
+            c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+            c.set_option(B.OPT_STREAM_GRADED, graded)
+            c.init_output(0x5EED1234)
+            for _ in range(6):
+                c.render(pkg.world.initial_camera(), 8, 64, pkg.STREAMS)
+            c.synchronize()
+            c.reset_stats()
+            c.set_timing(True)
+            c.render(pkg.world.initial_camera(), 8, 64, pkg.STREAMS)
+            ms = c.stats()["last_render_ms"]
+            wc = [int(x) for x in c.debug_counters()]
+        hist = {ENDS_FIRST + i: n for i, n in enumerate(wc[96:160]) if n}
+        first, last = min(hist), max(hist)
+        out["graded" if graded else "uniform"] = {"render_ms": round(ms, 3), "bin_us": 40.96, "waves": sum(hist.values()), "waves_ending_per_bin": hist,
+                                                  "first_wave_ends_at_fraction_of_the_last": round((first + 0.5) / (last + 0.5), 3),
+                                                  "mean_end_at_fraction_of_the_last": round(sum((b + 0.5) * n for b, n in hist.items()) / sum(hist.values()) / (last + 0.5), 3)}
+    print(json.dumps(out))
+
+
 def main():
     pkg = graft.load_package()
+    if len(sys.argv) > 1 and sys.argv[1] == "ends":
+        return ends(pkg)
     lib = os.path.join(ROOT, "build", "ab", "splitstats.so")
     if not os.path.exists(lib):
         os.makedirs(os.path.dirname(lib), exist_ok=True)
