@@ -198,6 +198,7 @@ struct SplitProbe {
     PTMI_PROBE static void stolen(unsigned int) {}
     PTMI_PROBE static void shared(unsigned int) {}
     PTMI_PROBE static void trace(bool) {}
+    PTMI_PROBE static void stamp(int) {}
     PTMI_PROBE static void tickets(bool, bool, int, unsigned int, unsigned int) {}
     PTMI_PROBE void flush(unsigned int *wc, unsigned int)
     {
@@ -231,6 +232,11 @@ struct SplitProbe {
     PTMI_PROBE void stolen(unsigned int n) { n_stolen += n; }
     PTMI_PROBE void shared(unsigned int n) { n_shared += n; }
     PTMI_PROBE void trace(bool has_ray) { n_trace += lanes(has_ray); }
+    // [224, 240): wave cycles (shader clock, u64) from one stamp to the next, by the block that ends at the stamp: 0 dead hits, 1 refill, 2 next
+    // ray / sample start / item end, 3 shade (first piece), 4 GLASS block + expand, 5 shade (rest), 6 trace, 7 loop control.  The waves of a SIMD
+    // interleave, so these are SHARES of a wave's time, not costs: a block whose share exceeds its share of the instructions is where the wave waits.
+    unsigned long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
+    PTMI_PROBE void stamp(int k) { const unsigned long long t = __builtin_readcyclecounter(); if (t_last) cyc[k] += t - t_last; t_last = t; }
     // what the wave still holds when it finds the last queue exhausted: [56] lanes with an item, [57] their samples left, [58] spill records,
     // [59] ring records, [60] the trips it makes after that (sum over the waves), [61] the most of any wave
     unsigned int at_end_busy = 0, at_end_samples = 0, at_end_spill = 0, at_end_ring = 0, trips_at_end = 0;
@@ -251,6 +257,7 @@ struct SplitProbe {
         const unsigned long long dur = __builtin_readcyclecounter() - t_start;
         atomicAdd(wc + 56, at_end_busy); atomicAdd(wc + 57, at_end_samples); atomicAdd(wc + 58, at_end_spill); atomicAdd(wc + 59, at_end_ring);
         atomicAdd(wc + 60, n_trips - trips_at_end); atomicMax(wc + 61, n_trips - trips_at_end);
+        for (int k = 0; k < 8; ++k) atomicAdd(reinterpret_cast<unsigned long long *>(wc + 224 + 2 * k), cyc[k]);
         atomicAdd(wc + 1, n_trips); atomicAdd(wc + 2, n_dead); atomicAdd(wc + 3, n_free); atomicAdd(wc + 4, n_ring);
         atomicAdd(wc + 5, n_start); atomicAdd(wc + 6, n_end); atomicAdd(wc + 7, n_refill); atomicAdd(wc + 8, n_shade);
         atomicAdd(wc + 9, n_glass); atomicAdd(wc + 10, n_trace); atomicAdd(wc + 11, n_busy);
@@ -280,6 +287,7 @@ struct SplitProbe {
     PTMI_PROBE static void stolen(unsigned int) {}
     PTMI_PROBE static void shared(unsigned int) {}
     PTMI_PROBE static void trace(bool) {}
+    PTMI_PROBE static void stamp(int) {}
     PTMI_PROBE static void tickets(bool, bool, int, unsigned int, unsigned int) {}
     PTMI_PROBE static void flush(unsigned int *, unsigned int) {}
 #endif

@@ -97,6 +97,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
 
     diag::SplitProbe probe; probe.begin(a.work_counter);                   // (diagnostic builds: ptmi_diag.h)
     for (;;) {
+        probe.stamp(7);
         probe.trip(pending && near_zero(throughput), busy);
         // ---- a hit whose ray arrived with near-zero throughput (numNewRays = 0, Trace.hs:329-331) adds its emittance and nothing
         // else of it survives: the lineage ends here
@@ -105,6 +106,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
             add_colour(scale_r(mk(ma.x, ma.y, ma.z), ma.w) * throughput);
             pending = false;
         }
+        probe.stamp(0);
         // ---- refill: lanes without an item take the next ones of the wave's chunk (whatever ray they are tracing meanwhile)
         const unsigned long long empty = __ballot(!busy);
         if ((unsigned int)__builtin_popcountll(empty) >= kItemBatch && chunks_left(cur)) {     // wave-uniform
@@ -133,16 +135,39 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
             }
             cur.taken += take;
             if (cur.taken >= cur.len) next_chunk(cur, it);
+            // (Tried and dropped, round 4: touching the records of the NEXT refill a trip early -- 8 or 16 lanes load one word each -- and taking
+            // the next chunk one chunk early to touch all of its records and then their seed snapshots: 8.21 / 8.25 / 8.16 ms against 8.09.  The
+            // refill's loads are not what the wave waits for long enough to pay for more loads.)
         }
         probe.tickets(chunks_left(cur), busy, samples_left, spill_n, ring_n);
+        probe.stamp(1);
         // ---- the next ray of every lane that holds neither a ray nor a hit: a child from the wave's ring first ...
         const bool free_lane = !pending && !has_ray;
         const unsigned long long free_m = __ballot(free_lane);
-        bool took = false;
         probe.next_ray(free_m, ring_n, free_lane && busy && samples_left > 0, free_lane && busy && samples_left <= 0);
-        if (ring_n && free_m) {                               // wave-uniform
+        if (ring_n == 0u && spill_n && free_m) {              // wave-uniform, rare: the ring is empty -- up to kRing records of the wave's spill queue move into it
+            // the records were written by this wave, at least a trip ago: once its stores have been acknowledged (they have: the
+            // wait is free) they are in the L2, and loads that bypass the L1 see them.  (Spill -> ring -> lane rather than spill -> lane: the
+            // lanes' ray state then has ONE source besides their own item, and the compiler keeps one copy of it.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned int n = spill_n < kRing ? spill_n : kRing;
+            if ((unsigned int)lane < n) {
+                const float4 *r = it.spill.record(w * kSpill + ((spill_head + (unsigned int)lane) & (kSpill - 1u)));
+                const float4 r0 = load_past_l1(r), r1 = load_past_l1(r + 1), r2 = load_past_l1(r + 2), r3 = load_past_l1(r + 3);
+                const unsigned int slot = (ring_head + (unsigned int)lane) & (kRing - 1u);
+                ring[0][slot] = f2u(r0.x); ring[1][slot] = f2u(r0.y); ring[2][slot] = f2u(r0.z);
+                ring[3][slot] = f2u(r0.w); ring[4][slot] = f2u(r1.x); ring[5][slot] = f2u(r1.y);
+                ring[6][slot] = f2u(r1.z); ring[7][slot] = f2u(r1.w); ring[8][slot] = f2u(r2.x);
+                ring[9][slot] = f2u(r2.y);
+                ring[10][slot] = f2u(r2.z); ring[11][slot] = f2u(r2.w); ring[12][slot] = f2u(r3.x); ring[13][slot] = f2u(r3.y);
+                ring[14][slot] = f2u(r3.z);
+            }
+            spill_head = (spill_head + n) & (kSpill - 1u); spill_n -= n; ring_n = n;
+        }
+        bool took = false;
+        {
             const unsigned int want = (unsigned int)__builtin_popcountll(free_m);
-            const unsigned int take = want < ring_n ? want : ring_n;
+            const unsigned int take = want < ring_n ? want : ring_n;       // (0 when the ring is empty: the block below then runs for no lane)
             const unsigned int rank = rank_in(free_m);
             if (free_lane && rank < take) {
                 const unsigned int slot = (ring_head + rank) & (kRing - 1u);
@@ -155,25 +180,6 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                 has_ray = true; foreign = true; took = true;
             }
             ring_head = (ring_head + take) & (kRing - 1u); ring_n -= take;
-        } else if (spill_n && free_m) {                       // ... or, the ring being empty, from the wave's spill queue (rare)
-            const unsigned int want = (unsigned int)__builtin_popcountll(free_m);
-            const unsigned int take = want < spill_n ? want : spill_n;
-            const unsigned int rank = rank_in(free_m);
-            // the records were written by this wave, at least a trip ago: once its stores have been acknowledged (they have: the
-            // wait is free) they are in the L2, and loads that bypass the L1 see them
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (free_lane && rank < take) {
-                const float4 *r = it.spill.record(w * kSpill + ((spill_head + rank) & (kSpill - 1u)));
-                const float4 r0 = load_past_l1(r), r1 = load_past_l1(r + 1), r2 = load_past_l1(r + 2), r3 = load_past_l1(r + 3);
-                o = mk(r0.x, r0.y, r0.z);
-                d = mk(r0.w, r1.x, r1.y);
-                throughput = mk(r1.z, r1.w, r2.x);
-                pixel = f2u(r2.y);
-                seed.a = f2u(r2.z); seed.b = f2u(r2.w); seed.c = f2u(r3.x); seed.counter = f2u(r3.y);
-                depth = f2u(r3.z);
-                has_ray = true; foreign = true; took = true;
-            }
-            spill_head = (spill_head + take) & (kSpill - 1u); spill_n -= take;
         }
         // ---- ... else the next sample of its own item (its start hit and that sample's seed are in the lane's LDS column); an
         // item without samples left is over: its colour goes to the planes, one atomic per word
@@ -209,6 +215,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
         // next trip refills: a `continue` here would be a second back edge, and cost the loop its register allocation.)
         if (!__any(has_ray || pending) && !chunks_left(cur) && !__any(busy) && ring_n == 0 && spill_n == 0) break;
         item_trips += busy ? 1u : 0u;
+        probe.stamp(2);
 
         // ---- shade round, for the hits of rays that are alive (a dead one just fetched waits for the next trip's first block).
         // GLASS is an ARM of the one shade, not a second shade: genVec's three draws come before the match for every material
@@ -218,53 +225,40 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
         // divergent block in the middle (it used to be the whole of glass_children, wave-wide for three lanes in nearly every trip).
         // PARKING (it.glass_batch > 1): a GLASS hit waits in its lane until that many of the wave's lanes hold one -- or the wave has
         // nothing else to shade or trace -- so that the block and the expand behind it run for >= glass_batch lanes at a time.
-        bool emits = false;
-        V3 ko = o, kd = o, kt = o; Sfc32 ks = seed;
         const float4 mb = M[2 * idx + 1];
         const bool alive = pending && !near_zero(throughput);
-        const bool glass = alive && f2u(mb.x) == 2u;
+        const bool glass_hit = alive && f2u(mb.x) == 2u;
         bool shade_now = alive;
         if (it.glass_batch > 1) {                                 // wave-uniform
-            const unsigned long long gm = __ballot(glass);
-            const bool hold = gm != 0ull && (unsigned int)__builtin_popcountll(gm) < (unsigned int)it.glass_batch && __any((alive && !glass) || has_ray);
-            if (hold) { shade_now = alive && !glass; probe.parked((unsigned int)__builtin_popcountll(gm)); }
+            const unsigned long long gm = __ballot(glass_hit);
+            const bool hold = gm != 0ull && (unsigned int)__builtin_popcountll(gm) < (unsigned int)it.glass_batch && __any((alive && !glass_hit) || has_ray);
+            if (hold) { shade_now = alive && !glass_hit; probe.parked((unsigned int)__builtin_popcountll(gm)); }
         }
+        const bool glass = shade_now && glass_hit;
         live_w += (unsigned int)__builtin_popcountll(__ballot(shade_now));    // one child per shaded hit ...
-        probe.shade(shade_now, shade_now && glass);
+        probe.shade(shade_now, glass);
+        // (the shade comes in three pieces -- [draws, mirror direction][the GLASS block with its expand][rotation and the child in the lane] -- so
+        // that the second child's thirteen words live only inside the middle piece, not across the three sin / cos pairs of the last one)
+        const float4 ma = M[2 * idx];
+        const V3 color = mk(ma.x, ma.y, ma.z);
+        V3 rv = mk(0.0f, 0.0f, 0.0f), reflection = rv;
+        float ia = 0.0f, glass_R = 0.0f;
         if (shade_now) {
-            const float4 ma = M[2 * idx];
-            const V3 color = mk(ma.x, ma.y, ma.z);
-            V3 rv;                                                // genVec (Util.hs:114-118)
-            rv.x = gen_component(seed); rv.y = gen_component(seed); rv.z = gen_component(seed);
-            const bool matte = f2u(mb.x) == 0u;
-            const float ia = dot(d, normal);
-            const V3 reflection = d - scale_l(2.0f * ia, normal);
-            float glass_R = 0.0f;
-            if (glass) {                                          // the refraction child (extension; spec = the oracle's glass_children)
+            rv.x = gen_component(seed); rv.y = gen_component(seed); rv.z = gen_component(seed);      // genVec (Util.hs:114-118)
+            ia = dot(d, normal);
+            reflection = d - scale_l(2.0f * ia, normal);
+        }
+        probe.stamp(3);
+        // ---- the GLASS block and expand: the refraction child (extension; spec = the oracle's glass_children), then compaction of the emitted
+        // children into the wave's ring; what the ring cannot hold goes to the wave's spill queue, what that cannot hold to the overflow stream
+        const unsigned long long kids = it.may_emit ? __ballot(glass) : 0ull;
+        if (kids) {                                           // wave-uniform
+            const bool emits = glass;
+            V3 ko = o, kd = o, kt = o; Sfc32 ks = seed;
+            if (glass) {
                 probe.glass_block(diag::lanes(true));
                 glass_R = glass_refraction_child(color, glass_constants_of<LDS_SCENE>(mb), o, normal, d, ia, reflection, throughput, seed, ko, kd, kt, ks);
-                emits = true;
             }
-            // Matte: rotate (anglesToQuaternion $ pi *^ rv) iNormal | Glossy: rotate (anglesToQuaternion $ (1 - p) *^ rv) reflection
-            const V3 axis = matte ? normal : reflection;
-            const float hk = matte ? 0.5f * kPi : mb.w;
-            const V3 rotated = rotate(quaternion_from_half_angles(hk * rv.x, hk * rv.y, hk * rv.z), axis);
-            const float nd = dot(rotated, axis);
-            const float brdf = matte ? mb.z * nd : __builtin_fmaxf(0.0f, nd);
-            constexpr float next_ray_prob = 1.0f / (kPi * 2.0f);
-            const float factor = glass ? glass_R : brdf * next_ray_prob;
-            const V3 next = mk(glass ? reflection.x : rotated.x, glass ? reflection.y : rotated.y, glass ? reflection.z : rotated.z);   // (component selects: a select between two structs went through scratch memory)
-            // computeResult for EVERY hit (Trace.hs:318-323), then the child in the lane (0 + e * t: an exact zero either way is skipped or changes nothing)
-            add_colour(mk(0.0f, 0.0f, 0.0f) + (scale_r(color, ma.w) * throughput));
-            o = o + scale_r(next, kEpsilon);
-            d = next;
-            throughput = throughput * scale_r(color, factor);
-            ++depth; pending = false; has_ray = true;          // the child: next traceStep, same lane
-        }
-        // ---- expand: compaction of the emitted children into the wave's ring; what the ring cannot hold goes to the wave's spill
-        // queue, what that cannot hold to the overflow stream
-        const unsigned long long kids = it.may_emit ? __ballot(emits) : 0ull;
-        if (kids) {                                           // wave-uniform
             const unsigned int cnt = (unsigned int)__builtin_popcountll(kids), rank = rank_in(kids);
             live_w += cnt;                                    // ... and a second one per GLASS hit
             const unsigned int room_ring = kRing - ring_n;
@@ -276,7 +270,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                 ring[6][slot] = f2u(kt.x); ring[7][slot] = f2u(kt.y); ring[8][slot] = f2u(kt.z);
                 ring[9][slot] = pixel;
                 ring[10][slot] = ks.a; ring[11][slot] = ks.b; ring[12][slot] = ks.c; ring[13][slot] = ks.counter;
-                ring[14][slot] = depth;
+                ring[14][slot] = depth + 1u;                  // the child's step index (its parent's is raised in the last piece of the shade)
             }
             ring_n += to_ring;
             if (cnt > to_ring) {                              // the ring is full (rare)
@@ -284,7 +278,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                 const unsigned int room_spill = kSpill - spill_n;
                 const unsigned int to_spill = rest < room_spill ? rest : room_spill;
                 if (emits && rank >= to_ring && rank - to_ring < to_spill)
-                    queue_store(it.spill, w * kSpill + ((spill_head + spill_n + (rank - to_ring)) & (kSpill - 1u)), ko, kd, kt, pixel, ks, depth);
+                    queue_store(it.spill, w * kSpill + ((spill_head + spill_n + (rank - to_ring)) & (kSpill - 1u)), ko, kd, kt, pixel, ks, depth + 1u);
                 spill_n += to_spill; spilled_w += to_spill;
                 if (rest > to_spill) {                        // the wave's spill queue is full too: the overflow stream (a later launch reads it)
                     const unsigned int cnt2 = rest - to_spill, first2 = to_ring + to_spill;
@@ -302,7 +296,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                         blk += cnt2;
                     }
                     const unsigned int lost = (unsigned int)__builtin_popcountll(__ballot(spills && slot >= it.out.capacity));
-                    if (spills && slot < it.out.capacity) queue_store(it.out, slot, ko, kd, kt, pixel, ks, depth);   // depth: the child's step index
+                    if (spills && slot < it.out.capacity) queue_store(it.out, slot, ko, kd, kt, pixel, ks, depth + 1u);   // depth: the child's step index
                     if (lane == 0) {                          // practically never: counted where it happens, not in registers carried round the loop
                         if (cnt2 > lost) {
                             atomicAdd(it.emitted + (size_t)(w & (unsigned int)(kLvEmitShards - 1)) * kCounterStride, cnt2 - lost);
@@ -313,6 +307,26 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                 }
             }
         }
+        probe.stamp(4);
+        // ---- the rest of the shade: Matte: rotate (anglesToQuaternion $ pi *^ rv) iNormal | Glossy: rotate (anglesToQuaternion $ (1 - p) *^ rv) reflection
+        if (shade_now) {
+            const bool matte = f2u(mb.x) == 0u;
+            const V3 axis = matte ? normal : reflection;
+            const float hk = matte ? 0.5f * kPi : mb.w;
+            const V3 rotated = rotate(quaternion_from_half_angles(hk * rv.x, hk * rv.y, hk * rv.z), axis);
+            const float nd = dot(rotated, axis);
+            const float brdf = matte ? mb.z * nd : __builtin_fmaxf(0.0f, nd);
+            constexpr float next_ray_prob = 1.0f / (kPi * 2.0f);
+            const float factor = glass ? glass_R : brdf * next_ray_prob;
+            const V3 next = mk(glass ? reflection.x : rotated.x, glass ? reflection.y : rotated.y, glass ? reflection.z : rotated.z);   // (component selects: a select between two structs went through scratch memory)
+            // computeResult for EVERY hit (Trace.hs:318-323), then the child in the lane (0 + e * t: an exact zero either way is skipped or changes nothing)
+            add_colour(mk(0.0f, 0.0f, 0.0f) + (scale_r(color, ma.w) * throughput));
+            o = o + scale_r(next, kEpsilon);
+            d = next;
+            throughput = throughput * scale_r(color, factor);
+            ++depth; pending = false; has_ray = true;          // the child: next traceStep, same lane
+        }
+        probe.stamp(5);
         // ---- trace round: one traceStep (Trace.hs:272-294) for every lane that holds a ray
         cut_w += (unsigned int)__builtin_popcountll(__ballot(has_ray && depth >= step_cap));
         probe.trace(has_ray);
@@ -330,6 +344,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                 }
             }
         }
+        probe.stamp(6);
     }
     probe.flush(a.work_counter, cur.home);
     // what is left of this wave's last overflow block: holes

@@ -54,11 +54,12 @@ def main():
     pkg = graft.load_package()
     if len(sys.argv) > 1 and sys.argv[1] == "ends":
         return ends(pkg)
-    lib = os.path.join(ROOT, "build", "ab", "splitstats.so")
+    extra = [a for a in sys.argv[1:] if a.startswith("-D")]          # e.g. an experiment's flag beside the statistics
+    lib = os.path.join(ROOT, "build", "ab", "splitstats%s.so" % "".join(e[2:].replace("=", "_") for e in extra))
     if not os.path.exists(lib):
         os.makedirs(os.path.dirname(lib), exist_ok=True)
-        pkg._build.build_lib(out=lib, extra_flags=["-DPTMI_SPLIT_STATS"])
-    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        pkg._build.build_lib(out=lib, extra_flags=["-DPTMI_SPLIT_STATS"] + extra)
+    if "build" in sys.argv[1:]:
         return
     pkg.binding._lib = None
     pkg.binding.load_library(lib)
@@ -97,6 +98,9 @@ def main():
                 "mean_over_longest": round(total / waves / max(longest, 1), 4), "spilled": st["stream_rays_spilled"], "live": st["live_bounces"],
                 "per_xcd": {"waves": wc[24:32], "mean_wave_kcycles": [round(wc[32 + x] * 4.096 / max(wc[24 + x], 1)) for x in range(8)],
                             "longest_wave_kcycles": [round(wc[40 + x] * 4.096) for x in range(8)], "trips_per_wave": [round(wc[48 + x] / max(wc[24 + x], 1)) for x in range(8)]},
+                "share_of_wave_time_by_block": dict(zip(["dead hits", "refill", "next ray / sample start / item end", "shade: draws, mirror direction", "GLASS block + expand",
+                                                         "shade: rotation, child", "trace", "loop control"],
+                                                        [round((wc[224 + 2 * k] | (wc[225 + 2 * k] << 32)) / max(sum(wc[224 + 2 * j] | (wc[225 + 2 * j] << 32) for j in range(8)), 1), 4) for k in range(8)])),
                 "when_the_tickets_ran_out_per_wave": {"lanes_with_an_item": round(wc[56] / waves, 1), "their_samples_left": round(wc[57] / waves, 1),
                                                       "spill_records": round(wc[58] / waves, 1), "ring_records": round(wc[59] / waves, 1),
                                                       "trips_after_that": round(wc[60] / waves, 1), "most_trips_after_that": wc[61]},
