@@ -380,7 +380,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
     it.hits = hits;
     it.n_positions = n_regions / 4u;
     it.passes = 1;
-    it.n_px = (unsigned int)n;
+    it.n_slots = (unsigned int)hit_slots;
     it.stats = c->d_qcount;
     auto tickets_of = [&](int launch) { return c->d_qcount + (size_t)(kLvTickets + 8 * launch) * kCounterStride; };
     const int cus = c->cus > 0 ? c->cus : 256;
@@ -458,15 +458,15 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
     // the passes: graded items, long first and single samples last (stream_schedule above); PTMI_OPT_STREAM_BATCH caps an item's samples
     int first[kMaxStreamPasses + 1];
     int passes = stream_schedule(n_spp, n, 64ull * grid, c->opt_batch, c->opt_graded != 0, first);
-    {   // the seed snapshots are passes x pixels x 16 bytes: within an eighth of the device's memory, merging the LAST passes if need be
+    {   // the seed snapshots are passes x record slots x 16 bytes: within an eighth of the device's memory, merging the LAST passes if need be
         const size_t budget = c->device_memory / 8;
-        while (passes > 1 && (size_t)passes * n * sizeof(uint4) > budget) { --passes; first[passes] = n_spp; }
-        if ((size_t)passes * n * sizeof(uint4) > budget) return fail(c, PTMI_ELIMIT, "seed snapshots of the stream form would exceed an eighth of the device's memory");
+        while (passes > 1 && (size_t)passes * hit_slots * sizeof(uint4) > budget) { --passes; first[passes] = n_spp; }
+        if ((size_t)passes * hit_slots * sizeof(uint4) > budget) return fail(c, PTMI_ELIMIT, "seed snapshots of the stream form would exceed an eighth of the device's memory");
     }
     const unsigned long long n_tickets = (unsigned long long)n_regions * (region_slots / 64u) * (unsigned long long)passes;
     if (n_tickets > 0x7fffffffull) return fail(c, PTMI_ELIMIT, "too many items for the stream form of Streams");
     if (grid > n_tickets) grid = (unsigned int)n_tickets;
-    const size_t snap_bytes = (size_t)passes * n * sizeof(uint4);
+    const size_t snap_bytes = (size_t)passes * hit_slots * sizeof(uint4);
     if (snap_bytes > c->snapshot_bytes) {
         PTMI_HIP(c, hipStreamSynchronize(c->stream));
         if (c->d_snapshots) { (void)hipFree(c->d_snapshots); c->d_snapshots = nullptr; c->snapshot_bytes = 0; }
@@ -506,7 +506,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
             c->pass_first_host = table;
         }
     }
-    PTMI_HIP(c, launch_streams_seeds(a.planes, static_cast<uint4 *>(c->d_snapshots), (long long)n, passes, c->d_pass_first, c->stream));
+    PTMI_HIP(c, launch_streams_seeds(a.planes, hits, static_cast<uint4 *>(c->d_snapshots), (long long)n, passes, c->d_pass_first, n_spp, c->stream));
     it.passes = passes; it.pass_first = c->d_pass_first;
     // GLASS hits wait in their lanes until that many are pending in the wave (measured: DESIGN.md 5.5); nothing to wait for without GLASS
     it.glass_batch = !c->has_glass ? 0 : (c->opt_glass_batch > 0 ? c->opt_glass_batch : kGlassBatchDefault);

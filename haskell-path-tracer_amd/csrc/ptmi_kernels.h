@@ -140,9 +140,9 @@ struct ItemArgs {
     // streams_split_kernel only
     const int *pass_first;          // device, passes + 1 entries: pass p renders samples [pass_first[p], pass_first[p + 1]) of its pixels -- long items first, short ones
                                     // at the end of the launch, which is as long as its last items (stream_schedule in ptmi_api.cpp)
-    const uint4 *seed_snapshots;    // [passes][n_px]: the seed sample pass_first[pass] of a pixel starts from
+    const uint4 *seed_snapshots;    // [passes][n_slots]: the seed the item (record slot, pass) starts from (streams_slot_seeds_kernel)
     int glass_batch;                // > 1: GLASS hits wait in their lanes until that many are pending in the wave (PTMI_OPT_GLASS_BATCH)
-    unsigned int n_px;
+    unsigned int n_slots;           // slots of the start-hit list: hits.n_regions * hits.region_slots
     RayQueue spill;                 // the waves' own spill queues: streams_spill_records() records each, gridDim of them
     RayQueue out;                   // overflow stream: children that found ring and spill queue full
     unsigned int *out_count;        // device: reservation cursor of `out`, zero at launch
@@ -159,7 +159,7 @@ int streams_split_waves();
 int streams_min_pass_samples();       // ordered passes: a pass must hold at least this many samples
 unsigned int streams_spill_records();   // records of a wave's spill queue in HBM
 unsigned int streams_regions(int width, int rows_local);    // regions of the start-hit list
-hipError_t launch_streams_seeds(Planes p, uint4 *snapshots, long long n, int passes, const int *pass_first, hipStream_t stream);   // pass_first: device, passes + 1 entries
+hipError_t launch_streams_seeds(Planes p, HitList hits, uint4 *snapshots, long long n, int passes, const int *pass_first, int draws, hipStream_t stream);   // pass_first: device, passes + 1 entries
 hipError_t launch_streams_level(const RenderArgs &a, const LevelArgs &lv, unsigned int grid, hipStream_t stream);
 hipError_t launch_streams_primary(const RenderArgs &a, HitList hits, unsigned int *counters, hipStream_t stream);
 // updateSeeds for the pixels without start hits (the ordered item kernel advances the others itself)

@@ -100,18 +100,37 @@ __global__ void __launch_bounds__(256) streams_advance_missed_kernel(const Rende
     a.planes.sa[pixel] = sd.a; a.planes.sb[pixel] = sd.b; a.planes.sc[pixel] = sd.c; a.planes.sctr[pixel] = sd.counter;
 }
 
-// updateSeed (Trace.hs:190-191) for every sample of the call: pass_first[passes] draws per pixel, and on the way the seed each of the
-// `passes` items of the pixel starts from (snapshots[pass][pixel]: the pixel's seed after pass_first[pass] draws).
-__global__ void __launch_bounds__(kBlock) streams_seeds_kernel(Planes p, uint4 *snapshots, long long n, int passes, const int *pass_first)
+// The seed every ITEM of the split kernel starts from, per record SLOT of the start-hit list and per pass: the pixel's seed after
+// pass_first[pass] draws (what that many updateSeeds leave), advanced by the 3 or 4 raw draws the ancestors of a cached glass child made.
+// Indexed by slot, not by pixel: a refilling lane knows its slot before it has seen its record, so the record and the snapshot are two
+// INDEPENDENT loads (indexed by the pixel the second waited for the first: two memory latencies in a row, in three trips of four), lanes that
+// take consecutive records read consecutive snapshots, and the advance is not repeated at every refill.  Reads the pixels' seeds BEFORE
+// streams_advance_seeds_kernel moves them.
+__global__ void __launch_bounds__(kBlock) streams_slot_seeds_kernel(Planes p, HitList hits, uint4 *snapshots, unsigned int n_slots, int passes, const int *pass_first)
+{
+    const unsigned int slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= n_slots) return;
+    const unsigned int region = slot / hits.region_slots;
+    if (slot - region * hits.region_slots >= hits.counts[region]) return;
+    const uint32_t *rec = hits.base + (size_t)slot * kHitListWords;
+    const uint32_t pixel = rec[13], draws = rec[14] >> 8;
+    Sfc32 s; s.a = p.sa[pixel]; s.b = p.sb[pixel]; s.c = p.sc[pixel]; s.counter = p.sctr[pixel];
+    int done = 0;
+    for (int k = 0; k < passes; ++k) {
+        for (const int upto = pass_first[k]; done < upto; ++done) (void)random_float(s);
+        Sfc32 t = s;
+        for (uint32_t q = 0; q < draws; ++q) (void)sfc32_next(t);
+        snapshots[(size_t)k * n_slots + slot] = uint4{t.a, t.b, t.c, t.counter};
+    }
+}
+
+// updateSeed (Trace.hs:190-191) for every sample of the call: `draws` draws per held pixel
+__global__ void __launch_bounds__(kBlock) streams_advance_seeds_kernel(Planes p, long long n, int draws)
 {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     Sfc32 s; s.a = p.sa[i]; s.b = p.sb[i]; s.c = p.sc[i]; s.counter = p.sctr[i];
-    int done = 0;
-    for (int k = 0; k < passes; ++k) {
-        snapshots[(size_t)k * (size_t)n + (size_t)i] = uint4{s.a, s.b, s.c, s.counter};
-        for (const int upto = pass_first[k + 1]; done < upto; ++done) (void)random_float(s);
-    }
+    for (int k = 0; k < draws; ++k) (void)random_float(s);
     p.sa[i] = s.a; p.sb[i] = s.b; p.sc[i] = s.c; p.sctr[i] = s.counter;
 }
 
@@ -144,10 +163,12 @@ hipError_t launch_streams_advance_missed(const RenderArgs &a, HitList hits, int 
     return hipGetLastError();
 }
 
-hipError_t launch_streams_seeds(Planes p, uint4 *snapshots, long long n, int passes, const int *pass_first, hipStream_t stream)
+hipError_t launch_streams_seeds(Planes p, HitList hits, uint4 *snapshots, long long n, int passes, const int *pass_first, int draws, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(streams_seeds_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, p, snapshots, n, passes, pass_first);
+    const unsigned int n_slots = hits.n_regions * hits.region_slots;
+    if (n_slots) hipLaunchKernelGGL(streams_slot_seeds_kernel, dim3(blocks_for(n_slots)), dim3(kBlock), 0, stream, p, hits, snapshots, n_slots, passes, pass_first);
+    hipLaunchKernelGGL(streams_advance_seeds_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, p, n, draws);      // (after it, in stream order)
     return hipGetLastError();
 }
 

@@ -115,16 +115,15 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
             const unsigned int take = want < avail ? want : avail;
             const unsigned int rank = rank_in(empty);
             if (!busy && rank < take) {
-                const float4 *r = it.hits.record(cur.first + cur.taken + rank);
+                // initialState (Trace.hs:158-162) one step on: the cached start hit, and the seed the ray of the item's first sample carries -- the
+                // pixel's seed after pass_first[pass] updateSeeds and, for a child of a cached glass primary hit, the 3 or 4 raw draws its ancestors
+                // made (streams_slot_seeds_kernel); two INDEPENDENT loads, both addressed by the slot.  (Indexed by the pixel, the snapshot waited
+                // for the record: two memory latencies in a row in three trips of four -- 8.09 -> 7.93 ms on the glass scene.)
+                const unsigned int slot = cur.first + cur.taken + rank;
+                const float4 *r = it.hits.record(slot);
+                const uint4 snap = it.seed_snapshots[(size_t)cur.pass * it.n_slots + slot];
                 const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
-                const uint32_t px = f2u(r3.y);
-                // initialState (Trace.hs:158-162) one step on: the cached start hit; the item's first sample starts from the
-                // pixel's seed advanced by pass_first[pass] draws, which is what that many updateSeeds leave
-                // ... and, for a child of a cached glass primary hit, by the 3 or 4 raw draws its ancestors made: the item keeps the
-                // seed its next sample's RAY carries, which updateSeed moves on by one like the pixel's own
-                const uint4 snap = it.seed_snapshots[(size_t)cur.pass * it.n_px + px];
                 Sfc32 s0; s0.a = snap.x; s0.b = snap.y; s0.c = snap.z; s0.counter = snap.w;
-                for (uint32_t q = 0; q < (f2u(r3.z) >> 8); ++q) (void)sfc32_next(s0);
                 put(0, r0.x); put(1, r0.y); put(2, r0.z); put(3, r0.w); put(4, r1.x); put(5, r1.y);
                 put(6, r1.z); put(7, r1.w); put(8, r2.x); put(9, r2.y); put(10, r2.z); put(11, r2.w);
                 put(12, u2f(f2u(r3.x) | ((f2u(r3.z) & 1u) << 10) | (f2u(r3.w) << 11))); put(13, r3.y);
@@ -135,9 +134,10 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
             }
             cur.taken += take;
             if (cur.taken >= cur.len) next_chunk(cur, it);
-            // (Tried and dropped, round 4: touching the records of the NEXT refill a trip early -- 8 or 16 lanes load one word each -- and taking
-            // the next chunk one chunk early to touch all of its records and then their seed snapshots: 8.21 / 8.25 / 8.16 ms against 8.09.  The
-            // refill's loads are not what the wave waits for long enough to pay for more loads.)
+            // (Tried and dropped, round 4: touching the records of the NEXT refill a trip early -- 8 or 16 lanes load one word each: 8.21 / 8.25
+            // ms against 8.09; taking the next chunk one chunk early to touch all of its records and then their seed snapshots: 8.16; taking only
+            // its TICKET and record count early, so that the switch to the next chunk waits for nothing: 8.01 against 7.93, C5 part 30.0 against
+            // 29.1 -- a wave that sits on two chunks takes from the queues earlier than it works.  Extra loads cost more than the latency they hide.)
         }
         probe.tickets(chunks_left(cur), busy, samples_left, spill_n, ring_n);
         probe.stamp(1);
