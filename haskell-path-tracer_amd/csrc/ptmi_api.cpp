@@ -463,7 +463,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
         while (passes > 1 && (size_t)passes * hit_slots * sizeof(uint4) > budget) { --passes; first[passes] = n_spp; }
         if ((size_t)passes * hit_slots * sizeof(uint4) > budget) return fail(c, PTMI_ELIMIT, "seed snapshots of the stream form would exceed an eighth of the device's memory");
     }
-    const unsigned long long n_tickets = (unsigned long long)n_regions * (region_slots / 64u) * (unsigned long long)passes;
+    const unsigned long long n_tickets = (unsigned long long)n_regions * (unsigned long long)passes;      // a ticket = a region of the start-hit list in one pass
     if (n_tickets > 0x7fffffffull) return fail(c, PTMI_ELIMIT, "too many items for the stream form of Streams");
     if (grid > n_tickets) grid = (unsigned int)n_tickets;
     const size_t snap_bytes = (size_t)passes * hit_slots * sizeof(uint4);

@@ -97,11 +97,11 @@ __device__ __forceinline__ void queue_store(const RayQueue &q, unsigned int i, V
     r[3] = float4{u2f(s.c), u2f(s.counter), u2f(depth), 0.0f};
 }
 
-// The chunk cursor of the item kernels.  A chunk is 64 slots of a region of the start-hit list; the regions come in groups
+// The chunk cursor of the item kernels.  A chunk is one region of the start-hit list (its records, up to 64 or 128); the regions come in groups
 // of four, one group per dispatch POSITION (the four tiles of a quad, most expensive quad first).  The positions are dealt to
 // eight queues, position p to queue p mod 8 -- one queue per XCD -- so that the tiles of a quad, whose pixels share cache lines
 // of the planes, are worked on behind ONE L2 (dealt to any XCD, every line of the planes was fetched four times).  A queue is a
-// ticket counter: ticket j stands for chunk (j mod n) of pass (j div n), n = the queue's chunks, passes outermost and
+// ticket counter: ticket j stands for region (j mod n) of pass (j div n), n = the queue's regions, passes outermost and
 // positions in dispatch order.  A wave takes tickets -- one returning atomic each; an item is tens to thousands of loop trips
 // -- from the queue of the XCD it runs on (HW_REG_XCC_ID; which wave works on which chunk changes no result) and, when that one
 // is exhausted, from the other XCDs' queues.  Eight counters instead of one: a single word serves ~90 atomics per microsecond
@@ -120,24 +120,28 @@ __device__ __forceinline__ unsigned int xcc_id()
 __device__ __forceinline__ bool chunks_left(const ChunkCursor &c) { return c.tries < 8u; }
 __device__ __forceinline__ void next_chunk(ChunkCursor &c, const ItemArgs &it)
 {
-    const unsigned int per = it.hits.region_slots >> 6;      // chunks per region: 1 or 2
+    // A chunk is a WHOLE region (64 slots, or 128 where a glass primary hit contributes two records).  Until round 4 a 128-slot region was two
+    // chunks of 64 with a ticket each: for every tile without split pixels -- nearly all -- the second ticket found nothing, and a ticket is a
+    // returning atomic followed by a load of the region's record count that needs its answer: two memory latencies in a row with nothing for the
+    // wave to do, paid twice per useful chunk.  Glass 1080p 7.91 -> 7.71 ms, C5 part 29.2 -> 28.5.  (Going further -- one ticket per dispatch
+    // POSITION, four regions and one 16-byte load of their counts -- is four times fewer tickets and much worse: a wave then owns up to 512
+    // items of one pass, heavy quads pile up in single waves, 8.05 ms and 36.4 with 250 000 rays in the overflow stream; the pixels kernel,
+    // whose items are whole pixels, went from 4.24 to 4.82 ms.)
     c.taken = 0; c.len = 0; c.ready = false;
     while (c.tries < 8u) {
         const unsigned int q = (c.home + c.tries) & 7u;
         // positions in queue q: p = 8 s + q < n_positions
         const unsigned int n_pos = c.n_positions > q ? (c.n_positions - q - 1u) / 8u + 1u : 0u;
-        const unsigned int n = n_pos * 4u * per;
+        const unsigned int n = n_pos * 4u;
         unsigned int j = 0;
         if ((threadIdx.x & 63) == 0) j = atomicAdd(it.chunk_cursor + (size_t)q * kCounterStride, 1u);
         j = (unsigned int)__builtin_amdgcn_readfirstlane((int)j);
         if (n == 0u || j / n >= (unsigned int)it.passes) { ++c.tries; continue; }
         c.pass = j / n;
-        const unsigned int k = j - c.pass * n, s_pos = k / (4u * per), r = k - s_pos * (4u * per);
-        c.region = (s_pos * 8u + q) * 4u + r / per;
-        const unsigned int half = r % per;
-        const unsigned int have = it.hits.counts[c.region];
-        c.first = c.region * it.hits.region_slots + half * 64u;
-        c.len = have > half * 64u ? (have - half * 64u < 64u ? have - half * 64u : 64u) : 0u;
+        const unsigned int k = j - c.pass * n, s_pos = k >> 2, r = k & 3u;
+        c.region = (s_pos * 8u + q) * 4u + r;
+        c.first = c.region * it.hits.region_slots;
+        c.len = it.hits.counts[c.region];
         if (c.len) return;
     }
 }
