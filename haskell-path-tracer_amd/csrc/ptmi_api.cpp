@@ -372,7 +372,11 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
     std::memcpy(key.dims, key_dims, sizeof key_dims);
     key.region_slots = region_slots; key.cap_allows_split = a.stream_step_cap >= 3 ? 1 : 0; key.planes_r = nullptr;
     const bool list_kept = c->hit_list_valid && std::memcmp(&key, &c->hit_key, sizeof key) == 0;
+    // A list built by THIS call counts as kept by later ones only if this call gets to its end: what the host keeps beside it (the split pixels'
+    // count, read back below) is only then the list's.  Any error return on the way leaves the list invalid.
+    struct ListGuard { ptmi_ctx *c; bool fresh; bool done = false; ~ListGuard() { if (fresh && !done) c->hit_list_valid = false; } } guard{c, !list_kept};
     if (!list_kept) {
+        c->hit_list_valid = false;
         PTMI_HIP(c, launch_streams_primary(a, hits, c->d_qcount, c->stream));
         c->hit_key = key; c->hit_list_valid = true;
     }
@@ -449,6 +453,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
             PTMI_HIP(c, hipEventRecord(c->ev_join, c->tail_stream));
             PTMI_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         }
+        guard.done = true;
         return PTMI_OK;
     }
 
@@ -572,6 +577,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
     if (c->hit_split_pixels && longest < 2) longest = 2;                        // the children of the cached glass primary hits: traceStep 2
     if (longest == 0) longest = 1;                                              // every primary ray missed: one traceStep all the same
     PTMI_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->d_iters), (int)longest, 1, c->stream));
+    guard.done = true;
     return PTMI_OK;
 }
 
