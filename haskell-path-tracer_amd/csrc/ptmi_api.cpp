@@ -119,6 +119,7 @@ struct ptmi_ctx {
     int opt_arithmetic = PTMI_ARITH_EXACT;
     int opt_glass_batch = 0;                   // PTMI_OPT_GLASS_BATCH: 0 = automatic, 1 = off, k = GLASS hits wait until k are pending in their wave
     int opt_graded = 1;                        // PTMI_OPT_STREAM_GRADED: the split kernel's passes shrink towards the end of the launch
+    int opt_snapshot_mb = 0;                   // PTMI_OPT_SNAPSHOT_BUDGET_MB: 0 = an eighth of the device's memory
 };
 
 namespace {
@@ -464,9 +465,9 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
     int first[kMaxStreamPasses + 1];
     int passes = stream_schedule(n_spp, n, 64ull * grid, c->opt_batch, c->opt_graded != 0, first);
     {   // the seed snapshots are passes x record slots x 16 bytes: within an eighth of the device's memory, merging the LAST passes if need be
-        const size_t budget = c->device_memory / 8;
+        const size_t budget = c->opt_snapshot_mb > 0 ? (size_t)c->opt_snapshot_mb << 20 : c->device_memory / 8;
         while (passes > 1 && (size_t)passes * hit_slots * sizeof(uint4) > budget) { --passes; first[passes] = n_spp; }
-        if ((size_t)passes * hit_slots * sizeof(uint4) > budget) return fail(c, PTMI_ELIMIT, "seed snapshots of the stream form would exceed an eighth of the device's memory");
+        if ((size_t)passes * hit_slots * sizeof(uint4) > budget) return fail(c, PTMI_ELIMIT, "seed snapshots of the stream form would exceed their budget (PTMI_OPT_SNAPSHOT_BUDGET_MB; default: an eighth of the device's memory)");
     }
     const unsigned long long n_tickets = (unsigned long long)n_regions * (unsigned long long)passes;      // a ticket = a region of the start-hit list in one pass
     if (n_tickets > 0x7fffffffull) return fail(c, PTMI_ELIMIT, "too many items for the stream form of Streams");
@@ -1001,6 +1002,9 @@ int ptmi_set_option(ptmi_ctx *c, int option, int64_t value)
     case PTMI_OPT_STREAM_GRADED:
         if (value != 0 && value != 1) return fail(c, PTMI_EINVAL, "graded passes are on (1) or off (0)");
         c->opt_graded = (int)value; return PTMI_OK;
+    case PTMI_OPT_SNAPSHOT_BUDGET_MB:
+        if (value < 0 || value > (1 << 20)) return fail(c, PTMI_EINVAL, "snapshot budget must be 0 (automatic) or megabytes in [1, 2^20]");
+        c->opt_snapshot_mb = (int)value; return PTMI_OK;
     default: return fail(c, PTMI_EINVAL, "unknown option");
     }
 }
@@ -1022,6 +1026,7 @@ int ptmi_get_option(ptmi_ctx *c, int option, int64_t *value)
     case PTMI_OPT_ORDERED_PASSES: *value = c->opt_ordered_passes; return PTMI_OK;
     case PTMI_OPT_GLASS_BATCH: *value = c->opt_glass_batch; return PTMI_OK;
     case PTMI_OPT_STREAM_GRADED: *value = c->opt_graded; return PTMI_OK;
+    case PTMI_OPT_SNAPSHOT_BUDGET_MB: *value = c->opt_snapshot_mb; return PTMI_OK;
     default: return fail(c, PTMI_EINVAL, "unknown option");
     }
 }

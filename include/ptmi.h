@@ -214,7 +214,13 @@ enum {
     /* PTMI_OPT_STREAM_GRADED: scenes with GLASS (or unordered items): 1 (default) = a pixel's samples are cut into GRADED passes -- long
      * items first, single samples last (ptmi_stream_schedule) -- so that the launch does not end with long items in few lanes;
      * 0 = uniform passes (round 3). */
-    PTMI_OPT_STREAM_GRADED = 11
+    PTMI_OPT_STREAM_GRADED = 11,
+    /* PTMI_OPT_SNAPSHOT_BUDGET_MB: the stream form's split kernel starts every pass of every start hit from a 16-byte seed snapshot
+     * (passes x record slots x 16 bytes of device memory: 66 MB per pass at 1080p).  This caps that block: where the schedule's passes
+     * would need more, its LAST passes are merged (longer items at the end of the launch; no seed and no ray changes), and a call whose
+     * single pass still does not fit fails with PTMI_ELIMIT.  0 (default) = an eighth of the device's memory; otherwise megabytes
+     * in [1, 2^20]. */
+    PTMI_OPT_SNAPSHOT_BUDGET_MB = 12
 };
 enum { PTMI_ARITH_EXACT = 0, PTMI_ARITH_CONTRACTED = 1 };
 enum { PTMI_SEED_KEEP_ACCUMULATOR = 0, PTMI_SEED_FROM_RESULT = 1, PTMI_SEED_AUTO = 2 };

@@ -246,14 +246,43 @@ def test_the_split_kernels_scheduling_knobs_change_no_ray_and_no_seed(ctx, pkg, 
         assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) <= REL_TOL
 
 
+def test_a_small_snapshot_budget_merges_the_last_passes_and_changes_no_ray(ctx, pkg, ora):
+    """PTMI_OPT_SNAPSHOT_BUDGET_MB: the seed snapshots are passes x record slots x 16 bytes (here 144 regions x 128 slots: 295 KB per pass, six
+    graded passes of 4, 3, 2, 2, 1, 1 samples); a budget of 1 MB holds three, so the last four passes run as one -- same rays, same seeds, same
+    counts as the oracle's.  A budget that does not hold ONE pass is PTMI_ELIMIT, and the context renders again once it is raised."""
+    B = pkg.binding
+    scene = pkg.world.glass_scene()
+    cam = pkg.world.initial_camera()
+    w, h, spp = 128, 72, 13
+    start = initial_planes(ora, w, h)
+    ctx.set_option(B.OPT_SNAPSHOT_BUDGET_MB, 1)
+    try:
+        assert ctx.get_option(B.OPT_SNAPSHOT_BUDGET_MB) == 1
+        got, st = render(ctx, pkg, scene, cam, w, h, spp, start, stream_form=True)
+        with pytest.raises(pkg.PtmiError) as e:
+            render(ctx, pkg, scene, cam, 640, 360, 2, initial_planes(ora, 640, 360), stream_form=True)     # 7.4 MB per pass
+        assert e.value.code == B.PTMI_ELIMIT
+    finally:
+        ctx.set_option(B.OPT_SNAPSHOT_BUDGET_MB, 0)
+    want, live, dropped, steps = ora.render_streams_wavefront(scene[0], scene[1], cam, w, h, CAP, spp, start)
+    for a, b in zip(got[3:], want[3:]):
+        assert np.array_equal(a, b)
+    assert st["live_bounces"] == live and st["stream_rays_dropped"] == dropped == 0 and st["stream_iterations"] == steps
+    for a, b in zip(got[:3], want[:3]):
+        assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) <= REL_TOL
+    again, _ = render(ctx, pkg, scene, cam, w, h, spp, start, stream_form=True)          # the default budget: six passes
+    for a, b in zip(again[3:], want[3:]):
+        assert np.array_equal(a, b)
+
+
 def test_options_of_the_stream_form_are_range_checked_and_visible(pkg):
     B = pkg.binding
     with pkg.Context(0) as c:
-        defaults = {B.OPT_STREAM_TAIL: -1, B.OPT_ORDERED_PASSES: 0, B.OPT_GLASS_BATCH: 0, B.OPT_STREAM_GRADED: 1}
+        defaults = {B.OPT_STREAM_TAIL: -1, B.OPT_ORDERED_PASSES: 0, B.OPT_GLASS_BATCH: 0, B.OPT_STREAM_GRADED: 1, B.OPT_SNAPSHOT_BUDGET_MB: 0}
         for opt, value in defaults.items():
             assert c.get_option(opt) == value
         for opt, bad in ((B.OPT_STREAM_TAIL, -2), (B.OPT_STREAM_TAIL, 1001), (B.OPT_ORDERED_PASSES, -1), (B.OPT_ORDERED_PASSES, 65),
-                         (B.OPT_GLASS_BATCH, 65), (B.OPT_STREAM_GRADED, 2)):
+                         (B.OPT_GLASS_BATCH, 65), (B.OPT_STREAM_GRADED, 2), (B.OPT_SNAPSHOT_BUDGET_MB, -1), (B.OPT_SNAPSHOT_BUDGET_MB, (1 << 20) + 1)):
             with pytest.raises(pkg.PtmiError) as e:
                 c.set_option(opt, bad)
             assert e.value.code == B.PTMI_EINVAL
