@@ -166,9 +166,10 @@ def streams_rooflines(pkg):
 
 
 def also_measurements(pkg, torch):
-    """The other BASELINE.json configs and the Streams forms, on this GPU, after the headline: 3 timed steps each behind a
-    short warm-up (clock ramp, recorded dispatch order: it is rebuilt before launch 1, 2, 4, 8, ... of a context, so nine warm-up
-    launches leave the three timed ones without a rebuild), resident state, one context each on a stream of its own.
+    """The other BASELINE.json configs and the Streams forms, on this GPU, after the headline: 3 to 5 timed steps each (the mean is
+    reported) behind a short warm-up (clock ramp, recorded dispatch order: it is rebuilt before launch 1, 2, 4, 8, ... of a context, so nine
+    warm-up launches -- every Streams entry has them -- leave the timed ones without a rebuild), resident state, one context each on a
+    stream of its own.
     kernel_ms: HIP events around the launches on the launch stream (ptmi_set_timing)."""
     B = pkg.binding
     cam = pkg.world.initial_camera()
@@ -214,12 +215,12 @@ def also_measurements(pkg, torch):
     run("C3: 3840x2160, 256 spp, limit 8, S16, render Inline", "s16", 3840, 2160, 256, BOUNCE_LIMIT, pkg.INLINE)
     run("C4: 3840x2160, 1024 spp, limit 8, S16, render Inline, the whole image on one GPU", "s16", 3840, 2160, 1024, BOUNCE_LIMIT, pkg.INLINE, warm=2)
     run("C4, one part of 8 (10-row stripes): what one rank of the 8-GPU job renders", "s16", 3840, 2160, 1024, BOUNCE_LIMIT, pkg.INLINE, part_of=8)
-    run("C5, one part of 8: glass scene, 3840x2160, 512 spp, render Streams, per-pixel tree walk (the default with GLASS)", "glass", 3840, 2160, 512, BOUNCE_LIMIT, pkg.STREAMS, part_of=8, profile="c5_tree")
-    run("C5, one part of 8, stream ('wavefront') form: start-hit regions, graded passes, child rings (BASELINE configs[4]'s path)", "glass", 3840, 2160, 512, BOUNCE_LIMIT, pkg.STREAMS, part_of=8, stream_form=True, profile="c5_stream")
-    run("C2 through render Streams, per-pixel chain", "s16", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, warm=9, profile="streams")
-    run("C2 through render Streams, stream form", "s16", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, stream_form=True, warm=9, profile="s16_stream")
-    run("glass scene, 1920x1080, 64 spp, render Streams, tree walk", "glass", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, warm=9, profile="glass_tree")
-    run("glass scene, 1920x1080, 64 spp, render Streams, stream form", "glass", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, stream_form=True, warm=9, profile="glass_stream")
+    run("C5, one part of 8: glass scene, 3840x2160, 512 spp, render Streams, per-pixel tree walk (the default with GLASS)", "glass", 3840, 2160, 512, BOUNCE_LIMIT, pkg.STREAMS, part_of=8, warm=9, profile="c5_tree")
+    run("C5, one part of 8, stream ('wavefront') form: start-hit regions, graded passes, child rings (BASELINE configs[4]'s path)", "glass", 3840, 2160, 512, BOUNCE_LIMIT, pkg.STREAMS, part_of=8, stream_form=True, warm=9, profile="c5_stream")
+    run("C2 through render Streams, per-pixel chain", "s16", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, warm=9, steps=5, profile="streams")
+    run("C2 through render Streams, stream form", "s16", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, stream_form=True, warm=9, steps=5, profile="s16_stream")
+    run("glass scene, 1920x1080, 64 spp, render Streams, tree walk", "glass", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, warm=9, steps=5, profile="glass_tree")
+    run("glass scene, 1920x1080, 64 spp, render Streams, stream form", "glass", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, stream_form=True, warm=9, steps=5, profile="glass_stream")
     return out
 
 
