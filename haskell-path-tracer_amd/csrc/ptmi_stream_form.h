@@ -34,8 +34,9 @@ namespace {
 //                            one float atomic per colour word per item; rays taken from the ring add with float atomics (exact
 //                            zeros skipped).  The order of a pixel's additions is undefined, as in Accelerate's permute.
 //   streams_level_kernel     the overflow levels: one launch per level of what is left in the HBM stream (usually nothing).
-//   streams_seeds_kernel     updateSeed (Trace.hs:190-191) for every pixel and sample of the call, with the seed each item
-//                            starts from recorded on the way (split kernel only).
+//   streams_slot_seeds_kernel / streams_advance_seeds_kernel (split kernel only)   the seed every item starts from, per record slot of the
+//                            start-hit list and per pass, recorded BEFORE updateSeed (Trace.hs:190-191) moves every pixel's seed on by the
+//                            call's samples.
 // Every ray carries its step index (the `awhile` iteration it belongs to), so the safety cap cuts the same rays as in
 // the other forms; cut rays, dropped children (overflow stream full) and emitted children are counted.
 // ---------------------------------------------------------------------------------------

@@ -137,7 +137,9 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
             // (Tried and dropped, round 4: touching the records of the NEXT refill a trip early -- 8 or 16 lanes load one word each: 8.21 / 8.25
             // ms against 8.09; taking the next chunk one chunk early to touch all of its records and then their seed snapshots: 8.16; taking only
             // its TICKET and record count early, so that the switch to the next chunk waits for nothing: 8.01 against 7.93, C5 part 30.0 against
-            // 29.1 -- a wave that sits on two chunks takes from the queues earlier than it works.  Extra loads cost more than the latency they hide.)
+            // 29.1 -- a wave that sits on two chunks takes from the queues earlier than it works.  Extra loads cost more than the latency they hide.
+            // Later in the round, on the final kernel: this block moved behind the "next ray" block with its eighteen words loaded straight into the lanes'
+            // LDS columns by global_load_lds_dword (tools/lds_dma_probe.hip), so that nothing waits for them: + 1 to 2 %.  HISTORY.md, "Round 4".)
         }
         probe.tickets(chunks_left(cur), busy, samples_left, spill_n, ring_n);
         probe.stamp(1);

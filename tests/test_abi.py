@@ -33,6 +33,28 @@ def test_binding_covers_exactly_the_header(pkg):
     pkg.load_library()          # types every symbol; AttributeError if one is missing
 
 
+def test_binding_constants_equal_the_headers_enumerators(pkg):
+    """Every PTMI_OPT_* / PTMI_FORM_* / PTMI_SEED_* / PTMI_ARITH_* / error enumerator of include/ptmi.h that the binding names has the header's value."""
+    text = open(os.path.join(ROOT, "include", "ptmi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    values = {name: int(v, 0) for name, v in re.findall(r"\b(PTMI_[A-Z0-9_]+)\s*=\s*(-?(?:0x[0-9a-fA-F]+|\d+))", text)}
+    B = pkg.binding
+    options = {n: v for n, v in values.items() if n.startswith("PTMI_OPT_")}
+    assert len(options) >= 12
+    checked = 0
+    for name, value in values.items():
+        for prefix in ("PTMI_OPT_", "PTMI_FORM_", "PTMI_ARITH_"):
+            if name.startswith(prefix):
+                short = name[len("PTMI_"):]
+                assert hasattr(B, short), "binding.py has no %s" % short
+                assert getattr(B, short) == value, name
+                checked += 1
+        if hasattr(B, name):                                   # error codes and the like keep their full names
+            assert getattr(B, name) == value, name
+            checked += 1
+    assert checked >= 20
+
+
 def test_version_and_strerror(pkg):
     lib = pkg.load_library()
     assert lib.ptmi_version() == 400
