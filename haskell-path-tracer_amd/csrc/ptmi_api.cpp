@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -288,7 +289,7 @@ int order_schedule(int launches, int stream_form, int *rebuild, int *record)
 // items of very different weight when the tickets run out) -- an eighth of the chip's wave-time idle.  So the passes are GRADED
 // (guided self-scheduling): at most `per_item` samples -- the size that gives a lane its ~16 items -- and never more than a
 // fraction of what is still to come, chosen so that an item five times the mean weight, taken when its pass begins, is over
-// before the remaining passes are: the last passes are single samples, and the end of the launch is as long as one sample's tree.
+// before the remaining passes are: the last passes are a few samples (not fewer than a floor: below), and the end of the launch is as long as their trees.
 // Which sample belongs to which pass changes no seed (snapshots) and no ray; only the order of a pixel's float additions,
 // which the stream form with GLASS does not define anyway.  Returns the number of passes (<= kMaxStreamPasses).
 constexpr int kMaxStreamPasses = 64;
@@ -315,15 +316,26 @@ int stream_schedule(int n_spp, unsigned long long n_px, unsigned long long lanes
     const double f = ((double)n_px / (double)lanes) / 5.0;     // items per lane and pass / the weight of a heavy item
     double frac = f / (1.0 + f);
     frac = frac < 0.2 ? 0.2 : (frac > 0.5 ? 0.5 : frac);
+    // ... and never BELOW a floor: a pass costs every start hit a ticket's share, a refill (record + snapshot into the lane's LDS column) and an
+    // item end (three float atomics), which a single sample does not repay -- glass 1080p / 64 spp with the passes ending 4, 2, 1, 1: 7.70-7.77 ms;
+    // ending 6, 6, 4: 7.60-7.61 (C5's 512 spp: no difference either way).  What the floor leaves over joins the pass before it where the item
+    // cap allows; the sizes are handed out longest first.
+    const int floor_size = per_item >= 16 ? 4 : (per_item >= 8 ? 2 : 1);
+    int sizes[kMaxStreamPasses];
     while (done < n_spp) {
         const int left = n_spp - done;
         int size = (int)((double)left * frac + 0.999999);
         if (size > per_item) size = per_item;
+        if (size < floor_size) size = floor_size;
         const int passes_left = kMaxStreamPasses - passes;     // never more than kMaxStreamPasses passes: a pass takes at least its share of what is left
         const int share = (left + passes_left - 1) / passes_left;
         if (size < share) size = share;
-        done += size; first[++passes] = done;
+        if (size > left) size = left;
+        if (left - size < floor_size && (left <= per_item || passes_left == 1)) size = left;      // (no pass below the floor at the very end)
+        done += size; sizes[passes++] = size;
     }
+    std::sort(sizes, sizes + passes, [](int x, int y) { return x > y; });
+    for (int k = 0, at = 0; k < passes; ++k) { at += sizes[k]; first[k + 1] = at; }
     return passes;
 }
 
@@ -461,7 +473,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
     // ---- rays may split, or the samples of a pixel run as unordered items
     if (quad_positions(a.width, a.rows_local) > (1u << 21)) a.quad_cost = nullptr;      // (the item record keeps the quad in 21 bits: no costs beyond 2^29 pixels)
     unsigned int grid = (unsigned int)(cus * 4 * streams_split_waves());
-    // the passes: graded items, long first and single samples last (stream_schedule above); PTMI_OPT_STREAM_BATCH caps an item's samples
+    // the passes: graded items, long first and short ones last (stream_schedule above); PTMI_OPT_STREAM_BATCH caps an item's samples
     int first[kMaxStreamPasses + 1];
     int passes = stream_schedule(n_spp, n, 64ull * grid, c->opt_batch, c->opt_graded != 0, first);
     {   // the seed snapshots are passes x record slots x 16 bytes: within an eighth of the device's memory, merging the LAST passes if need be

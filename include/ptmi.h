@@ -212,7 +212,7 @@ enum {
      * 1 = off, k in [2, 64]. */
     PTMI_OPT_GLASS_BATCH = 10,
     /* PTMI_OPT_STREAM_GRADED: scenes with GLASS (or unordered items): 1 (default) = a pixel's samples are cut into GRADED passes -- long
-     * items first, single samples last (ptmi_stream_schedule) -- so that the launch does not end with long items in few lanes;
+     * items first, short ones (4 samples where the long ones hold 16 or more) last (ptmi_stream_schedule) -- so that the launch does not end with long items in few lanes;
      * 0 = uniform passes (round 3). */
     PTMI_OPT_STREAM_GRADED = 11,
     /* PTMI_OPT_SNAPSHOT_BUDGET_MB: the stream form's split kernel starts every pass of every start hit from a 16-byte seed snapshot

@@ -224,7 +224,7 @@ def test_the_split_kernels_scheduling_knobs_change_no_ray_and_no_seed(ctx, pkg, 
     """PTMI_OPT_STREAM_GRADED (passes that shrink towards the end of the launch, the default, or round 3's uniform ones) and
     PTMI_OPT_GLASS_BATCH (GLASS hits parked in their lanes until that many are pending in the wave) decide WHEN a ray is traced and
     by which lane, never WHICH rays exist: counts and RNG planes equal the oracle's exactly, colours within the tolerance of the
-    undefined order of a pixel's additions.  13 samples: graded passes of 4, 3, 2, 2, 1, 1 at this size."""
+    undefined order of a pixel's additions.  13 samples: graded passes of 3, 2, 2, 2, 2, 2 at this size."""
     B = pkg.binding
     scene = pkg.world.glass_scene()
     cam = pkg.world.initial_camera()
@@ -248,7 +248,7 @@ def test_the_split_kernels_scheduling_knobs_change_no_ray_and_no_seed(ctx, pkg, 
 
 def test_a_small_snapshot_budget_merges_the_last_passes_and_changes_no_ray(ctx, pkg, ora):
     """PTMI_OPT_SNAPSHOT_BUDGET_MB: the seed snapshots are passes x record slots x 16 bytes (here 144 regions x 128 slots: 295 KB per pass, six
-    graded passes of 4, 3, 2, 2, 1, 1 samples); a budget of 1 MB holds three, so the last four passes run as one -- same rays, same seeds, same
+    graded passes of 3, 2, 2, 2, 2, 2 samples); a budget of 1 MB holds three, so the last four passes run as one -- same rays, same seeds, same
     counts as the oracle's.  A budget that does not hold ONE pass is PTMI_ELIMIT, and the context renders again once it is raised."""
     B = pkg.binding
     scene = pkg.world.glass_scene()
