@@ -506,14 +506,18 @@ inline unsigned int blocks_for(long long n, int block = kBlock) { return (unsign
 
 // Sample chunks (render_inline_kernel): only when the launch has few rounds of waves and every copy keeps >= 64 samples
 // (every copy re-evaluates the primary hit and moves the planes once more).  Sets b.spp_chunks (>= 1) and clears the flags.
-inline hipError_t choose_sample_chunks(RenderArgs &b, unsigned int per_copy, int waves_per_simd, hipStream_t stream)
+// `rounds`: how many rounds of waves the launch should have at least.  16 for the kernels whose copies are cheap to start (Inline and the Streams
+// chain: one part of 8 of a 4K image at 1024 spp is flat between 5 and 8 copies, 21.9 ms, against 22.6 with 2 and 22.4 with 16); 10 for the tree walk,
+// every copy of which evaluates its pixels' start records -- up to three traces and a glass split -- again (C5 per part: 29.2-29.3 ms with 4 copies,
+// 29.6-29.8 with 7, 30.7 with one; 1080p / 256 spp: 28.5 with one or two, 28.9 with 4).
+inline hipError_t choose_sample_chunks(RenderArgs &b, unsigned int per_copy, int waves_per_simd, hipStream_t stream, unsigned long long rounds = 16)
 {
     const int wanted = b.spp_chunks;                           // 0 = automatic, 1 = off, k = forced
     b.spp_chunks = 1;
     if (!b.chunk_done || b.chunk_capacity < per_copy || wanted == 1 || b.screen_x) return hipSuccess;
     const int cus = b.cus > 0 ? b.cus : 256;                   // of the context's device (ptmi_create)
     const unsigned long long slots = (unsigned long long)cus * 4ull * (unsigned long long)waves_per_simd;
-    int k = wanted > 1 ? wanted : (int)((16ull * slots + per_copy - 1) / per_copy);    // aim at >= 16 rounds of waves
+    int k = wanted > 1 ? wanted : (int)((rounds * slots + per_copy - 1) / per_copy);
     if (wanted <= 0 && k > b.n_spp / 64) k = b.n_spp / 64;
     if (k > b.n_spp) k = b.n_spp;
     if (k > 64) k = 64;

@@ -31,6 +31,15 @@ WORKLOADS = {
 for _k in (2, 4, 8, 16, 32):
     WORKLOADS["glass_stream_g%d" % _k] = ("glass", "streams", "stream", {"GLASS_BATCH": _k}, None)
     WORKLOADS["c5_stream_g%d" % _k] = ("glass", "streams", "stream", {"GLASS_BATCH": _k}, C5_PART)
+for _k in (1, 2, 4, 6, 8, 12, 16):                          # PTMI_OPT_SPP_CHUNKS of the per-tile kernels (0 = automatic is the plain workload)
+    WORKLOADS["glass_tree_c%d" % _k] = ("glass", "streams", "auto", {"SPP_CHUNKS": _k}, None)
+    WORKLOADS["c5_tree_c%d" % _k] = ("glass", "streams", "auto", {"SPP_CHUNKS": _k}, C5_PART)
+C4_PART = (3840, 2160, 1024, 8)     # one of 8 parts of BASELINE configs[3]
+WORKLOADS["c4_part"] = ("s16", "inline", "auto", {}, C4_PART)
+WORKLOADS["c4_part_streams"] = ("s16", "streams", "auto", {}, C4_PART)
+for _k in (1, 2, 4, 5, 6, 8, 12, 16):
+    WORKLOADS["c4_part_c%d" % _k] = ("s16", "inline", "auto", {"SPP_CHUNKS": _k}, C4_PART)
+    WORKLOADS["c4_part_streams_c%d" % _k] = ("s16", "streams", "auto", {"SPP_CHUNKS": _k}, C4_PART)
 for _k in (4, 8, 16, 32, 64):
     WORKLOADS["glass_stream_b%d" % _k] = ("glass", "streams", "stream", {"STREAM_BATCH": _k}, None)
     WORKLOADS["s16_stream_b%d" % _k] = ("s16", "streams", "stream", {"STREAM_BATCH": _k}, None)
