@@ -34,6 +34,8 @@ for _k in (2, 4, 8, 16, 32):
 for _k in (1, 2, 4, 6, 8, 12, 16):                          # PTMI_OPT_SPP_CHUNKS of the per-tile kernels (0 = automatic is the plain workload)
     WORKLOADS["glass_tree_c%d" % _k] = ("glass", "streams", "auto", {"SPP_CHUNKS": _k}, None)
     WORKLOADS["c5_tree_c%d" % _k] = ("glass", "streams", "auto", {"SPP_CHUNKS": _k}, C5_PART)
+for _k in (0, 50, 100, 150, 200, 250, 300, 400, 500):      # PTMI_OPT_STREAM_TAIL (thousandths of the recorded cost left to the per-pixel kernel)
+    WORKLOADS["s16_stream_t%d" % _k] = ("s16", "streams", "stream", {"STREAM_TAIL": _k}, None)
 C4_PART = (3840, 2160, 1024, 8)     # one of 8 parts of BASELINE configs[3]
 WORKLOADS["c4_part"] = ("s16", "inline", "auto", {}, C4_PART)
 WORKLOADS["c4_part_streams"] = ("s16", "streams", "auto", {}, C4_PART)
