@@ -260,6 +260,10 @@ def main():
                          "e.g. C5 per part: --scene glass --algorithm streams --width 3840 --height 2160 --spp 512 --part-of 8")
     ap.add_argument("--streams-form", choices=["auto", "stream"], default="auto",
                     help="render Streams: per-pixel kernels (auto) or the stream ('wavefront') form")
+    ap.add_argument("--ramp-spp", type=int, default=64,
+                    help="samples per launch of the untimed clock ramp before the warm-up (capped at the workload's spp); 0 = the workload's "
+                         "own spp, so that EVERY launch of the process is a launch of the workload -- what tools/pmc_kernels.sh passes: a "
+                         "per-kernel mean of a profile must not mix two launch sizes")
     args = ap.parse_args()
 
     import torch
@@ -353,10 +357,13 @@ def main():
     # Set-up, untimed and outside the W/K protocol: load the code object and let the device leave its idle
     # clock state (the first ~10 launches after start-up run ~7 % slower), so that W and K measure steady state
     # whatever their values.  State is re-initialised afterwards.
+    ramp_spp = spp if args.ramp_spp <= 0 else min(spp, args.ramp_spp)
     t_ramp = time.perf_counter()
+    ramp_launches = 0
     while time.perf_counter() - t_ramp < 0.3:
-        ctx.render(cam, BOUNCE_LIMIT, min(spp, 64), algorithm)
+        ctx.render(cam, BOUNCE_LIMIT, ramp_spp, algorithm)
         torch.cuda.synchronize()
+        ramp_launches += 1
     if world > 1:
         gather.overlapped(color)                     # first collective = communicator set-up; not a warm-up step
         gather.wait()
@@ -427,13 +434,31 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
     stats = ctx.stats()
 
+    per_rank, render_only_ms = None, None
     if world > 1:
+        # what every rank did in the timed region, so that a scaling record explains itself: the slowest rank sets the step (MAX below),
+        # imbalance = slowest rank's kernel time / the mean says how much of a missing speed-up is the stripes' doing
+        mine = torch.tensor([elapsed, kernel_ms, float(ctx.local_rows), float(stats["live_bounces"])], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [{"rank": r, "elapsed_ms_per_step": round(float(v[0]) / max(args.steps, 1) * 1e3, 4), "kernel_ms": round(float(v[1]), 4),
+                     "rows": int(v[2]), "live_bounces": int(v[3])} for r, v in enumerate(every)]
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
         tot = torch.tensor([stats["live_bounces"]], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot)
         live_total = int(tot[0])
+        # the same steps WITHOUT the gather (outside the timed region, same fences, MAX over ranks): what the overlap has to hide
+        k_only = max(1, min(args.steps, 4))
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(k_only):
+            ctx.render(cam, BOUNCE_LIMIT, spp, algorithm)
+        fence()
+        t_only = torch.tensor([(time.perf_counter() - t1) / k_only], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t_only, op=dist.ReduceOp.MAX)
+        render_only_ms = float(t_only[0]) * 1e3
     else:
         live_total = stats["live_bounces"]
 
@@ -531,8 +556,23 @@ def main():
             "live_bounce_fraction": round(live_total / (nominal_per_step * args.steps), 4) if args.algorithm == "inline" else None,
             "live_Mbounces_per_s": round(live_total / elapsed / 1e6, 1),
             "roofline": roofline,
+            # which binary produced these numbers: the id linked into the loaded libptmi.so (ptmi_build_id) and the hash of the sources
+            # beside it now -- binding.open_library has already refused the library if they differ
+            "binary_build_id": pkg.load_library().build_id, "source_hash_now": pkg._build.source_hash(),
+            "ramp": {"spp_per_launch": ramp_spp, "launches": ramp_launches},
         }
         if collective is not None:
+            collective["per_rank"] = per_rank
+            kms = [r["kernel_ms"] for r in per_rank]
+            collective["imbalance"] = round(max(kms) / (sum(kms) / len(kms)), 4) if sum(kms) > 0 else None
+            collective["imbalance_is"] = "slowest rank's kernel_ms / mean kernel_ms over the ranks, timed region (1 = perfectly even stripes)"
+            step_ms = elapsed / max(args.steps, 1) * 1e3
+            g_ms = collective["gather_ms_not_overlapped"]
+            collective["render_only_ms_per_step"] = round(render_only_ms, 4)
+            collective["gather_hidden_frac"] = round(1.0 - (step_ms - render_only_ms) / g_ms, 4) if g_ms > 0 else None
+            collective["gather_hidden_frac_is"] = ("1 - (ms_per_step with the overlapped gather - render_only_ms_per_step) / gather_ms_not_overlapped: "
+                                                   "1 = the gather costs the step nothing, 0 = it costs as much as when nothing runs beside it "
+                                                   "(figures of different loops: read it within their noise)")
             out["collective"] = collective
         if image_equal is not None:
             out["gathered_image_equals_one_context"] = bool(image_equal)

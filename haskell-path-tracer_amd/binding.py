@@ -33,6 +33,7 @@ class Stats(C.Structure):
 
 SYMBOLS = {
     "ptmi_version": (C.c_int, []),
+    "ptmi_build_id": (C.c_char_p, []),
     "ptmi_strerror": (C.c_char_p, [C.c_int]),
     "ptmi_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "ptmi_destroy": (None, [_vp]),
@@ -82,6 +83,7 @@ SYMBOLS = {
     "ptmi_partition_global_row": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ptmi_reset_stats": (C.c_int, [_vp]),
     "ptmi_debug_counters": (C.c_int, [_vp, _vp]),
+    "ptmi_debug_counters_n": (C.c_int, [_vp, _vp, C.c_int]),
     "ptmi_order_schedule": (C.c_int, [C.c_int, C.c_int, _i32p, _i32p]),
     "ptmi_stream_schedule": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, _vp, C.c_int]),
     "ptmi_eval_distance_to_sphere": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
@@ -99,15 +101,24 @@ class PtmiError(RuntimeError):
 _lib = None
 
 
-def open_library(path):
+def open_library(path, check_build_id=True):
     """dlopen one libptmi build and type every symbol (a second build -- the ablation library, a diagnostic build -- can be
-    open beside the default one: Context(library=...))."""
+    open beside the default one: Context(library=...)).
+    The library must have been built from the sources beside this file: its ptmi_build_id() has to start with
+    _build.source_hash() (behind it a diagnostic build names its extra flags).  A binary that travelled with edited sources, or
+    one from an older checkout, is refused here instead of being measured under the wrong name."""
     if not os.path.exists(path):
         raise PtmiError(PTMI_ESTATE, "libptmi.so not built (%s); run __graft_entry__.build()" % path)
     lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export it
         fn.restype, fn.argtypes = res, args
+    lib.build_id = (lib.ptmi_build_id() or b"").decode("ascii", "replace")
+    if check_build_id:
+        want = _build.source_hash()
+        if lib.build_id.split("+")[0] != want:
+            raise PtmiError(PTMI_ESTATE, "%s was built from other sources: it carries build id %r, the sources here hash to %r; "
+                                         "rebuild it (__graft_entry__.build())" % (path, lib.build_id, want))
     return lib
 
 
@@ -320,7 +331,9 @@ class Context:
 
     def debug_counters(self):
         out = np.zeros(256, np.uint32)
-        self._check(self._lib.ptmi_debug_counters(self._h, _ptr(out)))
+        n = self._lib.ptmi_debug_counters_n(self._h, _ptr(out), out.size)
+        if n < 0:
+            self._check(n)
         return out
 
     def reset_stats(self):

@@ -55,7 +55,7 @@ struct ptmi_ctx {
     hipStream_t tail_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned int *d_tail_start = nullptr;
-    int opt_tail_permille = -1;                // PTMI_OPT_STREAM_TAIL: thousandths of the recorded cost the tail may hold (0 = no tail; -1 = automatic; PTMI_STREAM_TAIL in the environment overrides at creation)
+    int opt_tail_permille = -1;                // PTMI_OPT_STREAM_TAIL: thousandths of the recorded cost the tail may hold (0 = no tail; -1 = automatic)
     bool ev_valid = false;
     int variant = 0;
     Stager stager;                          // pinned ring + worker threads for host-buffer entry points (ptmi_stage.h)
@@ -97,7 +97,7 @@ struct ptmi_ctx {
     size_t tree_stack_bytes = 0;
     unsigned int *d_region_done = nullptr;   // stream form, ordered passes: items published per region
     unsigned int region_done_words = 0;
-    int opt_ordered_passes = 0;      // PTMI_OPT_ORDERED_PASSES: 0 = automatic, 1 = off, k = k passes (PTMI_ORDERED_PASSES in the environment overrides at creation)
+    int opt_ordered_passes = 0;      // PTMI_OPT_ORDERED_PASSES: 0 = automatic, 1 = off, k = k passes
     int *d_pass_first = nullptr;     // stream form, split kernel: the samples of every pass (ItemArgs.pass_first), kMaxStreamPasses + 1 entries
     std::vector<int> pass_first_host;   // ... what the device block holds
     unsigned int *d_qcount = nullptr;
@@ -754,10 +754,6 @@ int ptmi_create(ptmi_ctx **out, int device)
     ptmi_ctx *c = new (std::nothrow) ptmi_ctx;
     if (!c) return fail(nullptr, PTMI_ENOMEM, "host allocation failed");
     c->device = device;
-    // Two environment OVERRIDES of options (PTMI_OPT_ORDERED_PASSES, PTMI_OPT_STREAM_TAIL), read once here, for experiments on a host
-    // program that cannot be rebuilt; values outside the options' ranges are ignored.  ptmi_get_option shows what is in force.
-    if (const char *e = std::getenv("PTMI_ORDERED_PASSES")) { const int v = std::atoi(e); if (v >= 0 && v <= 64) c->opt_ordered_passes = v; }
-    if (const char *e = std::getenv("PTMI_STREAM_TAIL")) { const int v = std::atoi(e); if (v >= -1 && v <= 1000) c->opt_tail_permille = v; }
     auto bail = [&](hipError_t err, const char *what) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);
         ptmi_destroy(c);
@@ -1270,15 +1266,23 @@ int ptmi_get_stats(ptmi_ctx *c, ptmi_stats *out)
     return PTMI_OK;
 }
 
-int ptmi_debug_counters(ptmi_ctx *c, uint32_t out[256])
+int ptmi_debug_counters_n(ptmi_ctx *c, uint32_t *out, int capacity)
 {
     if (!c) return PTMI_EINVAL;
     std::lock_guard<std::mutex> lock(c->mu);
     if (!out) return fail(c, PTMI_EINVAL, "out is NULL");
+    if (capacity < 0) return fail(c, PTMI_EINVAL, "capacity is negative");
+    const int words = capacity < kWorkWords ? capacity : kWorkWords;
     PTMI_HIP(c, hipSetDevice(c->device));
-    PTMI_HIP(c, hipMemcpyAsync(out, c->d_work, kWorkWords * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (words > 0) PTMI_HIP(c, hipMemcpyAsync(out, c->d_work, (size_t)words * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
-    return PTMI_OK;
+    return words;
+}
+
+int ptmi_debug_counters(ptmi_ctx *c, uint32_t out[64])
+{
+    const int rc = ptmi_debug_counters_n(c, out, 64);
+    return rc < 0 ? rc : PTMI_OK;
 }
 
 int ptmi_reset_stats(ptmi_ctx *c)

@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define PTMI_VERSION 400   /* 0.4.0: options 8-11 (the stream form's scheduling knobs, formerly environment variables), ptmi_stream_schedule, 256 debug counters */
+#define PTMI_VERSION 500   /* 0.5.0: ptmi_build_id; ptmi_debug_counters writes 64 words again (as in 0.3) and ptmi_debug_counters_n takes a
+                            * capacity; no option is read from the environment any more.  (0.4.0: options 8-12, ptmi_stream_schedule.) */
 
 /* ---- error codes ------------------------------------------------------------ */
 enum {
@@ -101,6 +102,11 @@ typedef struct ptmi_ctx ptmi_ctx;
 
 /* ---- lifetime ---------------------------------------------------------------- */
 int         ptmi_version(void);
+/* What this binary was built from: the first 16 hex digits of the sha256 over the kernel sources, headers and build flags
+ * (haskell-path-tracer_amd/_build.py: source_hash), followed by "+<flags>" for a non-default build (ablations, diagnostic builds).
+ * Every measurement names it (bench.py: binary_build_id; profiles/): a number belongs to the binary that carries the id, and the
+ * Python binding refuses a library whose id is not that of the sources beside it.  Never NULL; static storage. */
+const char *ptmi_build_id(void);
 const char *ptmi_strerror(int code);
 /* Create a context on HIP device `device` (>= 0).  Fails with PTMI_ENODEVICE when the
  * machine has no usable GPU: there is NO CPU fallback in this library. */
@@ -142,7 +148,7 @@ int ptmi_set_timing(ptmi_ctx *ctx, int enabled);
 /* Kernel variant selection for measurements: 0 = default.  See DESIGN.md "kernel variants". */
 int ptmi_set_variant(ptmi_ctx *ctx, int variant);
 
-/* Options.  1-5 and 8-11 concern `render Streams` (src/Scene/Trace.hs:141-191) and never change `render Inline`; 6 is a
+/* Options.  1-5 and 8-12 concern `render Streams` (src/Scene/Trace.hs:141-191) and never change `render Inline`; 6 is a
  * scheduling knob of the per-pixel kernels that changes no result; 7 is a labelled measurement mode of `render Inline`. */
 enum {
     /* Which seed a pixel carries out of `combine` (Trace.hs:179-184): the combination function keeps the seed of its
@@ -191,12 +197,12 @@ enum {
      * the oracle's (the RNG planes still are: integer arithmetic); DESIGN.md reports how far they are and what the literal
      * reading -- every operation rounded on its own, PTMI_ARITH_EXACT -- costs.  Variants and Streams ignore it. */
     PTMI_OPT_ARITHMETIC = 7,
-    /* 8-11: scheduling knobs of the stream form of Streams.  None changes a ray, a seed or (without GLASS) a bit of the planes.
+    /* 8-12: scheduling knobs of the stream form of Streams.  None changes a ray, a seed or (without GLASS) a bit of the planes.
      *
      * PTMI_OPT_STREAM_TAIL: scenes without GLASS, one-pass launches: the cheapest quads of the dispatch order -- the cheapest classes
      * that together hold at most this many THOUSANDTHS of the recorded cost -- are rendered by the per-pixel chain kernel on a
      * low-priority stream beside the persistent launch, whose waves' slots it fills as they end.  -1 (default) = automatic (150, or 400
-     * where a lane sees fewer than four pixels), 0 = no tail.  (Environment override at creation: PTMI_STREAM_TAIL.) */
+     * where a lane sees fewer than four pixels), 0 = no tail. */
     PTMI_OPT_STREAM_TAIL = 8,
     /* PTMI_OPT_ORDERED_PASSES: scenes without GLASS: a pixel's samples cut into this many ORDERED passes inside the one launch; the pixel's
      * seven words are handed from the lane that rendered pass p to whichever lane -- of any wave, on any XCD -- takes pass p + 1, through
@@ -205,7 +211,8 @@ enum {
      * profiles/r03_soak_ordered_passes.json) -- not a promise of the HSA memory model.  0 (default) = automatic (only for parts of an
      * image at >= 256 spp, where it is worth 5-8 %), 1 = OFF: one pass per launch, no hand-off between waves at all -- what a caller
      * who wants only architecturally guaranteed synchronisation sets -- k in [2, 64] = k passes.  1 also overrides PTMI_OPT_STREAM_BATCH
-     * for scenes without GLASS.  (Environment override at creation: PTMI_ORDERED_PASSES.) */
+     * for scenes without GLASS.  (Until 0.4 the environment variables PTMI_ORDERED_PASSES / PTMI_STREAM_TAIL overrode these two options at
+     * creation; nothing is read from the environment any more: a stray variable cannot change scheduling behind the caller's back.) */
     PTMI_OPT_ORDERED_PASSES = 9,
     /* PTMI_OPT_GLASS_BATCH: scenes with GLASS: a GLASS hit waits in its lane until this many lanes of its wave hold one (or the wave has
      * nothing else to shade or trace), so that the refraction block runs for that many lanes at a time.  0 (default) = automatic,
@@ -298,10 +305,13 @@ int ptmi_snapshot_color(ptmi_ctx *ctx, float *dst_device, void *hip_stream);
 
 int ptmi_get_stats(ptmi_ctx *ctx, ptmi_stats *out);   /* synchronises the launch stream */
 int ptmi_reset_stats(ptmi_ctx *ctx);
-/* Diagnostics: the 256 raw device counters (hand-out counter in [0]; the diagnostic builds of the kernels --
+/* Diagnostics: the raw device counters (hand-out counter in [0]; the diagnostic builds of the kernels --
  * -DPTMI_PHASE_STATS and the others listed in csrc/ptmi_diag.h -- add their statistics, see tools/phase_stats.py).
- * Synchronises the launch stream. */
-int ptmi_debug_counters(ptmi_ctx *ctx, uint32_t out[256]);
+ * ptmi_debug_counters writes the first 64 words (its contract since 0.3; 0.4 wrote 256 into the same argument and overran a
+ * caller built against 0.3); ptmi_debug_counters_n writes min(capacity, 256) words and returns how many, or a negative code.
+ * Both synchronise the launch stream. */
+int ptmi_debug_counters(ptmi_ctx *ctx, uint32_t out[64]);
+int ptmi_debug_counters_n(ptmi_ctx *ctx, uint32_t *out, int capacity);
 
 /* ---- groups: the GPUs of one node behind ONE host process ------------------------ */
 /* The reference's host is a single process holding one compiled function (app/Main.hs:188-191); a group lets that

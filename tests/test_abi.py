@@ -57,8 +57,51 @@ def test_binding_constants_equal_the_headers_enumerators(pkg):
 
 def test_version_and_strerror(pkg):
     lib = pkg.load_library()
-    assert lib.ptmi_version() == 400
+    assert lib.ptmi_version() == 500
     assert lib.ptmi_strerror(0) == b"ok" and lib.ptmi_strerror(-2) == b"no usable HIP device"
+
+
+def test_library_carries_the_hash_of_the_sources_it_was_built_from(pkg):
+    """ptmi_build_id() of the loaded library == the id read from the file == _build.source_hash() of the sources beside it."""
+    lib = pkg.load_library()
+    want = pkg._build.source_hash()
+    assert re.fullmatch(r"[0-9a-f]{16}", want)
+    assert lib.ptmi_build_id().decode() == want == lib.build_id
+    assert pkg._build.read_build_id(pkg._build.LIB) == want
+    assert not pkg._build.is_stale()
+    assert pkg._build.build_id(["-DPTMI_ABLATIONS"]) == want + "+PTMI_ABLATIONS"
+
+
+def test_a_library_built_from_other_sources_is_refused(pkg, tmp_path):
+    """A binary whose id is not the hash of the sources here (it travelled with edited sources, or comes from another checkout)
+    is refused by the binding and counts as stale for the build, whatever its file time says."""
+    import shutil
+    want = pkg._build.source_hash().encode()
+    blob = open(pkg._build.LIB, "rb").read()
+    marker = pkg._build.BUILD_ID_MARKER + want
+    assert blob.count(marker) == 1
+    foreign = bytes(reversed(want)) if bytes(reversed(want)) != want else b"0" * 16
+    other = tmp_path / "libptmi_foreign.so"
+    other.write_bytes(blob.replace(marker, pkg._build.BUILD_ID_MARKER + foreign))
+    os.utime(other, (2 ** 31, 2 ** 31))                      # newer than every source: an mtime rule would call it current
+    assert pkg._build.read_build_id(str(other)) == foreign.decode()
+    assert pkg._build.is_stale(str(other))
+    with pytest.raises(pkg.PtmiError) as e:
+        pkg.binding.open_library(str(other))
+    assert e.value.code == pkg.binding.PTMI_ESTATE and foreign.decode() in str(e.value)
+    lib = pkg.binding.open_library(str(other), check_build_id=False)       # (the explicit way round the check, for archaeology)
+    assert lib.build_id == foreign.decode()
+    assert pkg._build.read_build_id(str(tmp_path / "missing.so")) is None
+    shutil.copy(__file__, tmp_path / "not_a_library.so")
+    assert pkg._build.read_build_id(str(tmp_path / "not_a_library.so")) is None
+
+
+def test_debug_counters_capacity(pkg):
+    """ptmi_debug_counters keeps its 64-word contract; the sized entry point is declared with a capacity."""
+    text = open(os.path.join(ROOT, "include", "ptmi.h")).read()
+    assert "int ptmi_debug_counters(ptmi_ctx *ctx, uint32_t out[64]);" in text
+    assert "int ptmi_debug_counters_n(ptmi_ctx *ctx, uint32_t *out, int capacity);" in text
+    assert "getenv(\"PTMI_ORDERED_PASSES\")" not in open(os.path.join(ROOT, "haskell-path-tracer_amd", "csrc", "ptmi_api.cpp")).read()
 
 
 def test_struct_layouts_match_header(pkg):

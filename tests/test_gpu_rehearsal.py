@@ -36,3 +36,17 @@ def test_bench_strong_scaling_rehearsal_gathers_the_one_context_image():
     assert out["n_gpus"] == 3 and out["scaling"] == "strong"
     assert out["config"]["width"] == 3840 and out["config"]["height"] == 2160
     assert out["gathered_image_equals_one_context"] is True
+    # the line explains itself (bench.py, N > 1): the job checked its own image before anything was timed, says how many ranks and
+    # DISTINCT devices the collective saw (one here: the rehearsal shares cuda:0), what every rank did and what the gather cost
+    col = out["collective"]
+    assert col["world_size"] == 3 and col["backend"] == "gloo"
+    assert col["distinct_devices"] == 1 and len(col["devices"]) == 3
+    assert col["gathered_image_equals_one_context_at_6_spp"] is True
+    ranks = col["per_rank"]
+    assert [r["rank"] for r in ranks] == [0, 1, 2]
+    assert sum(r["rows"] for r in ranks) == 2160 and all(r["kernel_ms"] > 0 and r["live_bounces"] > 0 for r in ranks)
+    assert col["imbalance"] >= 1.0
+    assert col["render_only_ms_per_step"] > 0 and isinstance(col["gather_hidden_frac"], float)
+    assert max(r["elapsed_ms_per_step"] for r in ranks) == pytest.approx(out["ms_per_step"], rel=1e-3)
+    # ... and names the binary that produced it
+    assert out["binary_build_id"] == out["source_hash_now"]

@@ -2,7 +2,10 @@
 """pmc_summary.py DIR -- per-kernel totals of a tools/pmc_kernels.sh run: calls, time (kernel trace), SQ counters summed
 over all dispatches of the kernel, and what they imply (active lanes per VALU instruction, SIMD cycles per VALU
 instruction at the clock GRBM_GUI_ACTIVE implies, share of wave cycles spent waiting).  All figures are totals over the
-profiled run (ramp + warm-up + 4 timed steps of bench.py); ratios do not depend on that."""
+profiled run (ramp + warm-up + 4 timed steps of bench.py, every launch at the workload's own sample count: pmc_kernels.sh
+passes --ramp-spp 0); n / min / max of the dispatch durations say whether the mean is a mean of ONE launch size
+(`one_launch_size`: max <= 1.25 min; a profile that mixes sizes describes neither), and `_bench` carries the bench line's own
+kernel time under the profiler, which tools/valu_roofline.py holds every entry against."""
 import collections
 import csv
 import glob
@@ -21,11 +24,14 @@ def short(name):
 def main():
     src = sys.argv[1]
     calls, ns = collections.Counter(), collections.Counter()
+    lo, hi = {}, {}
     for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv")):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
+            d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             calls[k] += 1
-            ns[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            ns[k] += d
+            lo[k], hi[k] = min(lo.get(k, d), d), max(hi.get(k, d), d)
     counters = collections.defaultdict(collections.Counter)
     dispatches = collections.defaultdict(collections.Counter)
     for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
@@ -39,6 +45,7 @@ def main():
             continue
         c = counters.get(k, {})
         rec = {"calls": calls[k], "total_ms": round(ns[k] / 1e6, 3), "avg_us": round(ns[k] / calls[k] / 1e3, 2),
+               "min_us": round(lo[k] / 1e3, 2), "max_us": round(hi[k] / 1e3, 2), "one_launch_size": hi[k] <= 1.25 * lo[k],
                "share_of_gpu_time": round(ns[k] / sum(ns.values()), 4)}
         # a PMC pass may see a different number of dispatches than the trace pass (same command, same count expected)
         scale = {name: calls[k] / dispatches[k][name] for name in c if dispatches[k][name]}
@@ -64,7 +71,9 @@ def main():
         out[k] = rec
     try:
         bench = json.load(open(os.path.join(src, "bench.json")))
-        out["_bench"] = {"workload": bench["config"]["workload"], "ms_per_step_under_rocprof": bench["ms_per_step"]}
+        out["_bench"] = {"workload": bench["config"]["workload"], "ms_per_step_under_rocprof": bench["ms_per_step"],
+                         "kernel_ms_under_rocprof": bench["roofline"]["kernel_ms"], "steps": bench["steps"], "warmup": bench["warmup"],
+                         "ramp": bench.get("ramp"), "binary_build_id": bench.get("binary_build_id")}
     except Exception:
         pass
     print(json.dumps(out, indent=1))

@@ -31,6 +31,25 @@ MEASURED_OP = {"ADD_F32": "v_add_f32", "MUL_F32": "v_mul_f32", "FMA_F32": "v_fma
                "ADD_F64": "v_add_f64", "MUL_F64": "v_mul_f64", "FMA_F64": "v_fma_f64", "TRANS_F64": "v_sqrt_f32", "OTHER": "v_mov_b32"}
 
 
+class NotTheWorkload(ValueError):
+    pass
+
+
+def check_against_bench(name, rec, bench, tolerance=0.10):
+    """A per-call mean of a profile is evidence for a workload only if the profiled calls WERE that workload: the kernel's mean
+    duration in the trace must lie within `tolerance` of the bench line's own kernel time in the same (profiled) process, and the
+    dispatches must be of one size.  (Round 4's C5 entries failed both: 72 of 77 dispatches were 64-spp ramp launches, mean 5.6 ms
+    against a 28.7-ms step.)  Raises NotTheWorkload; the entry is then left out."""
+    if not bench or not bench.get("kernel_ms_under_rocprof"):
+        raise NotTheWorkload("%s: the summary has no _bench.kernel_ms_under_rocprof to hold the profile against (re-run tools/pmc_kernels.sh)" % name)
+    want_us = bench["kernel_ms_under_rocprof"] * 1e3
+    if abs(rec["avg_us"] - want_us) > tolerance * want_us:
+        raise NotTheWorkload("%s: %.1f us per call in the profile, %.1f us per step in its own bench line (n %s, min %s, max %s): not a profile of this workload"
+                             % (name, rec["avg_us"], want_us, rec.get("calls"), rec.get("min_us"), rec.get("max_us")))
+    if rec.get("one_launch_size") is False:
+        raise NotTheWorkload("%s: dispatches between %s and %s us: the profile mixes launch sizes" % (name, rec.get("min_us"), rec.get("max_us")))
+
+
 def account(name, rec, ops8):
     """The VALU issue accounting of one kernel of a pmc_summary (see the module docstring)."""
     c, calls = rec["counters_total"], rec["calls"]
@@ -100,7 +119,9 @@ def streams(tag):
             tail = [(k, v) for k, v in summary.items() if "render_streams_kernel" in k and "counters_total" in v and "SQ_INSTS_VALU" in v["counters_total"]]
             if tail:
                 tname, trec = tail[0]
-                both = {"calls": rec["calls"], "avg_us": max(rec["avg_us"], trec["avg_us"]), "counters_total": {}}
+                both = {"calls": rec["calls"], "avg_us": max(rec["avg_us"], trec["avg_us"]), "counters_total": {},
+                        "min_us": max(rec.get("min_us", 0), trec.get("min_us", 0)), "max_us": max(rec.get("max_us", 0), trec.get("max_us", 0)),
+                        "one_launch_size": rec.get("one_launch_size") and trec.get("one_launch_size")}
                 for cname, value in rec["counters_total"].items():
                     both["counters_total"][cname] = value + trec["counters_total"].get(cname, 0.0) * rec["calls"] / trec["calls"]
                 span_cycles = rec["counters_total"]["GRBM_GUI_ACTIVE"] / rec["avg_us"] * both["avg_us"]     # the same clock over the longer span
@@ -109,9 +130,17 @@ def streams(tag):
                     if k2 in rec:
                         both[k2] = rec[k2] + trec.get(k2, 0.0)
                 name, rec = name + " + " + tname + " (the tail beside it)", both
+        bench = summary.get("_bench", {})
+        try:
+            check_against_bench(name, rec, bench)
+        except NotTheWorkload as e:
+            print("REFUSED %s: %s" % (key, e), file=sys.stderr)
+            continue
         a = account(name, rec, ops8)
-        a.update({"workload": summary.get("_bench", {}).get("workload"), "source": "profiles/%s_pmc_%s.json + profiles/%s_valu_rates.json" % (tag, key, tag),
-                  "source_hash": source_hash})
+        a.update({"workload": bench.get("workload"), "source": "profiles/%s_pmc_%s.json + profiles/%s_valu_rates.json" % (tag, key, tag),
+                  "bench_kernel_us_under_rocprof": round(bench["kernel_ms_under_rocprof"] * 1e3, 1),
+                  # the id the PROFILED binary carried (its bench line printed ptmi_build_id()); else what the profile round recorded
+                  "source_hash": (bench.get("binary_build_id") or source_hash).split("+")[0]})
         out[key] = a
     json.dump(out, open(os.path.join(ROOT, "profiles", "%s_valu_roofline_streams.json" % tag), "w"), indent=1)
     for key, a in out.items():
@@ -127,11 +156,14 @@ def main():
     tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
     name, rec = next((k, v) for k, v in summary.items() if "render_inline_kernel" in k)
     ops8 = rates["results"]["waves_per_simd_8"]["ops"]
+    bench = summary.get("_bench", {})
+    check_against_bench(name, rec, bench)                # raises: a C2 profile that is not C2 must not become roofline.valu
     out = account(name, rec, ops8)
-    out.update({"workload": summary.get("_bench", {}).get("workload"),
+    out.update({"workload": bench.get("workload"),
                 "source": "rocprofv3 --pmc passes of tools/pmc_kernels.sh c2 (means over all launches of the run) + build/valu_rates",
-                # of the sources the PROFILED binary was built from (tools/profile_round.sh records it on the GPU box)
-                "source_hash": os.environ.get("PTMI_PROFILE_SOURCE_HASH") or graft.load_package()._build.source_hash()})
+                "bench_kernel_us_under_rocprof": round(bench["kernel_ms_under_rocprof"] * 1e3, 1),
+                # the id the PROFILED binary carried (its bench line printed ptmi_build_id()); else what tools/profile_round.sh recorded
+                "source_hash": (bench.get("binary_build_id") or os.environ.get("PTMI_PROFILE_SOURCE_HASH") or graft.load_package()._build.source_hash()).split("+")[0]})
     path = os.path.join(ROOT, "profiles", "%s_valu_roofline.json" % tag)
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
