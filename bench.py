@@ -434,7 +434,7 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
     stats = ctx.stats()
 
-    per_rank, render_only_ms = None, None
+    per_rank, render_only_ms, k_only = None, None, 0
     if world > 1:
         # what every rank did in the timed region, so that a scaling record explains itself: the slowest rank sets the step (MAX below),
         # imbalance = slowest rank's kernel time / the mean says how much of a missing speed-up is the stripes' doing
@@ -492,7 +492,7 @@ def main():
                 whole.set_scene(spheres, planes)
                 whole.resize(width, height)
                 whole.init_output(SEED0)
-                for _ in range(args.warmup + args.steps):
+                for _ in range(args.warmup + args.steps + k_only):      # every render since the last init_output, the render-only steps included
                     whole.render(cam, BOUNCE_LIMIT, spp, algorithm)
                 want = whole.download_color()
             got = final.cpu().numpy()

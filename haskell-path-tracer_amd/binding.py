@@ -122,12 +122,13 @@ def open_library(path, check_build_id=True):
     return lib
 
 
-def load_library(path=None):
-    """The default library of the process: libptmi.so (building nothing: see _build.build_lib), or `path` from then on."""
+def load_library(path=None, check_build_id=True):
+    """The default library of the process: libptmi.so (building nothing: see _build.build_lib), or `path` from then on.
+    check_build_id=False only for tools that compare binaries of DIFFERENT sources on purpose (tools/ab.py prints each one's id)."""
     global _lib
     if _lib is not None and path is None:
         return _lib
-    _lib = open_library(path or _build.LIB)
+    _lib = open_library(path or _build.LIB, check_build_id)
     return _lib
 
 

@@ -53,12 +53,12 @@ def one(lib, names, width=1920, height=1080, spp=64, repeats=7):
     pkg = graft.load_package()
     if lib != "default":
         pkg.binding._lib = None
-        pkg.binding.load_library(lib)
+        pkg.binding.load_library(lib, check_build_id=False)   # an A/B partner is built from OTHER sources on purpose; its id is printed
     else:
         pkg._build.build_lib()
     B = pkg.binding
     cam = pkg.world.initial_camera()
-    out = {}
+    out = {"build_id": pkg.load_library().build_id}
     # (the first workload a process times is ~0.5 % slower than the same workload later -- clocks, cold allocations: it is run once unrecorded)
     for k, name in enumerate([names[0]] + list(names)):
         scene, alg, form, options, shape = WORKLOADS[name]

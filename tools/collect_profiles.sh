@@ -28,6 +28,7 @@ json.dump({"hbm_bytes_per_launch": round(rd + wr), "fetch_bytes_corrected": roun
            "workload": "C2"}, open("%s/profiles/traffic.json" % root, "w"), indent=1)
 PY
 cp "$SRC/c4_part.json" "$ROOT/profiles/${TAG}_c4_part.json"
+[ -s "$SRC/c5_part.json" ] && cp "$SRC/c5_part.json" "$ROOT/profiles/${TAG}_c5_part.json"
 cp "$SRC/extra.json" "$ROOT/profiles/${TAG}_extra_measurements.json"
 cp "$SRC/phase_stats.json" "$ROOT/profiles/${TAG}_phase_stats.json"
 echo "profiles/${TAG}_* written"

@@ -34,7 +34,8 @@ bash tools/pmc_kernels.sh c5_stream --scene glass --algorithm streams --streams-
 if [ -x build/valu_rates ]; then timeout -k 10 600 build/valu_rates 1 2 6 8 > "$OUT/valu_rates.json" 2> "$OUT/valu_rates.err"; echo "valu_rates rc=$?"; fi
 
 # 4. strong scaling bound on one GPU (C4 parts), side measurements, round occupancies
-timeout -k 10 400 python3 tools/c4_part.py > "$OUT/c4_part.json" 2> "$OUT/c4_part.log"; echo "c4_part rc=$?"
+timeout -k 10 400 python3 tools/part_bound.py --config c4 > "$OUT/c4_part.json" 2> "$OUT/c4_part.log"; echo "c4_part rc=$?"
+timeout -k 10 600 python3 tools/part_bound.py --config c5 > "$OUT/c5_part.json" 2> "$OUT/c5_part.log"; echo "c5_part rc=$?"
 timeout -k 10 400 python3 tools/measure_extra.py > "$OUT/extra.json" 2> "$OUT/extra.log"; echo "extra rc=$?"
 timeout -k 10 300 python3 tools/phase_stats.py > "$OUT/phase_stats.json" 2> "$OUT/phase_stats.log"; echo "phase rc=$?"
 # 5. the stream form: lane participation per block of the split kernel, the end of the pixels kernel's launch; the contracted-arithmetic report
