@@ -260,6 +260,11 @@ def main():
                          "e.g. C5 per part: --scene glass --algorithm streams --width 3840 --height 2160 --spp 512 --part-of 8")
     ap.add_argument("--streams-form", choices=["auto", "stream"], default="auto",
                     help="render Streams: per-pixel kernels (auto) or the stream ('wavefront') form")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="experiments only: ptmi_set_option before the first render, by the binding's name without OPT_ (e.g. STREAM_SHORT_PASSES=2); repeatable")
+    ap.add_argument("--library", default=None,
+                    help="experiments only: a differently-flagged build of libptmi made from THESE sources (a diagnostic build of tools/traffic_terms.py); "
+                         "the binding still refuses a library built from other sources")
     ap.add_argument("--ramp-spp", type=int, default=64,
                     help="samples per launch of the untimed clock ramp before the warm-up (capped at the workload's spp); 0 = the workload's "
                          "own spp, so that EVERY launch of the process is a launch of the workload -- what tools/pmc_kernels.sh passes: a "
@@ -302,6 +307,8 @@ def main():
 
     pkg = graft.load_package()
     pkg._build.build_lib()
+    if args.library:
+        pkg.binding.load_library(os.path.abspath(args.library))
     from haskell_path_tracer_amd.parallel import ColorGatherer, StripePartition
 
     spheres, planes = {"s16": pkg.world.scene16, "main": pkg.world.main_scene, "glass": pkg.world.glass_scene}[args.scene]()
@@ -339,6 +346,9 @@ def main():
     ctx.set_variant(args.variant)
     if args.streams_form == "stream":
         ctx.set_option(pkg.binding.OPT_STREAMS_FORM, pkg.binding.FORM_STREAM)
+    for item in args.option:
+        name, value = item.split("=")
+        ctx.set_option(getattr(pkg.binding, "OPT_" + name), int(value))
     ctx.init_output(SEED0)
 
     gather = ColorGatherer(part, width, color.dtype, color.device, dst=0) if world > 1 else None
@@ -552,7 +562,8 @@ def main():
                        "parallelism": "row stripes of %d rows over %d GPU(s)%s"
                                       % (args.stripe_rows, world, " + RCCL gather of colour planes" if world > 1 else ""),
                        "rows_per_gpu": ctx.local_rows, "variant": args.variant,
-                       "part_of": args.part_of if n_parts != world else None},
+                       "part_of": args.part_of if n_parts != world else None,
+                       "options": args.option or None},
             "live_bounce_fraction": round(live_total / (nominal_per_step * args.steps), 4) if args.algorithm == "inline" else None,
             "live_Mbounces_per_s": round(live_total / elapsed / 1e6, 1),
             "roofline": roofline,

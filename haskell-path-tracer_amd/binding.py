@@ -14,7 +14,7 @@ from . import _build
 from .world import CAMERA_DTYPE, PLANE_DTYPE, SPHERE_DTYPE, INLINE, STREAMS
 
 OPT_STREAMS_SEED_RULE, OPT_STREAM_STEP_CAP, OPT_STREAM_CAPACITY, OPT_STREAMS_FORM, OPT_STREAM_BATCH, OPT_SPP_CHUNKS, OPT_ARITHMETIC = 1, 2, 3, 4, 5, 6, 7
-OPT_STREAM_TAIL, OPT_ORDERED_PASSES, OPT_GLASS_BATCH, OPT_STREAM_GRADED, OPT_SNAPSHOT_BUDGET_MB = 8, 9, 10, 11, 12
+OPT_STREAM_TAIL, OPT_ORDERED_PASSES, OPT_GLASS_BATCH, OPT_STREAM_GRADED, OPT_SNAPSHOT_BUDGET_MB, OPT_STREAM_SHORT_PASSES = 8, 9, 10, 11, 12, 13
 ARITH_EXACT, ARITH_CONTRACTED = 0, 1
 SEED_KEEP_ACCUMULATOR, SEED_FROM_RESULT, SEED_AUTO = 0, 1, 2
 FORM_AUTO, FORM_STREAM = 0, 1
@@ -86,6 +86,7 @@ SYMBOLS = {
     "ptmi_debug_counters_n": (C.c_int, [_vp, _vp, C.c_int]),
     "ptmi_order_schedule": (C.c_int, [C.c_int, C.c_int, _i32p, _i32p]),
     "ptmi_stream_schedule": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, _vp, C.c_int]),
+    "ptmi_stream_tickets": (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int]),
     "ptmi_eval_distance_to_sphere": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "ptmi_eval_distance_to_plane": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "ptmi_eval_sincos": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
@@ -139,6 +140,19 @@ def stream_schedule(n_spp, n_pixels, lanes, batch=0, graded=True):
     if passes < 0:
         raise PtmiError(passes, "ptmi_stream_schedule")
     return [int(v) for v in first[:passes + 1]]
+
+
+def stream_tickets(option, first, queue_regions):
+    """ptmi_stream_tickets: [(pass, region index within the queue)] in the order one ticket queue of the split kernel hands them out, for
+    the schedule `first` of stream_schedule."""
+    passes = len(first) - 1
+    n = passes * queue_regions
+    f = np.asarray(first, np.int32)
+    p, r = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    got = load_library().ptmi_stream_tickets(int(option), _ptr(f), passes, int(queue_regions), _ptr(p), _ptr(r), n)
+    if got < 0:
+        raise PtmiError(got, "ptmi_stream_tickets")
+    return list(zip(p[:got].tolist(), r[:got].tolist()))
 
 
 def _ptr(a):

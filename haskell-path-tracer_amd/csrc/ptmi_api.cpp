@@ -121,6 +121,7 @@ struct ptmi_ctx {
     int opt_glass_batch = 0;                   // PTMI_OPT_GLASS_BATCH: 0 = automatic, 1 = off, k = GLASS hits wait until k are pending in their wave
     int opt_graded = 1;                        // PTMI_OPT_STREAM_GRADED: the split kernel's passes shrink towards the end of the launch
     int opt_snapshot_mb = 0;                   // PTMI_OPT_SNAPSHOT_BUDGET_MB: 0 = an eighth of the device's memory
+    int opt_short_passes = 0;                  // PTMI_OPT_STREAM_SHORT_PASSES: 0 = automatic, 1 = off, k = the last k passes are handed out region by region
 };
 
 namespace {
@@ -339,6 +340,41 @@ int stream_schedule(int n_spp, unsigned long long n_px, unsigned long long lanes
     return passes;
 }
 
+// In which order the split kernel hands out its tickets (ItemArgs.group_first; PTMI_OPT_STREAM_SHORT_PASSES).  Pass by pass -- every region of the
+// start-hit list in pass 0, then every region in pass 1 ... -- a region's 64-byte records, its snapshots' lines and the colour lines of its pixels
+// come from HBM once per PASS: 1 482 MB of fetches per 1080p / 64-spp call of the glass scene (six passes), against 190 MB of records.  In GROUPS
+// of consecutive passes, each group region by region, the items of a start hit that belong to one group are taken within microseconds of each
+// other from one ticket queue by waves behind one L2, and only the first reads HBM (tools/traffic_terms.py, profiles/r05_traffic_terms.json:
+// 1 482 -> 959 MB in pairs, 757 in threes, 546 as one group, the launch's time within +- 0.5 %).  What a group must not do is undo the GRADING:
+// as ONE group the launch ends with the cheapest regions' items of EVERY pass, the long ones included -- with few regions per wave (a C5 part:
+// 2.6 per pass) that is + 2 % and a quarter more spilled children.  Hence, automatically: a group is a run of passes of EQUAL size (16, 16, 16 | 8 |
+// 4, 4 at 1080p / 64 spp; 74 x 5 | 50 | 32 | 21 | 14 | 9 | 6, 6 | 4 on a C5 part) -- within it every item is as long as every other, so the order
+// of its tickets cannot lengthen the end of the launch.
+// option 0 = automatic, 1 = every pass on its own, k in [2, 64] = the last k passes as one group, 100 + g = groups of g passes all the way (what
+// does not divide goes first, pass by pass).  Returns the number of groups; table[0 .. groups] = the first pass of every group, and `passes`.
+int pass_group_table(int option, const int *first, int passes, int table[kMaxStreamPasses + 1])
+{
+    int groups = 0;
+    table[0] = 0;
+    auto close = [&](int next_first) { table[++groups] = next_first; };
+    if (passes < 2 || option == 1) {
+        for (int p = 1; p <= passes; ++p) close(p);
+    } else if (option == 0) {
+        for (int p = 1; p <= passes; ++p)
+            if (p == passes || first[p + 1] - first[p] != first[p] - first[p - 1]) close(p);
+    } else if (option >= 100) {
+        int g = option - 100 < passes ? option - 100 : passes;
+        if (g < 1) g = 1;
+        for (int p = 1; p <= passes % g; ++p) close(p);
+        for (int p = passes % g + g; p <= passes; p += g) close(p);
+    } else {
+        const int g = option < passes ? option : passes;
+        for (int p = 1; p <= passes - g; ++p) close(p);
+        close(passes);
+    }
+    return groups;
+}
+
 // `render Streams` as a stream ("wavefront" form, ptmi_stream_*.hip).  Every sample of a pixel shoots the same primary ray: its
 // hit is evaluated once per call into the start-hit list (regions in dispatch order), then ONE persistent launch renders all
 // samples of the call:
@@ -363,7 +399,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
         if (c->d_hit_counts) { (void)hipFree(c->d_hit_counts); c->d_hit_counts = nullptr; c->hit_regions = 0; }
         if (c->d_hit_missed) { (void)hipFree(c->d_hit_missed); c->d_hit_missed = nullptr; }
         c->hit_list_valid = false;
-        PTMI_HIP(c, hipMalloc(&c->hit_block, (size_t)kHitListWords * hit_slots * 4));
+        PTMI_HIP(c, hipMalloc(&c->hit_block, (size_t)(kHitListWords + 1) * hit_slots * 4));      // the records, and behind them one key word per slot
         c->hit_capacity = hit_slots;
         PTMI_HIP(c, hipMalloc(&c->d_hit_counts, (size_t)n_regions * sizeof(unsigned int)));
         PTMI_HIP(c, hipMalloc(&c->d_hit_missed, (size_t)n_regions * sizeof(unsigned long long)));
@@ -372,6 +408,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
     if (!c->d_qcount) PTMI_HIP(c, hipMalloc(&c->d_qcount, (size_t)kLvWords * sizeof(unsigned int)));
     HitList hits;
     hits.base = static_cast<uint32_t *>(c->hit_block);
+    hits.slot_key = hits.base + (size_t)kHitListWords * c->hit_capacity;
     hits.counts = c->d_hit_counts;
     hits.missed = c->d_hit_missed;
     hits.region_slots = region_slots;
@@ -396,7 +433,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
     ItemArgs it{};
     it.hits = hits;
     it.n_positions = n_regions / 4u;
-    it.passes = 1;
+    it.passes = 1; it.group_first = nullptr; it.groups = 0;
     it.n_slots = (unsigned int)hit_slots;
     it.stats = c->d_qcount;
     auto tickets_of = [&](int launch) { return c->d_qcount + (size_t)(kLvTickets + 8 * launch) * kCounterStride; };
@@ -422,7 +459,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
         const int most = n_spp / streams_min_pass_samples();   // a pass holds at least that many samples
         if (passes > most) passes = most;
         if (passes < 1) passes = 1;
-        it.passes = passes;
+        it.passes = passes;                                // (ordered passes wait for each other: every pass on its own, no group table)
         it.chunk_cursor = tickets_of(0);
         // THE TAIL.  A lane renders a pixel's whole sample chain, so the persistent launch ends as its last items do: its waves end between
         // 70 and 100 % of it.  The cheapest quads of the dispatch order -- the order kernel marks where they begin, on the device -- are
@@ -515,17 +552,23 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
     }
     std::vector<unsigned int> base((size_t)kLvMaxLevels, 0u);   // per level (mod kLvMaxLevels): where its reserved blocks start
 
-    {   // the pass table on the device: rewritten only when the schedule changes
-        const std::vector<int> table(first, first + passes + 1);
-        if (!c->d_pass_first) PTMI_HIP(c, hipMalloc(&c->d_pass_first, (size_t)(kMaxStreamPasses + 1) * sizeof(int)));
+    int group_table[kMaxStreamPasses + 1];
+    const int groups = pass_group_table(c->opt_short_passes, first, passes, group_table);
+    {   // the pass table and the group table on the device (one block: kMaxStreamPasses + 1 entries each): rewritten only when they change
+        std::vector<int> table(first, first + passes + 1);
+        table.resize((size_t)kMaxStreamPasses + 1, 0);
+        table.insert(table.end(), group_table, group_table + groups + 1);
+        if (!c->d_pass_first) PTMI_HIP(c, hipMalloc(&c->d_pass_first, 2 * (size_t)(kMaxStreamPasses + 1) * sizeof(int)));
         if (table != c->pass_first_host) {
-            PTMI_HIP(c, hipStreamSynchronize(c->stream));      // (an earlier launch may still be reading the old table)
+            PTMI_HIP(c, hipStreamSynchronize(c->stream));      // (an earlier launch may still be reading the old tables)
             PTMI_HIP(c, hipMemcpy(c->d_pass_first, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice));
             c->pass_first_host = table;
         }
     }
     PTMI_HIP(c, launch_streams_seeds(a.planes, hits, static_cast<uint4 *>(c->d_snapshots), (long long)n, passes, c->d_pass_first, n_spp, c->stream));
     it.passes = passes; it.pass_first = c->d_pass_first;
+    it.group_first = groups < passes ? c->d_pass_first + (kMaxStreamPasses + 1) : nullptr;     // (every pass on its own needs no table)
+    it.groups = groups;
     // GLASS hits wait in their lanes until that many are pending in the wave (measured: DESIGN.md 5.5); nothing to wait for without GLASS
     it.glass_batch = !c->has_glass ? 0 : (c->opt_glass_batch > 0 ? c->opt_glass_batch : kGlassBatchDefault);
     it.chunk_cursor = tickets_of(0);
@@ -972,6 +1015,25 @@ int ptmi_stream_schedule(int n_spp, uint64_t n_pixels, uint64_t lanes, int batch
     return passes;
 }
 
+int ptmi_stream_tickets(int option, const int32_t *first, int passes, int queue_regions, int32_t *pass_out, int32_t *region_out, int capacity)
+{
+    if (passes < 1 || passes > kMaxStreamPasses || queue_regions < 1 || !first || !pass_out || !region_out) return PTMI_EINVAL;
+    if (option < 0 || option > 164 || (option > 64 && option < 102)) return PTMI_EINVAL;
+    for (int p = 0; p < passes; ++p)
+        if (first[p + 1] <= first[p]) return PTMI_EINVAL;
+    int table[kMaxStreamPasses + 1], sizes[kMaxStreamPasses + 1];
+    for (int p = 0; p <= passes; ++p) sizes[p] = first[p];
+    const int groups = pass_group_table(option, sizes, passes, table);
+    const long long tickets = (long long)passes * queue_regions;
+    if (tickets > capacity) return PTMI_ELIMIT;
+    for (long long j = 0; j < tickets; ++j) {
+        unsigned int pass = 0, k = 0;
+        decode_ticket((unsigned int)j, (unsigned int)queue_regions, groups < passes ? table : nullptr, groups, pass, k);
+        pass_out[j] = (int32_t)pass; region_out[j] = (int32_t)k;
+    }
+    return (int)tickets;
+}
+
 int ptmi_set_option(ptmi_ctx *c, int option, int64_t value)
 {
     if (!c) return PTMI_EINVAL;
@@ -1013,6 +1075,9 @@ int ptmi_set_option(ptmi_ctx *c, int option, int64_t value)
     case PTMI_OPT_SNAPSHOT_BUDGET_MB:
         if (value < 0 || value > (1 << 20)) return fail(c, PTMI_EINVAL, "snapshot budget must be 0 (automatic) or megabytes in [1, 2^20]");
         c->opt_snapshot_mb = (int)value; return PTMI_OK;
+    case PTMI_OPT_STREAM_SHORT_PASSES:
+        if (value < 0 || value > 164 || (value > 64 && value < 102)) return fail(c, PTMI_EINVAL, "short passes must be 0 (automatic), 1 (none), k in [2, 64] or 100 + g, g in [2, 64]");
+        c->opt_short_passes = (int)value; return PTMI_OK;
     default: return fail(c, PTMI_EINVAL, "unknown option");
     }
 }
@@ -1034,6 +1099,7 @@ int ptmi_get_option(ptmi_ctx *c, int option, int64_t *value)
     case PTMI_OPT_ORDERED_PASSES: *value = c->opt_ordered_passes; return PTMI_OK;
     case PTMI_OPT_GLASS_BATCH: *value = c->opt_glass_batch; return PTMI_OK;
     case PTMI_OPT_STREAM_GRADED: *value = c->opt_graded; return PTMI_OK;
+    case PTMI_OPT_STREAM_SHORT_PASSES: *value = c->opt_short_passes; return PTMI_OK;
     case PTMI_OPT_SNAPSHOT_BUDGET_MB: *value = c->opt_snapshot_mb; return PTMI_OK;
     default: return fail(c, PTMI_EINVAL, "unknown option");
     }

@@ -171,6 +171,15 @@ struct TailProbe {
 #endif
 };
 
+// -DPTMI_TRAFFIC_SKIP=<bits>: MEASUREMENT builds of the split kernel that leave one source of its HBM traffic out, so that the bytes of
+// a launch can be attributed term by term (tools/traffic_terms.py; their planes are wrong on purpose): 1 = the item-end colour atomics,
+// 2 = the colour atomics of rays taken from the ring, 4 = the cost record of an item (quad_cost atomics).  0 in every other build: the
+// conditions fold away and the kernel is the kernel without them, instruction for instruction.
+#ifndef PTMI_TRAFFIC_SKIP
+#define PTMI_TRAFFIC_SKIP 0
+#endif
+constexpr unsigned int kTrafficSkip = PTMI_TRAFFIC_SKIP;
+
 // ---- streams_split_kernel, summed over the waves: [1] trips, [2] dead hits finished, [3] lanes free for a next ray, [4] ... that took
 // one from the ring, [5] ... that started a sample of their item, [6] ... whose item ended, [7] refill blocks run, [8] hits shaded,
 // [9] ... of which GLASS, [10] rays traced, [11] lanes holding an item, [12] sum and [14] maximum of the waves' durations (u64),

@@ -110,6 +110,8 @@ constexpr int kLvWords = (kLvTickets + 8 * kLvMaxLaunches) * kCounterStride;
 // throughput, the step index and the number of raw draws its ray's seed is ahead of the sample's: regions then have 128 slots.
 struct HitList {             // records of 16 words: [position xyz, normal x] [normal yz, direction xy] [direction z, throughput xyz] [primitive, local pixel index, meta, quad]
     uint32_t *base;
+    uint32_t *slot_key;      // per record slot: the record's pixel (30 bits) | the code of its raw draws (0, 3, 4 -> 0, 1, 2) << 30 -- all that
+                             // streams_slot_seeds_kernel needs of a record: 4 bytes per slot and call instead of the record's 64-byte line
     unsigned int *counts;    // records per region
     unsigned long long *missed;   // per region: the lanes (pixels of the tile) that have no start hit
     unsigned int region_slots;   // 64, or 128 when a primary hit can split
@@ -135,6 +137,10 @@ struct ItemArgs {
     unsigned int n_positions;       // groups of four regions (dispatch positions): hits.n_regions / 4
     const unsigned int *tail_start; // streams_pixels_kernel: a device word -- the positions from there on are left to the per-pixel kernel (NULL: none)
     int passes;                     // tickets run over the chunks this many times: a pixel's samples in that many items
+    const int *group_first;         // device, groups + 1 entries (NULL: every pass on its own): the passes are handed out in GROUPS of consecutive passes
+    int groups;                     // [group_first[g], group_first[g + 1]), a group region by region -- region r in every pass of the group, then region r + 1: a
+                                    // region's items of one group follow each other through one ticket queue, and all but the first find its records and
+                                    // colour lines in that XCD's L2 (decode_ticket).  A group of one pass is that pass, pass by pass as ever
     unsigned int *region_done;      // streams_pixels_kernel, passes > 1: per region, the items published so far (zero at launch)
     unsigned int *chunk_cursor;     // device: the launch's eight ticket counters, kCounterStride words apart, zero at launch
     // streams_split_kernel only
@@ -151,6 +157,24 @@ struct ItemArgs {
     unsigned int *stats;
     int may_emit;
 };
+
+// Ticket j of a queue of n regions -> (pass, the region's index k in the queue), j < n * passes.  Without a group table: pass by pass.  With one:
+// group g owns tickets [n group_first[g], n group_first[g + 1]) and hands them out region by region.  Host and device: the kernels' next_chunk and
+// ptmi_stream_tickets (the order as a pure function, tested without a GPU).  (The scan is wave-uniform scalar work, once per ticket -- an item is
+// hundreds to thousands of loop trips; a graded schedule has a handful of groups.)
+PTMI_HD void decode_ticket(unsigned int j, unsigned int n, const int *group_first, int groups, unsigned int &pass, unsigned int &k)
+{
+    if (!group_first) {
+        pass = j / n;
+        k = j - pass * n;
+        return;
+    }
+    int g = 0;
+    while (g + 1 < groups && j >= n * (unsigned int)group_first[g + 1]) ++g;
+    const unsigned int first = (unsigned int)group_first[g], size = (unsigned int)group_first[g + 1] - first, rem = j - n * first;
+    k = rem / size;
+    pass = first + (rem - k * size);
+}
 
 hipError_t launch_streams_pixels(const RenderArgs &a, const ItemArgs &it, unsigned int grid, hipStream_t stream);
 hipError_t launch_streams_split(const RenderArgs &a, const ItemArgs &it, unsigned int grid, hipStream_t stream);

@@ -138,8 +138,9 @@ __device__ __forceinline__ void next_chunk(ChunkCursor &c, const ItemArgs &it)
         if ((threadIdx.x & 63) == 0) j = atomicAdd(it.chunk_cursor + (size_t)q * kCounterStride, 1u);
         j = (unsigned int)__builtin_amdgcn_readfirstlane((int)j);
         if (n == 0u || j / n >= (unsigned int)it.passes) { ++c.tries; continue; }
-        c.pass = j / n;
-        const unsigned int k = j - c.pass * n, s_pos = k >> 2, r = k & 3u;
+        unsigned int k;
+        decode_ticket(j, n, it.group_first, it.groups, c.pass, k);
+        const unsigned int s_pos = k >> 2, r = k & 3u;
         c.region = (s_pos * 8u + q) * 4u + r;
         c.first = c.region * it.hits.region_slots;
         c.len = it.hits.counts[c.region];

@@ -79,7 +79,9 @@ __global__ void __launch_bounds__(256) streams_primary_kernel(const RenderArgs a
             r[0] = float4{p.x, p.y, p.z, n.x};
             r[1] = float4{n.y, n.z, dd.x, dd.y};
             r[2] = float4{dd.z, tt.x, tt.y, tt.z};
-            r[3] = float4{u2f((uint32_t)(e == 0 ? prim[0] : prim[1])), u2f((uint32_t)pixel), u2f(e == 0 ? meta[0] : meta[1]), u2f(quad)};
+            const uint32_t mt = e == 0 ? meta[0] : meta[1], draws = mt >> 8;                  // 0, or 3 / 4 for the children of a glass primary hit
+            r[3] = float4{u2f((uint32_t)(e == 0 ? prim[0] : prim[1])), u2f((uint32_t)pixel), u2f(mt), u2f(quad)};
+            out.slot_key[i] = (uint32_t)pixel | ((draws ? draws - 2u : 0u) << 30);            // (the stream form holds < 2^30 pixels)
         }
     }
 }
@@ -112,8 +114,8 @@ __global__ void __launch_bounds__(kBlock) streams_slot_seeds_kernel(Planes p, Hi
     if (slot >= n_slots) return;
     const unsigned int region = slot / hits.region_slots;
     if (slot - region * hits.region_slots >= hits.counts[region]) return;
-    const uint32_t *rec = hits.base + (size_t)slot * kHitListWords;
-    const uint32_t pixel = rec[13], draws = rec[14] >> 8;
+    // (the slot's key word, not its record: rec[13] and rec[14] cost the record's 64-byte line -- 190 MB per 1080p call of the glass scene)
+    const uint32_t key = hits.slot_key[slot], pixel = key & 0x3fffffffu, code = key >> 30, draws = code ? code + 2u : 0u;
     Sfc32 s; s.a = p.sa[pixel]; s.b = p.sb[pixel]; s.c = p.sc[pixel]; s.counter = p.sctr[pixel];
     int done = 0;
     for (int k = 0; k < passes; ++k) {

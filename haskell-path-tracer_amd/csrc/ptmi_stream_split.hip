@@ -87,6 +87,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
     // computeResult + permute (+) (Trace.hs:179-184, :318-323); adding an exact zero changes nothing
     auto add_colour = [&](V3 c) __attribute__((always_inline)) {
         if (foreign) {
+            if (diag::kTrafficSkip & 2u) return;
             if (c.x != 0.0f) atomicAdd(&plane_at(a.planes.r, pixel << 2), c.x);
             if (c.y != 0.0f) atomicAdd(&plane_at(a.planes.g, pixel << 2), c.y);
             if (c.z != 0.0f) atomicAdd(&plane_at(a.planes.b, pixel << 2), c.z);
@@ -128,7 +129,10 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                 put(6, r1.z); put(7, r1.w); put(8, r2.x); put(9, r2.y); put(10, r2.z); put(11, r2.w);
                 put(12, u2f(f2u(r3.x) | ((f2u(r3.z) & 1u) << 10) | (f2u(r3.w) << 11))); put(13, r3.y);
                 put(14, u2f(s0.a)); put(15, u2f(s0.b)); put(16, u2f(s0.c)); put(17, u2f(s0.counter));
-                item_trips = 0;
+                // an item's cost (its loop trips) is recorded for later launches' dispatch order by the items of pass 0 ONLY -- the bit above the
+                // trip count says "do not record".  One atomic per item was 14.6 M atomics per 1080p call on 8 100 words that all eight XCDs
+                // share: 565 MB of the split kernel's 688 MB of HBM writes (tools/traffic_terms.py, round 5); the longest pass ranks the quads as well.
+                item_trips = cur.pass == 0u ? 0u : 0x80000000u;
                 samples_left = it.pass_first[cur.pass + 1u] - it.pass_first[cur.pass];      // the samples of this pass (ItemArgs.pass_first)
                 busy = true;
             }
@@ -204,11 +208,13 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                 pending = true; foreign = false;              // (a start hit of a dead ray -- a reflection of weight ~0 -- waits for the next trip's first block)
             } else {
                 const uint32_t px = f2u(get(13));
-                if (own_acc.x != 0.0f) atomicAdd(&plane_at(a.planes.r, px << 2), own_acc.x);
-                if (own_acc.y != 0.0f) atomicAdd(&plane_at(a.planes.g, px << 2), own_acc.y);
-                if (own_acc.z != 0.0f) atomicAdd(&plane_at(a.planes.b, px << 2), own_acc.z);
+                if (!(diag::kTrafficSkip & 1u)) {
+                    if (own_acc.x != 0.0f) atomicAdd(&plane_at(a.planes.r, px << 2), own_acc.x);
+                    if (own_acc.y != 0.0f) atomicAdd(&plane_at(a.planes.g, px << 2), own_acc.y);
+                    if (own_acc.z != 0.0f) atomicAdd(&plane_at(a.planes.b, px << 2), own_acc.z);
+                }
                 own_acc = mk(0.0f, 0.0f, 0.0f);
-                if (TILES) record_item_cost(a, f2u(get(12)) >> 11, item_trips);     // (the quad travels with the start hit: no division here, where two lanes of 64 are active)
+                if (TILES && !(item_trips >> 31) && !(diag::kTrafficSkip & 4u)) record_item_cost(a, f2u(get(12)) >> 11, item_trips);     // (the quad travels with the start hit: no division here, where two lanes of 64 are active)
                 busy = false;
             }
         }

@@ -148,7 +148,7 @@ int ptmi_set_timing(ptmi_ctx *ctx, int enabled);
 /* Kernel variant selection for measurements: 0 = default.  See DESIGN.md "kernel variants". */
 int ptmi_set_variant(ptmi_ctx *ctx, int variant);
 
-/* Options.  1-5 and 8-12 concern `render Streams` (src/Scene/Trace.hs:141-191) and never change `render Inline`; 6 is a
+/* Options.  1-5 and 8-13 concern `render Streams` (src/Scene/Trace.hs:141-191) and never change `render Inline`; 6 is a
  * scheduling knob of the per-pixel kernels that changes no result; 7 is a labelled measurement mode of `render Inline`. */
 enum {
     /* Which seed a pixel carries out of `combine` (Trace.hs:179-184): the combination function keeps the seed of its
@@ -197,7 +197,7 @@ enum {
      * the oracle's (the RNG planes still are: integer arithmetic); DESIGN.md reports how far they are and what the literal
      * reading -- every operation rounded on its own, PTMI_ARITH_EXACT -- costs.  Variants and Streams ignore it. */
     PTMI_OPT_ARITHMETIC = 7,
-    /* 8-12: scheduling knobs of the stream form of Streams.  None changes a ray, a seed or (without GLASS) a bit of the planes.
+    /* 8-13: scheduling knobs of the stream form of Streams.  None changes a ray, a seed or (without GLASS) a bit of the planes.
      *
      * PTMI_OPT_STREAM_TAIL: scenes without GLASS, one-pass launches: the cheapest quads of the dispatch order -- the cheapest classes
      * that together hold at most this many THOUSANDTHS of the recorded cost -- are rendered by the per-pixel chain kernel on a
@@ -227,7 +227,16 @@ enum {
      * would need more, its LAST passes are merged (longer items at the end of the launch; no seed and no ray changes), and a call whose
      * single pass still does not fit fails with PTMI_ELIMIT.  0 (default) = an eighth of the device's memory; otherwise megabytes
      * in [1, 2^20]. */
-    PTMI_OPT_SNAPSHOT_BUDGET_MB = 12
+    PTMI_OPT_SNAPSHOT_BUDGET_MB = 12,
+    /* PTMI_OPT_STREAM_SHORT_PASSES: in which order the split kernel hands out its items.  Pass by pass -- every region of the start-hit list in pass
+     * 0, then every region in pass 1 ... -- a region's 64-byte records and the colour lines of its pixels come from HBM once per pass.  In GROUPS of
+     * consecutive passes, each group region by region (region r in every pass of the group, then region r + 1), the items of a start hit that belong
+     * to one group are taken within microseconds of each other from one ticket queue, by waves behind one L2, and only the first of them reads HBM.
+     * Changes no ray and no seed, only which lane renders which item when.  0 (default) = automatic: a group is a run of passes of EQUAL size (16,
+     * 16, 16 | 8 | 4, 4 at 1080p / 64 spp) -- the grading of the passes, which keeps the end of the launch short, is then untouched; 1 = every pass on
+     * its own (round 4); k in [2, 64] = the LAST k passes as one group; 100 + g (g in [2, 64]) = groups of g passes all the way.
+     * ptmi_stream_tickets is the order as a pure function. */
+    PTMI_OPT_STREAM_SHORT_PASSES = 13
 };
 enum { PTMI_ARITH_EXACT = 0, PTMI_ARITH_CONTRACTED = 1 };
 enum { PTMI_SEED_KEEP_ACCUMULATOR = 0, PTMI_SEED_FROM_RESULT = 1, PTMI_SEED_AUTO = 2 };
@@ -242,6 +251,11 @@ int ptmi_stream_schedule(int n_spp, uint64_t n_pixels, uint64_t lanes, int batch
  * shape, limit, algorithm), does the next launch rebuild the order from the recorded costs (before launch 1, 2, 4, 8, ...; never once
  * the recording limit -- 2^20 launches, 2^11 for the stream form -- is reached) and does it record its costs?  Returns the state after it. */
 int ptmi_order_schedule(int launches, int stream_form, int *rebuild, int *record);
+/* The order in which ONE of the eight ticket queues of the split kernel hands out its passes x queue_regions items under
+ * PTMI_OPT_STREAM_SHORT_PASSES = option, for the schedule first[0 .. passes] of ptmi_stream_schedule: ticket j is (pass_out[j], region_out[j]),
+ * region = the region's index within the queue.  Every (pass, region) pair appears exactly once.  Pure host arithmetic.  Returns the number of
+ * tickets, PTMI_ELIMIT if `capacity` entries do not hold them. */
+int ptmi_stream_tickets(int option, const int32_t *first, int passes, int queue_regions, int32_t *pass_out, int32_t *region_out, int capacity);
 int ptmi_get_option(ptmi_ctx *ctx, int option, int64_t *value);
 
 /* ---- state: initialOutput / genSeeds / reseed -------------------------------- */

@@ -246,6 +246,30 @@ def test_the_split_kernels_scheduling_knobs_change_no_ray_and_no_seed(ctx, pkg, 
         assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) <= REL_TOL
 
 
+@pytest.mark.parametrize("order", [1, 2, 3, 102, 104, 164])
+def test_the_ticket_order_changes_no_ray_and_no_seed(ctx, pkg, ora, order):
+    """PTMI_OPT_STREAM_SHORT_PASSES: pass by pass (1), the last two or three passes as one group, pairs, groups of four behind two passes
+    in pass order, everything region by region (164) -- six graded passes of 3, 2, 2, 2, 2, 2 samples at this size.  Every item is handed out
+    exactly once whatever the order: counts and RNG planes equal the oracle's, colours within the tolerance of the undefined order of additions."""
+    B = pkg.binding
+    scene = pkg.world.glass_scene()
+    cam = pkg.world.initial_camera()
+    w, h, spp = 128, 72, 13
+    start = initial_planes(ora, w, h)
+    ctx.set_option(B.OPT_STREAM_SHORT_PASSES, order)
+    try:
+        assert ctx.get_option(B.OPT_STREAM_SHORT_PASSES) == order
+        got, st = render(ctx, pkg, scene, cam, w, h, spp, start, stream_form=True)
+    finally:
+        ctx.set_option(B.OPT_STREAM_SHORT_PASSES, 0)
+    want, live, dropped, steps = ora.render_streams_wavefront(scene[0], scene[1], cam, w, h, CAP, spp, start)
+    for a, b in zip(got[3:], want[3:]):
+        assert np.array_equal(a, b)
+    assert st["live_bounces"] == live and st["stream_rays_dropped"] == dropped == 0 and st["stream_iterations"] == steps
+    for a, b in zip(got[:3], want[:3]):
+        assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) <= REL_TOL
+
+
 def test_a_small_snapshot_budget_merges_the_last_passes_and_changes_no_ray(ctx, pkg, ora):
     """PTMI_OPT_SNAPSHOT_BUDGET_MB: the seed snapshots are passes x record slots x 16 bytes (here 144 regions x 128 slots: 295 KB per pass, six
     graded passes of 3, 2, 2, 2, 2, 2 samples); a budget of 1 MB holds three, so the last four passes run as one -- same rays, same seeds, same
@@ -278,11 +302,13 @@ def test_a_small_snapshot_budget_merges_the_last_passes_and_changes_no_ray(ctx, 
 def test_options_of_the_stream_form_are_range_checked_and_visible(pkg):
     B = pkg.binding
     with pkg.Context(0) as c:
-        defaults = {B.OPT_STREAM_TAIL: -1, B.OPT_ORDERED_PASSES: 0, B.OPT_GLASS_BATCH: 0, B.OPT_STREAM_GRADED: 1, B.OPT_SNAPSHOT_BUDGET_MB: 0}
+        defaults = {B.OPT_STREAM_TAIL: -1, B.OPT_ORDERED_PASSES: 0, B.OPT_GLASS_BATCH: 0, B.OPT_STREAM_GRADED: 1, B.OPT_SNAPSHOT_BUDGET_MB: 0,
+                    B.OPT_STREAM_SHORT_PASSES: 0}
         for opt, value in defaults.items():
             assert c.get_option(opt) == value
         for opt, bad in ((B.OPT_STREAM_TAIL, -2), (B.OPT_STREAM_TAIL, 1001), (B.OPT_ORDERED_PASSES, -1), (B.OPT_ORDERED_PASSES, 65),
-                         (B.OPT_GLASS_BATCH, 65), (B.OPT_STREAM_GRADED, 2), (B.OPT_SNAPSHOT_BUDGET_MB, -1), (B.OPT_SNAPSHOT_BUDGET_MB, (1 << 20) + 1)):
+                         (B.OPT_GLASS_BATCH, 65), (B.OPT_STREAM_GRADED, 2), (B.OPT_SNAPSHOT_BUDGET_MB, -1), (B.OPT_SNAPSHOT_BUDGET_MB, (1 << 20) + 1),
+                         (B.OPT_STREAM_SHORT_PASSES, -1), (B.OPT_STREAM_SHORT_PASSES, 65), (B.OPT_STREAM_SHORT_PASSES, 101), (B.OPT_STREAM_SHORT_PASSES, 165)):
             with pytest.raises(pkg.PtmiError) as e:
                 c.set_option(opt, bad)
             assert e.value.code == B.PTMI_EINVAL

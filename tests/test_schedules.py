@@ -67,3 +67,47 @@ def test_the_dispatch_order_is_rebuilt_before_launch_1_2_4_8_and_never_after_the
     for state in (limit, limit + 1, 1 << 30, -5):                      # at and beyond the limit (and nonsense): nothing happens any more
         nxt = lib.ptmi_order_schedule(state, stream_form, C.byref(rebuild), C.byref(record))
         assert (rebuild.value, record.value, nxt) == (0, 0, limit)
+
+
+def test_every_ticket_order_hands_out_every_item_exactly_once(pkg):
+    """PTMI_OPT_STREAM_SHORT_PASSES (ptmi_stream_tickets): whatever the option and the schedule, the tickets of a queue are a permutation of
+    {passes} x {the queue's regions} -- no item twice, none missing."""
+    T, S = pkg.binding.stream_tickets, pkg.binding.stream_schedule
+    schedules = [S(64, 1920 * 1080, LANES), S(512, 3840 * 270, LANES), S(64, 1920 * 1080, LANES, graded=False), S(13, 128 * 72, LANES), S(1, 10, LANES),
+                 S(4096, 1920 * 1080, LANES, 1), list(range(65))]
+    for first in schedules:
+        passes = len(first) - 1
+        for regions in (1, 4, 12, 100):
+            for option in (0, 1, 2, 3, 5, 64, 102, 103, 104, 106, 113, 164):
+                got = T(option, first, regions)
+                assert len(got) == passes * regions
+                assert sorted(got) == [(p, r) for p in range(passes) for r in range(regions)], (first, regions, option)
+
+
+def test_the_ticket_orders_by_name(pkg):
+    T, S = pkg.binding.stream_tickets, pkg.binding.stream_schedule
+    first = S(64, 1920 * 1080, LANES)                            # 16, 16, 16, 8, 4, 4
+    by_pass = [(p, r) for p in range(6) for r in range(4)]
+    by_region = [(p, r) for r in range(4) for p in range(6)]
+    assert T(1, first, 4) == by_pass
+    assert T(164, first, 4) == by_region == T(106, first, 4)
+    # automatic: runs of passes of equal size -- (16, 16, 16) region by region, 8 on its own, (4, 4) region by region
+    assert T(0, first, 4) == [(p, r) for r in range(4) for p in (0, 1, 2)] + [(3, r) for r in range(4)] + [(p, r) for r in range(4) for p in (4, 5)]
+    assert T(0, S(64, 1920 * 1080, LANES, graded=False), 4) == [(p, r) for r in range(4) for p in range(4)]      # uniform passes: one group
+    c5 = S(512, 3840 * 270, LANES)                               # 74 x 5, 50, 32, 21, 14, 9, 6, 6, 4
+    auto = T(0, c5, 2)
+    assert auto[:10] == [(p, r) for r in range(2) for p in range(5)] and auto[10:12] == [(5, 0), (5, 1)]
+    assert auto[-6:] == [(10, 0), (11, 0), (10, 1), (11, 1), (12, 0), (12, 1)]
+    # the last two passes as one group behind four passes in pass order
+    assert T(2, first, 4) == [(p, r) for p in range(4) for r in range(4)] + [(p, r) for r in range(4) for p in (4, 5)]
+    # pairs all the way: (0, 1) (2, 3) (4, 5), each pair region by region; seven passes: the odd one first, on its own
+    assert T(102, first, 4) == [(p, r) for g in range(3) for r in range(4) for p in (2 * g, 2 * g + 1)]
+    seven = list(range(8))
+    assert T(102, seven, 4)[:4] == [(0, r) for r in range(4)] and T(102, seven, 4)[4:6] == [(1, 0), (2, 0)]
+    lib = pkg.load_library()
+    buf = (C.c_int32 * 8)()
+    f = (C.c_int32 * 7)(*first)
+    assert lib.ptmi_stream_tickets(0, f, 6, 4, buf, buf, 8) == pkg.binding.PTMI_ELIMIT
+    assert lib.ptmi_stream_tickets(65, f, 6, 4, buf, buf, 8) == pkg.binding.PTMI_EINVAL
+    assert lib.ptmi_stream_tickets(0, f, 0, 4, buf, buf, 8) == pkg.binding.PTMI_EINVAL
+    assert lib.ptmi_stream_tickets(0, None, 6, 4, buf, buf, 8) == pkg.binding.PTMI_EINVAL
