@@ -48,6 +48,7 @@ def test_a_faithful_dump_passes_every_assumption(tool, tmp_path):
     assert [len(dump["sections"][k]) for k in ("words", "created", "probe_states", "probe_words", "probe_floats", "inline_1", "streams_2")] == [3, 4, 4, 4, 4, 7, 7]
     report = tool.analyse(dump, use_device=False)
     assert report["all_pass"] and report["first_failure"] is None, report["assumptions"]
+    assert report["arithmetic"] is None                       # (which arithmetic the dump is closer to is asked on a GPU box only)
     assert report["assumptions"]["A3"]["plane_order_in_toVectors"] == ["a", "b", "c", "counter"]
     for tag in ("inline", "streams_from_result"):
         for k in ("after_1", "after_2"):
@@ -118,3 +119,23 @@ def test_the_comparator_drives_libptmi_on_the_dumps_inputs(tool, tmp_path):
     assert report["all_pass"]
     for tag in ("inline", "streams_from_result", "streams_keep_accumulator"):
         assert report["renders"][tag].get("device_equals_oracle") is True, report["renders"][tag]
+    # ... and asks which arithmetic the dump's is: a dump made by the oracle is identical to libptmi's exact arithmetic and not to the contracted one
+    ar = report["arithmetic"]
+    assert ar["closer_to_the_dump"] == "exact" and ar["identical_to_the_dump"] == ["exact"]
+    assert ar["contracted"]["after_2"]["colour_bit_identical"] < 1.0 and ar["contracted"]["after_2"]["colour_within_1e-4"] > 0.99
+
+
+@pytest.mark.gpu
+def test_a_dump_from_a_contracting_backend_is_recognised_as_such(tool, tmp_path):
+    """--perturb A6: the Inline planes as a backend that fuses a * b + c would have written them (libptmi's PTMI_ARITH_CONTRACTED, the only
+    contracted evaluation this repository has).  The generator checks pass, A6 / A7 fail as "rounding only", and the arithmetic question says
+    `contracted` -- the answer about A6 that only a real dump can give."""
+    path = str(tmp_path / "contracted.bin")
+    tool.synthesize(path, 800, 600, "A6")
+    report = tool.analyse(tool.read_dump(path), use_device=True)
+    A = report["assumptions"]
+    assert all(A[k]["status"] == "pass" for k in ("A1", "A2", "A3", "A4", "A5"))
+    assert report["first_failure"] == "A6" and "rounding only" in A["A6"]["detail"]
+    ar = report["arithmetic"]
+    assert ar["closer_to_the_dump"] == "contracted" and ar["identical_to_the_dump"] == ["contracted"]
+    assert ar["exact"]["after_2"]["colour_within_1e-4"] > 0.99

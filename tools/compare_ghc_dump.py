@@ -15,8 +15,13 @@ for each of the named assumptions the restatement rests on, whether the dump bea
     A6  every f32 operation rounded on its own  }                      inline_1 / inline_2 against the oracle: bit-identical, or the
     A7  sin / cos = glibc's sinf / cosf         }                      fraction of pixels within 1e-4 and with an identical RNG state
 
-Nothing here runs the reference.  `--synthesize OUT [--perturb A1|A2|A3|A4|A5] [--size WxH]` writes a dump in the same format FROM
-THE ORACLE (optionally with one assumption deliberately broken): what tests/test_ghc_dump.py feeds back in."""
+On a GPU box it asks one question more, the one about A6 only a real dump can answer: libptmi renders the dump's inputs in BOTH arithmetics
+-- PTMI_ARITH_EXACT (every operation rounded on its own: the oracle's reading, the default) and PTMI_ARITH_CONTRACTED (a * b + c fused, what
+Accelerate's fast-math LLVM backends may do on an FMA host) -- and the report says which one the dump is closer to (`arithmetic`).
+
+Nothing here runs the reference.  `--synthesize OUT [--perturb A1|A2|A3|A4|A5|A6] [--size WxH]` writes a dump in the same format FROM
+THE ORACLE (optionally with one assumption deliberately broken; A6: the Inline planes from libptmi's contracted arithmetic, which needs the
+GPU): what tests/test_ghc_dump.py feeds back in."""
 import argparse
 import itertools
 import json
@@ -164,8 +169,8 @@ def oracle_steps(pkg, ora, width, height, limit, start, algorithm, seed_rule=Non
     return outs
 
 
-def device_steps(pkg, width, height, limit, start, algorithm, seed_rule=None):
-    """the same through libptmi (None when no GPU or library is present)"""
+def device_steps(pkg, width, height, limit, start, algorithm, seed_rule=None, arithmetic=None):
+    """the same through libptmi (None when no GPU or library is present); arithmetic: PTMI_OPT_ARITHMETIC for render Inline"""
     try:
         import torch
         if not torch.cuda.is_available():
@@ -177,6 +182,8 @@ def device_steps(pkg, width, height, limit, start, algorithm, seed_rule=None):
             c.resize(width, height)
             if seed_rule is not None:
                 c.set_option(B.OPT_STREAMS_SEED_RULE, seed_rule)
+            if arithmetic is not None:
+                c.set_option(B.OPT_ARITHMETIC, arithmetic)
             c.upload_state(*start)
             outs = []
             for _ in range(2):
@@ -185,6 +192,36 @@ def device_steps(pkg, width, height, limit, start, algorithm, seed_rule=None):
         return outs
     except Exception as e:        # noqa: BLE001 -- a report must still come out
         return "device path failed: %s" % e
+
+
+def arithmetic_question(pkg, W, H, limit, start, dump_planes):
+    """render Inline of the dump's inputs through libptmi under PTMI_ARITH_EXACT and PTMI_ARITH_CONTRACTED, each against the dump's inline_1 /
+    inline_2: {"exact": {...}, "contracted": {...}, "closer_to_the_dump": "exact" | "contracted" | "neither"}, or None without a GPU.  Closer =
+    more pixels with an identical RNG state (a branch that went the same way), then more bit-identical colours, then more within 1e-4 -- after
+    the last sample the dump holds."""
+    B = pkg.binding
+    out = {}
+    for name, mode in (("exact", B.ARITH_EXACT), ("contracted", B.ARITH_CONTRACTED)):
+        dev = device_steps(pkg, W, H, limit, start, "inline", arithmetic=mode)
+        if dev is None:
+            return None
+        if isinstance(dev, str):
+            return {"error": dev}
+        out[name] = {}
+        for k in (1, 2):
+            got = dump_planes("inline_%d" % k)
+            out[name]["after_%d" % k] = None if got is None else compare_planes(got, dev[k - 1], W)
+
+    def score(entry):
+        m = entry.get("after_2") or entry.get("after_1")
+        return None if m is None else (m["rng_state_identical"], m["colour_bit_identical"], m["colour_within_1e-4"])
+    se, sc = score(out["exact"]), score(out["contracted"])
+    if se is None or sc is None:
+        out["closer_to_the_dump"] = None
+    else:
+        out["closer_to_the_dump"] = "exact" if se > sc else ("contracted" if sc > se else "neither")
+        out["identical_to_the_dump"] = [n for n, sco in (("exact", se), ("contracted", sc)) if sco == (1.0, 1.0, 1.0)]
+    return out
 
 
 def as_state(planes4, perm, shape):
@@ -317,6 +354,8 @@ def analyse(dump, use_device=True):
                     elif dev is not None:
                         entry["device_equals_oracle"] = all(compare_planes(d, o, W)["first_differing_pixel_y_x"] is None for d, o in zip(dev, want))
                 report["renders"][tag] = entry
+        # ---- which arithmetic is the dump's?  (GPU only: the contracted build exists on the device alone)
+        report["arithmetic"] = arithmetic_question(pkg, W, H, limit, start, dump_planes) if use_device else None
         inl = report["renders"]["inline"]
         upstream = all(A[k]["status"] == "pass" for k in ("A1", "A2", "A4"))
         if inl["after_1"] is None:
@@ -372,6 +411,10 @@ def synthesize(path, width, height, perturb=None):
     start = [np.zeros((height, width), np.float32) for _ in range(3)] + [p.reshape(height, width) for p in created]
     streams_rule = ora.SEED_KEEP_ACCUMULATOR if perturb == "A5" else ora.SEED_FROM_RESULT
     inline = oracle_steps(pkg, ora, width, height, LIMIT, start, "inline")
+    if perturb == "A6":                                      # the Inline planes as a contracting backend would have produced them (libptmi's measurement mode: GPU)
+        inline = device_steps(pkg, width, height, LIMIT, start, "inline", arithmetic=pkg.binding.ARITH_CONTRACTED)
+        if inline is None or isinstance(inline, str):
+            raise SystemExit("--perturb A6 needs a GPU (the contracted arithmetic exists on the device only): %s" % inline)
     streams = oracle_steps(pkg, ora, width, height, LIMIT, start, "streams", streams_rule)
 
     def seven(planes):
@@ -388,7 +431,7 @@ def main():
     ap.add_argument("--json")
     ap.add_argument("--no-device", action="store_true")
     ap.add_argument("--synthesize", metavar="OUT")
-    ap.add_argument("--perturb", choices=["A1", "A2", "A3", "A4", "A5"])
+    ap.add_argument("--perturb", choices=["A1", "A2", "A3", "A4", "A5", "A6"])
     ap.add_argument("--size", default="96x64")
     args = ap.parse_args()
     if args.synthesize:
@@ -410,6 +453,16 @@ def main():
                     tag, k, m["colour_bit_identical"], m["colour_within_1e-4"], m["rng_state_identical"], m["first_differing_pixel_y_x"]))
         if "device_equals_oracle" in entry:
             print("   %-26s libptmi == oracle on these inputs: %s" % (tag, entry["device_equals_oracle"]))
+    ar = report.get("arithmetic")
+    if ar and "closer_to_the_dump" in ar:
+        for name in ("exact", "contracted"):
+            m = ar[name].get("after_2") or ar[name].get("after_1")
+            if m:
+                print("   libptmi, %-10s arithmetic against the dump's render Inline: colour bit-identical %.6f  within 1e-4 %.6f  RNG state identical %.6f" % (
+                    name, m["colour_bit_identical"], m["colour_within_1e-4"], m["rng_state_identical"]))
+        print("   the dump's arithmetic is closer to: %s%s" % (ar["closer_to_the_dump"], (" (identical to: %s)" % ", ".join(ar["identical_to_the_dump"])) if ar.get("identical_to_the_dump") else ""))
+    elif ar is None:
+        print("   (no GPU here: which arithmetic -- exact or contracted -- the dump is closer to is asked on a GPU box only)")
     print("first failure:", report["first_failure"], "| all pass:", report["all_pass"])
     if args.json:
         json.dump(report, open(args.json, "w"), indent=1)
