@@ -35,6 +35,7 @@ module Scene.HIP
   ( Handle
   , initialise
   , handleSize
+  , libraryBuildId
   -- * resident wiring
   , resetOutput
   , renderResident
@@ -88,11 +89,17 @@ data Handle = Handle { handleCtx :: !(ForeignPtr PtmiCtx), handleWidth :: !Int, 
 handleSize :: Handle -> (Int, Int)
 handleSize h = (handleWidth h, handleHeight h)
 
+-- | What the loaded libptmi was built from (ptmi_build_id: the hash of its kernel sources, headers and flags): print it next to
+-- any timing, so that a number can be tied to a binary.
+libraryBuildId :: IO String
+libraryBuildId = c_build_id >>= peekCString
+
 data PtmiError = PtmiError Int String deriving Show
 instance Exception PtmiError
 
 -- Calls that run for milliseconds to seconds are `safe`, so that the graphics and input threads keep running
 -- (app/Main.hs:178-180).  An address import takes no safety annotation.
+foreign import ccall unsafe "ptmi.h ptmi_build_id" c_build_id    :: IO CString
 foreign import ccall safe "ptmi.h ptmi_create"      c_create      :: Ptr (Ptr PtmiCtx) -> CInt -> IO CInt
 foreign import ccall      "ptmi.h &ptmi_destroy"    p_destroy     :: FunPtr (Ptr PtmiCtx -> IO ())
 foreign import ccall safe "ptmi.h ptmi_last_error"  c_last_error  :: Ptr PtmiCtx -> IO CString

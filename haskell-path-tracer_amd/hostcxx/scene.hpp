@@ -112,6 +112,7 @@ public:
         check(ptmi_resize(raw, width_, height_));
     }
     ptmi_ctx *get() const { return ctx_.get(); }
+    static std::string buildId() { return ptmi_build_id(); }      // what the loaded libptmi was built from: print it next to any timing
     int width() const { return width_; }
     int height() const { return height_; }
     void check(int rc) const { if (rc != PTMI_OK) throw PtmiError(rc, ptmi_last_error(ctx_.get())); }

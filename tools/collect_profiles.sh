@@ -1,7 +1,7 @@
 #!/bin/bash
 # collect_profiles.sh TAG -- after tools/profile_round.sh ran on the GPU box: summarise and copy into profiles/ (tracked).
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/gpurun_out/prof_$TAG
 cp "$SRC/bench.json" "$ROOT/profiles/${TAG}_bench.json"
@@ -36,5 +36,6 @@ for w in streams s16_stream; do [ -d "$ROOT/gpurun_out/pmcx_$w" ] && python3 "$R
 [ -s "$SRC/ab_options.txt" ] && cp "$SRC/ab_options.txt" "$ROOT/profiles/${TAG}_ab_options.txt"
 for f in split_stats tail_stats tail_phases; do [ -s "$SRC/$f.json" ] && cp "$SRC/$f.json" "$ROOT/profiles/${TAG}_$f.json"; done
 [ -s "$SRC/contracted.json" ] && cp "$SRC/contracted.json" "$ROOT/profiles/${TAG}_contracted_arithmetic.json"
+[ -s "$SRC/traffic_terms.json" ] && cp "$SRC/traffic_terms.json" "$ROOT/profiles/${TAG}_traffic_terms.json"
 for f in tree_stats; do [ -s "$SRC/$f.json" ] && cp "$SRC/$f.json" "$ROOT/profiles/${TAG}_$f.json"; done
 true

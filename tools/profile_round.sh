@@ -1,15 +1,18 @@
 #!/bin/bash
 # profile_round.sh -- the measurement pass behind profiles/<tag>_* (run ON the GPU box, from the repo root):
-#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/profile_round.sh r04'
-# then, back in the container:  bash tools/collect_profiles.sh r04   (copies the summaries into profiles/).
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/profile_round.sh r05'
+# then, back in the container:  bash tools/collect_profiles.sh r05   (copies the summaries into profiles/).
 # Counters are collected in their own passes (rocprofv3 --pmc with --kernel-trace only), the program itself after `--`.
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
+PART=${2:-all}    # all | a (bench lines, kernel traces, PMC passes: ~10 min) | b (rates, part bounds, statistics builds, traffic terms: ~10 min) -- two gpurun calls of <= 1200 s
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
-rm -rf "$OUT"; mkdir -p "$OUT"   # (locally, delete gpurun_out/pmc_* and gpurun_out/prof_<tag> of earlier runs first: gpurun MERGES what comes back into what is there)
+if [ "$PART" != "b" ]; then rm -rf "$OUT"; fi
+mkdir -p "$OUT"   # (locally, delete gpurun_out/pmc_* and gpurun_out/prof_<tag> of earlier runs first: gpurun MERGES what comes back into what is there)
 cd /tmp; export TMPDIR=/tmp; cd "$ROOT"
 
+if [ "$PART" != "b" ]; then
 # 0. what this profile is a profile OF: the hash of kernel sources, headers and flags (bench.py says `stale` when they have moved on)
 python3 -c "import __graft_entry__ as g; print(g.load_package()._build.source_hash())" > "$OUT/source_hash.txt"
 # 1. the bench line as the driver runs it (N = 1, defaults), cpu_baseline included; C4 on one GPU (the N > 1 workload)
@@ -30,6 +33,8 @@ bash tools/pmc_kernels.sh s16_stream --algorithm streams --streams-form stream >
 bash tools/pmc_kernels.sh c5_tree --scene glass --algorithm streams --width 3840 --height 2160 --spp 512 --part-of 8 > "$OUT/pmc_c5_tree.log" 2>&1; echo "pmc c5 tree rc=$?"
 bash tools/pmc_kernels.sh c5_stream --scene glass --algorithm streams --streams-form stream --width 3840 --height 2160 --spp 512 --part-of 8 > "$OUT/pmc_c5_stream.log" 2>&1; echo "pmc c5 stream rc=$?"
 
+fi
+if [ "$PART" != "a" ]; then
 # 3. per-opcode VALU issue costs (shader-clock domain) -- with 2. the inputs of tools/valu_roofline.py
 if [ -x build/valu_rates ]; then timeout -k 10 600 build/valu_rates 1 2 6 8 > "$OUT/valu_rates.json" 2> "$OUT/valu_rates.err"; echo "valu_rates rc=$?"; fi
 
@@ -48,4 +53,7 @@ timeout -k 10 300 python3 tools/tail_stats.py phases > "$OUT/tail_phases.json" 2
 bash tools/pmc_extra.sh streams --algorithm streams > "$OUT/pmcx_streams.log" 2>&1; echo "pmcx streams rc=$?"
 bash tools/pmc_extra.sh s16_stream --algorithm streams --streams-form stream > "$OUT/pmcx_s16_stream.log" 2>&1; echo "pmcx s16 stream rc=$?"
 timeout -k 10 300 python3 tools/contracted_report.py > "$OUT/contracted.json" 2> "$OUT/contracted.log"; echo "contracted rc=$?"
-echo "all done: $OUT"
+# 7. where the split kernel's HBM bytes go, term by term (product, ticket orders, measurement builds that leave one source out)
+timeout -k 10 900 python3 tools/traffic_terms.py --out "$ROOT/gpurun_out/traffic_terms_$TAG" --variants product,pass_by_pass,one_group,uniform_4x16,skip_item_atomics,skip_ring_atomics,skip_item_costs > "$OUT/traffic_terms.json" 2> "$OUT/traffic_terms.log"; echo "traffic terms rc=$?"
+fi
+echo "all done ($PART): $OUT"

@@ -12,8 +12,10 @@ against the product, which are the terms:
 
     product - skip_item_atomics      what the three colour atomics at every item's end cost in fetches and write-backs
     product - skip_ring_atomics      ... and the atomics of rays taken from the ring
-    (uniform_4x16 against graded 6)  what a pass costs: every start hit's 64-byte record and 16-byte snapshot read once more, three more atomics
-    short_2 / short_3                PTMI_OPT_STREAM_SHORT_PASSES: the last passes handed out region by region (their records found in the L2)
+    product - skip_item_costs        ... and the cost record of an item (one atomic on a word all XCDs share; pass 0's items only since round 5)
+    pass_by_pass - product           what the ticket order saves: PTMI_OPT_STREAM_SHORT_PASSES = 1 is round 4's order, every region's records from HBM once per pass
+    one_group, groups_of_2 / 3, short_2 / 3    other ticket orders
+    uniform_4x16                     four passes instead of six: what a pass costs
 """
 import argparse
 import collections
@@ -31,7 +33,8 @@ import __graft_entry__ as graft  # noqa: E402
 DEFAULT_WORKLOAD = ["--scene", "glass", "--algorithm", "streams", "--streams-form", "stream"]
 # name -> (extra compile flags of a measurement build or None, bench options)
 VARIANTS = collections.OrderedDict([
-    ("product", (None, [])),
+    ("product", (None, [])),                                                     # tickets in groups of equal-size passes (automatic)
+    ("pass_by_pass", (None, ["--option", "STREAM_SHORT_PASSES=1"])),             # round 4's order
     ("short_2", (None, ["--option", "STREAM_SHORT_PASSES=2"])),
     ("short_3", (None, ["--option", "STREAM_SHORT_PASSES=3"])),
     ("groups_of_2", (None, ["--option", "STREAM_SHORT_PASSES=102"])),
