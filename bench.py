@@ -123,7 +123,7 @@ def valu_accounting(pkg, kernel_ms):
     changed since the profile was taken (source_hash); implied_clock_ghz = the shader clock this run's launch time implies
     for the same cycle count -- outside 2.1-2.5 GHz the profile no longer describes the binary."""
     d, name = None, None
-    for tag in ("r04", "r03", "r02"):
+    for tag in ("r05", "r04", "r03", "r02"):
         d = load_json("%s_valu_roofline.json" % tag)
         if d:
             name = "profiles/%s_valu_roofline.json" % tag
@@ -153,7 +153,7 @@ def valu_accounting(pkg, kernel_ms):
 def streams_rooflines(pkg):
     """{workload key: the VALU issue accounting of its kernel} from the newest profiles/rNN_valu_roofline_streams.json
     (tools/valu_roofline.py streams TAG: the accounting of `roofline.valu`, for the Streams kernels), with `stale` by the same hash rule."""
-    for tag in ("r04", "r03"):
+    for tag in ("r05", "r04", "r03"):
         d = load_json("%s_valu_roofline_streams.json" % tag)
         if d:
             now = pkg._build.source_hash()

@@ -70,7 +70,7 @@ def test_pmc_summary_reports_n_min_max_and_the_bench_lines_kernel_time(tmp_path)
     assert res.returncode == 0, res.stderr
     out = json.loads(res.stdout)
     split = out["streams_split_kernel<true, true>"]
-    assert (split["calls"], split["min_us"], split["max_us"], split["one_launch_size"]) == (5, 1000.0, 5000.0, False)
+    assert (split["calls"], split["min_us"], split["median_us"], split["max_us"], split["one_launch_size"]) == (5, 1000.0, 1000.0, 5000.0, False)
     assert split["avg_us"] == 2600.0 and split["valu_wave_instr_per_call"] == 100
     assert out["streams_slot_seeds_kernel(Planes)"]["one_launch_size"] is True
     assert out["_bench"] == {"workload": "synthetic", "ms_per_step_under_rocprof": 5.1, "kernel_ms_under_rocprof": 5.0, "steps": 2, "warmup": 0,

@@ -9,8 +9,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def load(name):
-    with open(os.path.join(ROOT, "profiles", name)) as f:
-        return json.load(f)
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except FileNotFoundError:
+        return None
 
 
 def thousands(x):
@@ -50,7 +53,7 @@ def main():
             if "{" in line:
                 ab.append(json.loads(line[line.index("{"):]))
     if ab:
-        keys = [k for k in ab[0] if not k.endswith("dropped")]
+        keys = [k for k in ab[0] if not k.endswith("dropped") and k != "build_id"]
         print("tools/ab.py, best of 7, the runs of the profile round: " + "; ".join("%s %s" % (k, " / ".join("%.2f" % run[k] for run in ab if k in run)) for k in keys))
         print()
     print("| kernel (workload) | VALU instr per call | issue fraction | active lanes of 64 | SIMD cycles per instr | HBM MB per call |")
@@ -61,15 +64,20 @@ def main():
     s = load("%s_valu_roofline_streams.json" % tag)
     for k, x in s.items():
         if isinstance(x, dict) and "kernel" in x:
-            per_call = "-" if k.startswith("c5") else "%.2f G" % (x["valu_wave_instr_per_launch"] / 1e9)
-            hbm = "-" if k.startswith("c5") else "%.0f" % x["hbm_MB_per_call"]
+            per_call = "%.2f G" % (x["valu_wave_instr_per_launch"] / 1e9)      # (since round 5 every profiled launch is the workload's: C5's too)
+            hbm = "%.0f" % x["hbm_MB_per_call"]
             print("| %s (%s) | %s | %.3f | **%.1f** | %.2f | %s |" % (x["kernel"].split(" +")[0], k, per_call, x["frac_in_profile"], 64 * x["active_lane_frac"],
                                                                    x["measured_simd_cycles_per_instr"], hbm))
     print()
     c = load("%s_c4_part.json" % tag)
     print("C4 on one GPU: whole image %.1f ms, slowest part of 8 %.2f ms, part / whole %.4f, predicted 8-GPU speedup %.2f" %
           (c["whole"]["best_ms"], c["best"]["slowest_part_ms"], c["best"]["per_part_over_whole"], c["best"]["predicted_speedup"]))
-    e = load("%s_split_ends.json" % tag)
+    c5 = load("%s_c5_part.json" % tag) or {}
+    for form, x in c5.get("forms", {}).items():
+        print("C5 on one GPU, %s: whole image %.1f ms; %s" % (form, x["whole"]["best_ms"], "; ".join(
+            "%s-row stripes: slowest part %.2f ms, imbalance %.3f, predicted 8-GPU speedup %.2f" % (s, y["slowest_part_chunks_0_ms"], y["imbalance_chunks_0"], y["predicted_speedup_8_gpus_chunks_0"])
+            for s, y in x["stripes"].items())))
+    e = load("%s_split_ends.json" % tag) or {}
     for k, x in e.items():
         print("split kernel's waves, %s passes: first ends at %.3f of the launch, mean %.3f (%.3f ms with the probe)" %
               (k, x["first_wave_ends_at_fraction_of_the_last"], x["mean_end_at_fraction_of_the_last"], x["render_ms"]))

@@ -3,8 +3,8 @@
 over all dispatches of the kernel, and what they imply (active lanes per VALU instruction, SIMD cycles per VALU
 instruction at the clock GRBM_GUI_ACTIVE implies, share of wave cycles spent waiting).  All figures are totals over the
 profiled run (ramp + warm-up + 4 timed steps of bench.py, every launch at the workload's own sample count: pmc_kernels.sh
-passes --ramp-spp 0); n / min / max of the dispatch durations say whether the mean is a mean of ONE launch size
-(`one_launch_size`: max <= 1.25 min; a profile that mixes sizes describes neither), and `_bench` carries the bench line's own
+passes --ramp-spp 0); n / min / median / max of the dispatch durations say whether the mean is a mean of ONE launch size
+(`one_launch_size`: nine dispatches in ten within 20 % of the median; a profile that mixes sizes describes neither), and `_bench` carries the bench line's own
 kernel time under the profiler, which tools/valu_roofline.py holds every entry against."""
 import collections
 import csv
@@ -24,7 +24,7 @@ def short(name):
 def main():
     src = sys.argv[1]
     calls, ns = collections.Counter(), collections.Counter()
-    lo, hi = {}, {}
+    lo, hi, every = {}, {}, collections.defaultdict(list)
     for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv")):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
@@ -32,6 +32,7 @@ def main():
             calls[k] += 1
             ns[k] += d
             lo[k], hi[k] = min(lo.get(k, d), d), max(hi.get(k, d), d)
+            every[k].append(d)
     counters = collections.defaultdict(collections.Counter)
     dispatches = collections.defaultdict(collections.Counter)
     for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
@@ -45,7 +46,9 @@ def main():
             continue
         c = counters.get(k, {})
         rec = {"calls": calls[k], "total_ms": round(ns[k] / 1e6, 3), "avg_us": round(ns[k] / calls[k] / 1e3, 2),
-               "min_us": round(lo[k] / 1e3, 2), "max_us": round(hi[k] / 1e3, 2), "one_launch_size": hi[k] <= 1.25 * lo[k],
+               "min_us": round(lo[k] / 1e3, 2), "max_us": round(hi[k] / 1e3, 2), "median_us": round(sorted(every[k])[len(every[k]) // 2] / 1e3, 2),
+               # one size = nine dispatches in ten within 20 % of the median (the first, cold launches of a process run up to 30 % longer)
+               "one_launch_size": sum(1 for d in every[k] if abs(d - sorted(every[k])[len(every[k]) // 2]) <= 0.2 * sorted(every[k])[len(every[k]) // 2]) >= 0.9 * len(every[k]),
                "share_of_gpu_time": round(ns[k] / sum(ns.values()), 4)}
         # a PMC pass may see a different number of dispatches than the trace pass (same command, same count expected)
         scale = {name: calls[k] / dispatches[k][name] for name in c if dispatches[k][name]}
