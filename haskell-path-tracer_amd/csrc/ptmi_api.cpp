@@ -272,15 +272,18 @@ RayQueue carve_queue(void *block, size_t capacity, int which)
 }
 
 // The schedule of the cost-ordered dispatch: `launches` = launches made so far with one (camera, scene, shape, limit, algorithm).
-// Every launch below the limit RECORDS its costs (the sums stay far from 2^32); the order is REBUILT from them before launch 1, 2, 4,
-// 8, ... -- and never again once the limit is reached: the state stops there, it is a power of two itself, and a rebuild bumps the
-// order's generation, which would make the stream form re-run its primary kernel on every later call of a standing camera.
+// The order is REBUILT from the recorded costs before launch 1, 2, 4, 8, ... -- and never again once the limit is reached: the state stops
+// there, it is a power of two itself, and a rebuild bumps the order's generation, which would make the stream form re-run its primary kernel
+// on every later call of a standing camera.  A launch RECORDS its costs only if the NEXT launch rebuilds -- launch 0, 1, 3, 7, 15, ... (the
+// sums stay far from 2^32) -- since round 5: a recorded cost is an atomic per wave, or per item in the stream form, on words that all XCDs share
+// (~ 40 bytes of write traffic each, tools/traffic_terms.py), and between two rebuilds nobody reads them; every rebuild still sees one more
+// launch than the one before it, and a standing camera's steady state records nothing.
 int order_schedule(int launches, int stream_form, int *rebuild, int *record)
 {
     const int limit = stream_form ? (1 << 11) : (1 << 20);
     const bool below = launches >= 0 && launches < limit;
     if (rebuild) *rebuild = (below && launches > 0 && (launches & (launches - 1)) == 0) ? 1 : 0;
-    if (record) *record = below ? 1 : 0;
+    if (record) *record = (below && launches + 1 < limit && ((launches + 1) & launches) == 0) ? 1 : 0;
     return below ? launches + 1 : limit;
 }
 
@@ -680,7 +683,7 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
         const int dims[8] = {width, height, rows_local, stripe_rows, n_parts, part, bounce_limit, stream_form ? 2 : algorithm};
         std::memcpy(key.dims, dims, sizeof dims);
         if (std::memcmp(&key, &c->order_key, sizeof key) != 0) { c->order_key = key; c->order_state = 0; ++c->order_generation; }
-        // order_state counts the launches made with this key.  Every launch adds its costs (a 1-spp launch says little
+        // order_state counts the launches made with this key.  The launches before a rebuild add their costs (a 1-spp launch says little
         // on its own: the compat entry renders one sample per call); the order is rebuilt before launch 1, 2, 4, 8, ...
         const int launches = c->order_state;
         int rebuild = 0, record = 0;
@@ -701,7 +704,8 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
             ++c->order_generation;
         }
         if (launches > 0) a.quad_order = c->d_quad_order;
-        if (record) { a.quad_cost = c->d_quad_cost; next_order_state = state_after; }
+        if (record) a.quad_cost = c->d_quad_cost;
+        next_order_state = state_after;                        // (every launch counts, whether or not it records)
     }
     if (per_pixel_kernel) {
         // one word per tile workgroup for the sample chunks of the tiled per-pixel kernels (ptmi_device.h: enter_sample_chunk)

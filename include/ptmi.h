@@ -251,7 +251,8 @@ int ptmi_set_option(ptmi_ctx *ctx, int option, int64_t value);
 int ptmi_stream_schedule(int n_spp, uint64_t n_pixels, uint64_t lanes, int batch, int graded, int32_t *first, int capacity);
 /* The schedule of the cost-ordered dispatch, host arithmetic: given the launches made so far with one (camera, scene,
  * shape, limit, algorithm), does the next launch rebuild the order from the recorded costs (before launch 1, 2, 4, 8, ...; never once
- * the recording limit -- 2^20 launches, 2^11 for the stream form -- is reached) and does it record its costs?  Returns the state after it. */
+ * the recording limit -- 2^20 launches, 2^11 for the stream form -- is reached) and does it record its costs (only if the launch after it
+ * rebuilds: launch 0, 1, 3, 7, 15, ...)?  Returns the state after it. */
 int ptmi_order_schedule(int launches, int stream_form, int *rebuild, int *record);
 /* The order in which ONE of the eight ticket queues of the split kernel hands out its passes x queue_regions items under
  * PTMI_OPT_STREAM_SHORT_PASSES = option, for the schedule first[0 .. passes] of ptmi_stream_schedule: ticket j is (pass_out[j], region_out[j]),
