@@ -71,6 +71,7 @@ def account(name, rec, ops8):
     return {
         "kernel": name,
         "n_simds": n_simds, "clock_ghz": round(clock_ghz, 4), "kernel_us_in_profile": kernel_us,
+        "dispatches_in_profile": {"n": calls, "min_us": rec.get("min_us"), "median_us": rec.get("median_us"), "max_us": rec.get("max_us")},
         "valu_wave_instr_per_launch": total,
         "mix_wave_instr_per_launch": {k: round(v) for k, v in sorted(mix.items())},
         "class_cost_cycles": NOMINAL,
