@@ -114,6 +114,9 @@ struct ptmi_ctx {
     int opt_seed_rule = PTMI_SEED_AUTO;              // resolved per scene: effective_seed_rule()
     int opt_step_cap = kStreamStepCapDefault;
     int opt_capacity = 4;
+    int grown_capacity = 0;                          // stream form with GLASS: rays per pixel the overflow streams have been GROWN to after a call would have dropped children (0: never)
+    void *colour_backup = nullptr;                   // ... the three colour planes as they were before the call's launch (the call is redone if children were dropped)
+    size_t colour_backup_bytes = 0;
     int opt_form = PTMI_FORM_AUTO;
     int opt_batch = 0;
     int opt_spp_chunks = 0;                    // 0 = automatic
@@ -297,6 +300,7 @@ int order_schedule(int launches, int stream_form, int *rebuild, int *record)
 // Which sample belongs to which pass changes no seed (snapshots) and no ray; only the order of a pixel's float additions,
 // which the stream form with GLASS does not define anyway.  Returns the number of passes (<= kMaxStreamPasses).
 constexpr int kMaxStreamPasses = 64;
+constexpr int kMaxStreamRaysPerPixel = 64;   // PTMI_OPT_STREAM_CAPACITY's upper end, and how far a call grows its overflow streams before it counts drops
 int stream_schedule(int n_spp, unsigned long long n_px, unsigned long long lanes, int batch, bool graded, int first[kMaxStreamPasses + 1])
 {
     first[0] = 0;
@@ -531,21 +535,26 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
         PTMI_HIP(c, hipMalloc(&c->d_snapshots, snap_bytes));
         c->snapshot_bytes = snap_bytes;
     }
-    // the overflow streams: rays per pixel (PTMI_OPT_STREAM_CAPACITY) x pixels, at least every wave's static block
+    // the overflow streams: rays per pixel (PTMI_OPT_STREAM_CAPACITY, or what an earlier call grew them to) x pixels, at least every wave's static block
     const unsigned int first_block = streams_first_block();
     const unsigned int level_grid_max = (unsigned int)(cus * 4 * 6);
-    size_t need = n * (size_t)c->opt_capacity;
     const size_t floor_slots = (size_t)(grid > level_grid_max ? grid : level_grid_max) * first_block + 256;
-    if (need < floor_slots) need = floor_slots;
-    if (need > 0xfffffff0ull) return fail(c, PTMI_ELIMIT, "image too large for the stream form of Streams");
-    if (need > c->queue_capacity) {
-        PTMI_HIP(c, hipStreamSynchronize(c->stream));
-        if (c->queue_block) { (void)hipFree(c->queue_block); c->queue_block = nullptr; c->queue_capacity = 0; }
-        PTMI_HIP(c, hipMalloc(&c->queue_block, 2 * (size_t)kRayQueueWords * need * 4));
-        c->queue_capacity = need;
-    }
-    const size_t capacity = c->queue_capacity;
-    const RayQueue q[2] = {carve_queue(c->queue_block, capacity, 0), carve_queue(c->queue_block, capacity, 1)};
+    int cap_rays = c->grown_capacity > c->opt_capacity ? c->grown_capacity : c->opt_capacity;
+    auto size_streams = [&](int rays_per_pixel) -> int {
+        size_t need = n * (size_t)rays_per_pixel;
+        if (need < floor_slots) need = floor_slots;
+        if (need > 0xfffffff0ull) return fail(c, PTMI_ELIMIT, "image too large for the stream form of Streams");
+        if (need > c->queue_capacity) {
+            PTMI_HIP(c, hipStreamSynchronize(c->stream));
+            if (c->queue_block) { (void)hipFree(c->queue_block); c->queue_block = nullptr; c->queue_capacity = 0; }
+            PTMI_HIP(c, hipMalloc(&c->queue_block, 2 * (size_t)kRayQueueWords * need * 4));
+            c->queue_capacity = need;
+        }
+        return PTMI_OK;
+    };
+    if (int rc = size_streams(cap_rays)) return rc;
+    size_t capacity = c->queue_capacity;
+    RayQueue q[2] = {carve_queue(c->queue_block, capacity, 0), carve_queue(c->queue_block, capacity, 1)};
     const size_t spill_records = (size_t)grid * streams_spill_records();
     if (spill_records > c->spill_capacity) {
         PTMI_HIP(c, hipStreamSynchronize(c->stream));
@@ -577,13 +586,10 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
     it.chunk_cursor = tickets_of(0);
     it.seed_snapshots = static_cast<const uint4 *>(c->d_snapshots);
     it.spill = carve_queue(c->spill_block, c->spill_capacity, 0);
-    it.out = q[0];
     it.out_count = c->d_qcount + cursor_of(0);
     it.out_base = grid * first_block;
     it.emitted = it.out_count + 2 * kCounterStride;
     it.may_emit = c->has_glass ? 1 : 0;
-    base[0] = it.out_base;
-    PTMI_HIP(c, launch_streams_split(a, it, grid, c->stream));
 
     std::vector<unsigned int> raw((size_t)kLvWords);
     auto emitted_of = [&](int level) {                        // children the level stored: the sum of its shards (read back into `raw`)
@@ -598,33 +604,84 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
         PTMI_HIP(c, hipStreamSynchronize(c->stream));
         return PTMI_OK;
     };
-    // stream_iterations lives in the per-pixel kernels' sharded counter: shard 0 carries this form's figure, copied on the device
-    PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, kItersBytes, c->stream));
-    if (int rc = read_counters(1)) return rc;
-    // `null state` (Trace.hs:166-170): the loop goes on while the last level left children in its overflow stream (a level
-    // cuts the rays the step cap forbids as it reads them, and counts them)
-    for (int level = 0; c->has_glass && emitted_of(level) > 0u;) {
-        c->rays_overflowed += emitted_of(level);
-        const size_t cursor = (size_t)raw[cursor_of(level)] + base[(size_t)(level % kLvMaxLevels)];
-        const size_t items = cursor < capacity ? cursor : capacity;
-        ++level;
-        LevelArgs lv{};
-        lv.in = q[(level + 1) & 1]; lv.out = q[level & 1];
-        lv.stats = c->d_qcount;
-        lv.in_count = c->d_qcount + cursor_of(level - 1);
-        lv.in_base = base[(size_t)((level - 1) % kLvMaxLevels)];
-        lv.out_count = c->d_qcount + cursor_of(level);
-        lv.emitted = lv.out_count + 2 * kCounterStride;
-        lv.may_emit = 1;
-        const size_t chunks = (items + 63) / 64;
-        const unsigned int lgrid = (unsigned int)(chunks < 1 ? 1 : (chunks > level_grid_max ? level_grid_max : chunks));
-        lv.out_base = lgrid * first_block;
-        base[(size_t)(level % kLvMaxLevels)] = lv.out_base;
-        // the counter words of this level: long idle when they come round again
-        PTMI_HIP(c, hipMemsetAsync(lv.out_count, 0, (size_t)kLvPerLevel * kCounterStride * sizeof(unsigned int), c->stream));
-        PTMI_HIP(c, launch_streams_level(a, lv, lgrid, c->stream));
-        if (int rc = read_counters(level + 1)) return rc;
+    // `expand` (Trace.hs:284-293) makes its vectors as long as the step needs; the overflow streams here have a capacity.  A call that WOULD drop
+    // children is therefore redone with longer streams: the three colour planes -- all a launch changes that the next attempt reads; the seeds moved
+    // before the launch, the snapshots stand -- are copied aside first (25 MB at 1080p: ~ 10 us in stream order), and when the counters say that
+    // children found no room the planes are put back, the streams doubled (up to kMaxStreamRaysPerPixel rays per pixel, or to what the device
+    // still has) and the launch and its levels run again.  The capacity a call reached is kept for later calls.  Only with GLASS: nothing else emits.
+    const size_t plane_bytes = n * sizeof(float);
+    if (c->has_glass) {
+        if (3 * plane_bytes > c->colour_backup_bytes) {
+            PTMI_HIP(c, hipStreamSynchronize(c->stream));
+            if (c->colour_backup) { (void)hipFree(c->colour_backup); c->colour_backup = nullptr; c->colour_backup_bytes = 0; }
+            PTMI_HIP(c, hipMalloc(&c->colour_backup, 3 * plane_bytes));
+            c->colour_backup_bytes = 3 * plane_bytes;
+        }
+        char *bk = static_cast<char *>(c->colour_backup);
+        PTMI_HIP(c, hipMemcpyAsync(bk, a.planes.r, plane_bytes, hipMemcpyDeviceToDevice, c->stream));
+        PTMI_HIP(c, hipMemcpyAsync(bk + plane_bytes, a.planes.g, plane_bytes, hipMemcpyDeviceToDevice, c->stream));
+        PTMI_HIP(c, hipMemcpyAsync(bk + 2 * plane_bytes, a.planes.b, plane_bytes, hipMemcpyDeviceToDevice, c->stream));
     }
+    unsigned long long overflowed = 0;
+    for (int attempt = 0;; ++attempt) {
+        it.out = q[0];
+        base[0] = it.out_base;
+        PTMI_HIP(c, launch_streams_split(a, it, grid, c->stream));
+        // stream_iterations lives in the per-pixel kernels' sharded counter: shard 0 carries this form's figure, copied on the device
+        if (attempt == 0) PTMI_HIP(c, hipMemsetAsync(c->d_iters, 0, kItersBytes, c->stream));
+        if (int rc = read_counters(1)) return rc;
+        overflowed = 0;
+        // `null state` (Trace.hs:166-170): the loop goes on while the last level left children in its overflow stream (a level
+        // cuts the rays the step cap forbids as it reads them, and counts them)
+        for (int level = 0; c->has_glass && emitted_of(level) > 0u;) {
+            overflowed += emitted_of(level);
+            const size_t cursor = (size_t)raw[cursor_of(level)] + base[(size_t)(level % kLvMaxLevels)];
+            const size_t items = cursor < capacity ? cursor : capacity;
+            ++level;
+            LevelArgs lv{};
+            lv.in = q[(level + 1) & 1]; lv.out = q[level & 1];
+            lv.stats = c->d_qcount;
+            lv.in_count = c->d_qcount + cursor_of(level - 1);
+            lv.in_base = base[(size_t)((level - 1) % kLvMaxLevels)];
+            lv.out_count = c->d_qcount + cursor_of(level);
+            lv.emitted = lv.out_count + 2 * kCounterStride;
+            lv.may_emit = 1;
+            const size_t chunks = (items + 63) / 64;
+            const unsigned int lgrid = (unsigned int)(chunks < 1 ? 1 : (chunks > level_grid_max ? level_grid_max : chunks));
+            lv.out_base = lgrid * first_block;
+            base[(size_t)(level % kLvMaxLevels)] = lv.out_base;
+            // the counter words of this level: long idle when they come round again
+            PTMI_HIP(c, hipMemsetAsync(lv.out_count, 0, (size_t)kLvPerLevel * kCounterStride * sizeof(unsigned int), c->stream));
+            PTMI_HIP(c, launch_streams_level(a, lv, lgrid, c->stream));
+            if (int rc = read_counters(level + 1)) return rc;
+        }
+        const unsigned int dropped = raw[(size_t)kLvDropped * kCounterStride];
+        if (!c->has_glass || dropped == 0u || cap_rays >= kMaxStreamRaysPerPixel) break;
+        // ---- children were dropped: longer streams, the planes put back, once more
+        const int grown = cap_rays * 2 < kMaxStreamRaysPerPixel ? cap_rays * 2 : kMaxStreamRaysPerPixel;
+        size_t need = n * (size_t)grown;
+        if (need < floor_slots) need = floor_slots;
+        if (need > 0xfffffff0ull) break;
+        if (need > c->queue_capacity) {
+            void *bigger = nullptr;
+            if (hipMalloc(&bigger, 2 * (size_t)kRayQueueWords * need * 4) != hipSuccess) { (void)hipGetLastError(); break; }    // the device has no more: the drops stand, counted
+            (void)hipFree(c->queue_block);                   // (the stream is idle: read_counters synchronised it)
+            c->queue_block = bigger; c->queue_capacity = need;
+        }
+        cap_rays = grown; c->grown_capacity = grown;
+        capacity = c->queue_capacity;
+        q[0] = carve_queue(c->queue_block, capacity, 0); q[1] = carve_queue(c->queue_block, capacity, 1);
+        char *bk = static_cast<char *>(c->colour_backup);
+        PTMI_HIP(c, hipMemcpyAsync(a.planes.r, bk, plane_bytes, hipMemcpyDeviceToDevice, c->stream));
+        PTMI_HIP(c, hipMemcpyAsync(a.planes.g, bk + plane_bytes, plane_bytes, hipMemcpyDeviceToDevice, c->stream));
+        PTMI_HIP(c, hipMemcpyAsync(a.planes.b, bk + 2 * plane_bytes, plane_bytes, hipMemcpyDeviceToDevice, c->stream));
+        // every counter of the call starts over -- but for the split pixels' count, which the primary kernel wrote and which is not run again
+        const unsigned int split_pixels = raw[(size_t)kLvSplitPixels * kCounterStride];
+        PTMI_HIP(c, hipMemsetAsync(c->d_qcount, 0, (size_t)kLvWords * sizeof(unsigned int), c->stream));
+        PTMI_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->d_qcount + (size_t)kLvSplitPixels * kCounterStride), (int)split_pixels, 1, c->stream));
+        std::fill(base.begin(), base.end(), 0u);
+    }
+    c->rays_overflowed += overflowed;
     for (int k = 0; k < kLvLiveShards; ++k) c->live_host += raw[(size_t)(kLvLive + k) * kCounterStride];
     // the two children of every glass primary hit whose split is cached in the start list: counted here, per sample
     if (!list_kept) c->hit_split_pixels = raw[(size_t)kLvSplitPixels * kCounterStride];
@@ -845,6 +902,7 @@ void ptmi_destroy(ptmi_ctx *c)
     if (c->d_stream_counters) (void)hipFree(c->d_stream_counters);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->queue_block) (void)hipFree(c->queue_block);
+    if (c->colour_backup) (void)hipFree(c->colour_backup);
     if (c->hit_block) (void)hipFree(c->hit_block);
     if (c->d_hit_counts) (void)hipFree(c->d_hit_counts);
     if (c->d_hit_missed) (void)hipFree(c->d_hit_missed);
@@ -1051,7 +1109,7 @@ int ptmi_set_option(ptmi_ctx *c, int option, int64_t value)
         c->opt_step_cap = (int)value; return PTMI_OK;
     case PTMI_OPT_STREAM_CAPACITY:
         if (value < 1 || value > 64) return fail(c, PTMI_EINVAL, "stream capacity must be in [1, 64] rays per pixel-sample");
-        c->opt_capacity = (int)value; return PTMI_OK;
+        c->opt_capacity = (int)value; c->grown_capacity = 0; return PTMI_OK;
     case PTMI_OPT_STREAMS_FORM:
         if (value != PTMI_FORM_AUTO && value != PTMI_FORM_STREAM) return fail(c, PTMI_EINVAL, "unknown Streams form");
         c->opt_form = (int)value; return PTMI_OK;
@@ -1094,7 +1152,7 @@ int ptmi_get_option(ptmi_ctx *c, int option, int64_t *value)
     switch (option) {
     case PTMI_OPT_STREAMS_SEED_RULE: *value = c->opt_seed_rule; return PTMI_OK;
     case PTMI_OPT_STREAM_STEP_CAP:   *value = c->opt_step_cap; return PTMI_OK;
-    case PTMI_OPT_STREAM_CAPACITY:   *value = c->opt_capacity; return PTMI_OK;
+    case PTMI_OPT_STREAM_CAPACITY:   *value = c->grown_capacity > c->opt_capacity ? c->grown_capacity : c->opt_capacity; return PTMI_OK;
     case PTMI_OPT_STREAMS_FORM:      *value = c->opt_form; return PTMI_OK;
     case PTMI_OPT_STREAM_BATCH:      *value = c->opt_batch; return PTMI_OK;
     case PTMI_OPT_SPP_CHUNKS: *value = c->opt_spp_chunks; return PTMI_OK;

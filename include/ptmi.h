@@ -94,7 +94,7 @@ typedef struct ptmi_stats {
     uint64_t samples;              /* pixels x samples                                                       */
     float    last_render_ms;       /* device time of the last ptmi_render launch(es); 0 unless timing is on */
     uint32_t stream_iterations;    /* Streams: the longest chain of traceSteps any ray lineage took (stream form: of the last sample) */
-    uint64_t stream_rays_dropped;  /* Streams with ray splitting: children that found no room (next stream / lane stack full) */
+    uint64_t stream_rays_dropped;  /* Streams with ray splitting: children that found no room -- tree walk: a lane's stack of 16 waiting children full; stream form: the overflow streams full even at 64 rays per pixel (below that the call is redone with longer streams) */
     uint64_t stream_rays_truncated;/* Streams: rays still alive when PTMI_OPT_STREAM_STEP_CAP cut their lineage (the reference has no cap) */
     uint64_t stream_rays_spilled;  /* Streams, stream form: children that found their wave's ring in LDS full and travelled through HBM (nothing is lost) */
     uint64_t stream_rays_overflowed; /* ... of which those that found the wave's spill queue full too and were traced by a later launch (an overflow level) */
@@ -170,10 +170,12 @@ enum {
      * bound (notFinished never stops a non-empty stream, Trace.hs:166-170); the default, 65536, only guarantees
      * termination, for both forms.  Rays it cuts are counted in ptmi_stats.stream_rays_truncated. */
     PTMI_OPT_STREAM_STEP_CAP = 2,
-    /* Stream form only: how many rays per pixel the overflow streams hold (default 4); children beyond are dropped and
-     * counted in ptmi_stats.stream_rays_dropped.  (Children wait in their wave's ring in LDS, then in its spill queue; the
-     * overflow streams are the last resort and practically unused: ptmi_stats.stream_rays_overflowed.)  The reference's vectors
-     * grow as needed. */
+    /* Stream form only: how many rays per pixel the overflow streams hold to begin with (default 4).  (Children wait in their wave's ring in
+     * LDS, then in its spill queue; the overflow streams are the last resort and practically unused: ptmi_stats.stream_rays_overflowed.)
+     * The reference's vectors grow as needed (expand, Trace.hs:284-293), and since 0.5 so do these: a call that WOULD drop children puts the
+     * colour planes back (they are copied aside before the launch), doubles the streams and runs again, up to 64 rays per pixel or what the
+     * device's memory allows; only beyond that are children dropped and counted in ptmi_stats.stream_rays_dropped.  ptmi_get_option returns
+     * the capacity in force (what the context has grown to); setting the option starts over from the value given. */
     PTMI_OPT_STREAM_CAPACITY = 3,
     /* PTMI_FORM_AUTO (default): the per-pixel kernels (one lane walks its pixel's rays; with GLASS: its ray trees).
      * PTMI_FORM_STREAM: the stream ("wavefront") form -- the start hits of the pixels as a compacted list, persistent waves whose

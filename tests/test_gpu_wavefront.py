@@ -150,6 +150,50 @@ def test_overflow_levels_with_tiny_rings(pkg, ora, tmp_path_factory):
             assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) <= REL_TOL
 
 
+def test_a_call_that_would_drop_children_is_redone_with_longer_streams(pkg, ora, tmp_path_factory):
+    """`expand` (Trace.hs:284-293) makes its vectors as long as the step needs.  The overflow streams have a capacity (PTMI_OPT_STREAM_CAPACITY
+    rays per pixel); a call that would DROP children puts the colour planes back, doubles the streams and runs again, until nothing is dropped
+    (or 64 rays per pixel / the device's memory are reached).  Forced here with a ring of 2 and a spill queue of 4 records per wave and ONE ray
+    per pixel of overflow stream: the first attempt drops thousands of children; the call still returns the oracle's rays, counts and seeds,
+    says stream_rays_dropped == 0, and the context keeps the capacity it grew to (visible through ptmi_get_option; a later call does not redo)."""
+    B = pkg.binding
+    out = os.path.join(str(tmp_path_factory.mktemp("tinyrings_grow")), "libptmi_tinyrings.so")
+    lib = B.open_library(pkg._build.build_lib(out=out, extra_flags=["-DPTMI_RING=2", "-DPTMI_SPILL=4"]))
+    scene = pkg.world.glass_scene()
+    cam = pkg.world.initial_camera()
+    w, h, spp = 800, 600, 4                                  # 480 000 pixels: more than the streams' floor (the waves' static blocks, 393 472 slots), so one ray per pixel IS the capacity
+    start = initial_planes(ora, w, h)
+    want, live, dropped, steps = ora.render_streams_wavefront(scene[0], scene[1], cam, w, h, CAP, spp, start, capacity_factor=64)
+    assert dropped == 0
+    with pkg.Context(0, library=lib) as c:
+        c.set_scene(*scene)
+        c.resize(w, h)
+        c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+        c.set_option(B.OPT_STREAM_CAPACITY, 1)
+        assert c.get_option(B.OPT_STREAM_CAPACITY) == 1
+        c.upload_state(*start)
+        c.render(cam, 15, spp, pkg.STREAMS)
+        got, st = c.download_state(), c.stats()
+        grown = c.get_option(B.OPT_STREAM_CAPACITY)
+        assert grown > 1, "one ray per pixel held every child of a tiny-ring build: the test no longer forces the growth"
+        for a, b in zip(got[3:], want[3:]):
+            assert np.array_equal(a, b)
+        assert st["live_bounces"] == live and st["stream_rays_dropped"] == 0 and st["stream_iterations"] == steps
+        for a, b in zip(got[:3], want[:3]):
+            assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) <= REL_TOL
+        # the same samples again from the same state: the grown streams hold them at the first attempt, the colour is not added twice
+        c.upload_state(*start)
+        c.reset_stats()
+        c.render(cam, 15, spp, pkg.STREAMS)
+        again, st2 = c.download_state(), c.stats()
+        assert c.get_option(B.OPT_STREAM_CAPACITY) == grown
+        assert st2["live_bounces"] == live and st2["stream_rays_dropped"] == 0
+        for a, b in zip(again[:3], want[:3]):
+            assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) <= REL_TOL
+        c.set_option(B.OPT_STREAM_CAPACITY, 2)                    # setting the option starts over from the value given
+        assert c.get_option(B.OPT_STREAM_CAPACITY) == 2
+
+
 @pytest.mark.parametrize("rule", ["auto", "keep"])
 def test_ordered_passes_inside_one_launch_are_bit_exact(ctx, pkg, ora, rule):
     """Without a ray-splitting material the stream form cuts a pixel's samples into ORDERED passes inside its one launch (a
