@@ -151,9 +151,9 @@ def _rows_through_the_glass_spheres(pkg, ora, rows, n=4):
     return [cand[k] for k in best]
 
 
-@pytest.mark.parametrize("form,part", [("tree_walk", 5), ("stream", 5), ("stream", 0), ("stream", 7), ("tree_walk", 0), ("tree_walk", 7)])
+@pytest.mark.parametrize("form,part", [(f, p) for p in range(8) for f in ("tree_walk", "stream")])
 def test_c5_glass_4k_512spp_one_part_of_8(pkg, ora, form, part):
-    """configs[4] at full size on three of its 8 parts: the glass scene (build-defined GLASS extension: no reference
+    """configs[4] at full size on EVERY one of its 8 parts (round 4: three of them): the glass scene (build-defined GLASS extension: no reference
     semantics, the repo's oracle is the definition), 3840x2160, 512 spp, `render Streams` -- through the per-pixel tree walk
     (the default with GLASS) and through the stream ("wavefront") form BASELINE.json names: start hits in regions, graded passes,
     child rings, spill queues.  No child ray may be dropped or cut, the RNG planes are exact (updateSeed: 512 draws per pixel), and
