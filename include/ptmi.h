@@ -36,7 +36,8 @@ extern "C" {
 #endif
 
 #define PTMI_VERSION 500   /* 0.5.0: ptmi_build_id; ptmi_debug_counters writes 64 words again (as in 0.3) and ptmi_debug_counters_n takes a
-                            * capacity; no option is read from the environment any more.  (0.4.0: options 8-12, ptmi_stream_schedule.) */
+                            * capacity; option 13 and ptmi_stream_tickets; the stream form's overflow streams grow instead of dropping children;
+                            * no option is read from the environment any more.  (0.4.0: options 8-12, ptmi_stream_schedule.) */
 
 /* ---- error codes ------------------------------------------------------------ */
 enum {
