@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "libptoracle.so")
+LIB = os.environ.get("PTMI_ORACLE_LIB") or os.path.join(HERE, "libptoracle.so")   # (the override: tests/test_oracle_sanitized.py loads an ASan / UBSan build)
 
 # independent declarations of the flat records (must equal the byte layout of pt_oracle.h)
 SPHERE_DTYPE = np.dtype([("position", "<f4", 3), ("radius", "<f4"), ("color", "<f4", 3),
@@ -64,6 +64,8 @@ def default_seed_rule(spheres, planes):
 
 
 def build(force=False):
+    if os.environ.get("PTMI_ORACLE_LIB"):
+        return LIB
     src = [os.path.join(HERE, f) for f in ("pt_oracle.c", "pt_oracle.h", "Makefile")]
     if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in src):
         subprocess.run(["make", "-s", "-C", HERE, "-f", os.path.join(HERE, "Makefile")], check=True)
