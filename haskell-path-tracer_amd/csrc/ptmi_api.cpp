@@ -279,7 +279,7 @@ RayQueue carve_queue(void *block, size_t capacity, int which)
 // there, it is a power of two itself, and a rebuild bumps the order's generation, which would make the stream form re-run its primary kernel
 // on every later call of a standing camera.  A launch RECORDS its costs only if the NEXT launch rebuilds -- launch 0, 1, 3, 7, 15, ... (the
 // sums stay far from 2^32) -- since round 5: a recorded cost is an atomic per wave, or per item in the stream form, on words that all XCDs share
-// (~ 40 bytes of write traffic each, tools/traffic_terms.py), and between two rebuilds nobody reads them; every rebuild still sees one more
+// (32 bytes of write traffic each, tools/traffic_terms.py), and between two rebuilds nobody reads them; every rebuild still sees one more
 // launch than the one before it, and a standing camera's steady state records nothing.
 int order_schedule(int launches, int stream_form, int *rebuild, int *record)
 {

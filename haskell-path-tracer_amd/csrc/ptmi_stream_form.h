@@ -102,8 +102,8 @@ __device__ __forceinline__ void queue_store(const RayQueue &q, unsigned int i, V
 // of four, one group per dispatch POSITION (the four tiles of a quad, most expensive quad first).  The positions are dealt to
 // eight queues, position p to queue p mod 8 -- one queue per XCD -- so that the tiles of a quad, whose pixels share cache lines
 // of the planes, are worked on behind ONE L2 (dealt to any XCD, every line of the planes was fetched four times).  A queue is a
-// ticket counter: ticket j stands for region (j mod n) of pass (j div n), n = the queue's regions, passes outermost and
-// positions in dispatch order.  A wave takes tickets -- one returning atomic each; an item is tens to thousands of loop trips
+// ticket counter: ticket j stands for a (pass, region) of the queue's n regions -- pass (j div n), region (j mod n), passes outermost, or,
+// with a group table, groups of passes outermost and each group region by region (decode_ticket, ptmi_kernels.h) -- positions in dispatch order.  A wave takes tickets -- one returning atomic each; an item is tens to thousands of loop trips
 // -- from the queue of the XCD it runs on (HW_REG_XCC_ID; which wave works on which chunk changes no result) and, when that one
 // is exhausted, from the other XCDs' queues.  Eight counters instead of one: a single word serves ~90 atomics per microsecond
 // and thousands of waves start together.  Regions without records (tiles whose primary rays all miss) are skipped.

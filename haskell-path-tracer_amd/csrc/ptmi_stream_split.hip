@@ -130,8 +130,8 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                 put(12, u2f(f2u(r3.x) | ((f2u(r3.z) & 1u) << 10) | (f2u(r3.w) << 11))); put(13, r3.y);
                 put(14, u2f(s0.a)); put(15, u2f(s0.b)); put(16, u2f(s0.c)); put(17, u2f(s0.counter));
                 // an item's cost (its loop trips) is recorded for later launches' dispatch order by the items of pass 0 ONLY -- the bit above the
-                // trip count says "do not record".  One atomic per item was 14.6 M atomics per 1080p call on 8 100 words that all eight XCDs
-                // share: 565 MB of the split kernel's 688 MB of HBM writes (tools/traffic_terms.py, round 5); the longest pass ranks the quads as well.
+                // trip count says "do not record".  One atomic per item was 17.8 M atomics per 1080p call on 8 100 words that all eight XCDs
+                // share: 577 MB of the split kernel's 688 MB of HBM writes (tools/traffic_terms.py, round 5); the longest pass ranks the quads as well.
                 item_trips = cur.pass == 0u ? 0u : 0x80000000u;
                 samples_left = it.pass_first[cur.pass + 1u] - it.pass_first[cur.pass];      // the samples of this pass (ItemArgs.pass_first)
                 busy = true;
