@@ -261,7 +261,7 @@ def main():
     ap.add_argument("--streams-form", choices=["auto", "stream"], default="auto",
                     help="render Streams: per-pixel kernels (auto) or the stream ('wavefront') form")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
-                    help="experiments only: ptmi_set_option before the first render, by the binding's name without OPT_ (e.g. STREAM_SHORT_PASSES=2); repeatable")
+                    help="experiments only: ptmi_set_option before the first render, by the binding's name without OPT_ (e.g. STREAM_PASS_GROUPS=2); repeatable")
     ap.add_argument("--library", default=None,
                     help="experiments only: a differently-flagged build of libptmi made from THESE sources (a diagnostic build of tools/traffic_terms.py); "
                          "the binding still refuses a library built from other sources")

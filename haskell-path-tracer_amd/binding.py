@@ -14,7 +14,7 @@ from . import _build
 from .world import CAMERA_DTYPE, PLANE_DTYPE, SPHERE_DTYPE, INLINE, STREAMS
 
 OPT_STREAMS_SEED_RULE, OPT_STREAM_STEP_CAP, OPT_STREAM_CAPACITY, OPT_STREAMS_FORM, OPT_STREAM_BATCH, OPT_SPP_CHUNKS, OPT_ARITHMETIC = 1, 2, 3, 4, 5, 6, 7
-OPT_STREAM_TAIL, OPT_ORDERED_PASSES, OPT_GLASS_BATCH, OPT_STREAM_GRADED, OPT_SNAPSHOT_BUDGET_MB, OPT_STREAM_SHORT_PASSES = 8, 9, 10, 11, 12, 13
+OPT_STREAM_TAIL, OPT_ORDERED_PASSES, OPT_GLASS_BATCH, OPT_STREAM_GRADED, OPT_SNAPSHOT_BUDGET_MB, OPT_STREAM_PASS_GROUPS = 8, 9, 10, 11, 12, 13
 ARITH_EXACT, ARITH_CONTRACTED = 0, 1
 SEED_KEEP_ACCUMULATOR, SEED_FROM_RESULT, SEED_AUTO = 0, 1, 2
 FORM_AUTO, FORM_STREAM = 0, 1

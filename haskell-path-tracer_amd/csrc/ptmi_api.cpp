@@ -124,7 +124,7 @@ struct ptmi_ctx {
     int opt_glass_batch = 0;                   // PTMI_OPT_GLASS_BATCH: 0 = automatic, 1 = off, k = GLASS hits wait until k are pending in their wave
     int opt_graded = 1;                        // PTMI_OPT_STREAM_GRADED: the split kernel's passes shrink towards the end of the launch
     int opt_snapshot_mb = 0;                   // PTMI_OPT_SNAPSHOT_BUDGET_MB: 0 = an eighth of the device's memory
-    int opt_short_passes = 0;                  // PTMI_OPT_STREAM_SHORT_PASSES: 0 = automatic, 1 = off, k = the last k passes are handed out region by region
+    int opt_pass_groups = 0;                  // PTMI_OPT_STREAM_PASS_GROUPS: 0 = automatic, 1 = off, k = the last k passes are handed out region by region
 };
 
 namespace {
@@ -347,7 +347,7 @@ int stream_schedule(int n_spp, unsigned long long n_px, unsigned long long lanes
     return passes;
 }
 
-// In which order the split kernel hands out its tickets (ItemArgs.group_first; PTMI_OPT_STREAM_SHORT_PASSES).  Pass by pass -- every region of the
+// In which order the split kernel hands out its tickets (ItemArgs.group_first; PTMI_OPT_STREAM_PASS_GROUPS).  Pass by pass -- every region of the
 // start-hit list in pass 0, then every region in pass 1 ... -- a region's 64-byte records, its snapshots' lines and the colour lines of its pixels
 // come from HBM once per PASS: 1 482 MB of fetches per 1080p / 64-spp call of the glass scene (six passes), against 190 MB of records.  In GROUPS
 // of consecutive passes, each group region by region, the items of a start hit that belong to one group are taken within microseconds of each
@@ -565,7 +565,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
     std::vector<unsigned int> base((size_t)kLvMaxLevels, 0u);   // per level (mod kLvMaxLevels): where its reserved blocks start
 
     int group_table[kMaxStreamPasses + 1];
-    const int groups = pass_group_table(c->opt_short_passes, first, passes, group_table);
+    const int groups = pass_group_table(c->opt_pass_groups, first, passes, group_table);
     {   // the pass table and the group table on the device (one block: kMaxStreamPasses + 1 entries each): rewritten only when they change
         std::vector<int> table(first, first + passes + 1);
         table.resize((size_t)kMaxStreamPasses + 1, 0);
@@ -1137,9 +1137,9 @@ int ptmi_set_option(ptmi_ctx *c, int option, int64_t value)
     case PTMI_OPT_SNAPSHOT_BUDGET_MB:
         if (value < 0 || value > (1 << 20)) return fail(c, PTMI_EINVAL, "snapshot budget must be 0 (automatic) or megabytes in [1, 2^20]");
         c->opt_snapshot_mb = (int)value; return PTMI_OK;
-    case PTMI_OPT_STREAM_SHORT_PASSES:
-        if (value < 0 || value > 164 || (value > 64 && value < 102)) return fail(c, PTMI_EINVAL, "short passes must be 0 (automatic), 1 (none), k in [2, 64] or 100 + g, g in [2, 64]");
-        c->opt_short_passes = (int)value; return PTMI_OK;
+    case PTMI_OPT_STREAM_PASS_GROUPS:
+        if (value < 0 || value > 164 || (value > 64 && value < 102)) return fail(c, PTMI_EINVAL, "pass groups must be 0 (automatic), 1 (every pass on its own), k in [2, 64] or 100 + g, g in [2, 64]");
+        c->opt_pass_groups = (int)value; return PTMI_OK;
     default: return fail(c, PTMI_EINVAL, "unknown option");
     }
 }
@@ -1161,7 +1161,7 @@ int ptmi_get_option(ptmi_ctx *c, int option, int64_t *value)
     case PTMI_OPT_ORDERED_PASSES: *value = c->opt_ordered_passes; return PTMI_OK;
     case PTMI_OPT_GLASS_BATCH: *value = c->opt_glass_batch; return PTMI_OK;
     case PTMI_OPT_STREAM_GRADED: *value = c->opt_graded; return PTMI_OK;
-    case PTMI_OPT_STREAM_SHORT_PASSES: *value = c->opt_short_passes; return PTMI_OK;
+    case PTMI_OPT_STREAM_PASS_GROUPS: *value = c->opt_pass_groups; return PTMI_OK;
     case PTMI_OPT_SNAPSHOT_BUDGET_MB: *value = c->opt_snapshot_mb; return PTMI_OK;
     default: return fail(c, PTMI_EINVAL, "unknown option");
     }

@@ -233,7 +233,7 @@ enum {
      * single pass still does not fit fails with PTMI_ELIMIT.  0 (default) = an eighth of the device's memory; otherwise megabytes
      * in [1, 2^20]. */
     PTMI_OPT_SNAPSHOT_BUDGET_MB = 12,
-    /* PTMI_OPT_STREAM_SHORT_PASSES: in which order the split kernel hands out its items.  Pass by pass -- every region of the start-hit list in pass
+    /* PTMI_OPT_STREAM_PASS_GROUPS: in which order the split kernel hands out its items.  Pass by pass -- every region of the start-hit list in pass
      * 0, then every region in pass 1 ... -- a region's 64-byte records and the colour lines of its pixels come from HBM once per pass.  In GROUPS of
      * consecutive passes, each group region by region (region r in every pass of the group, then region r + 1), the items of a start hit that belong
      * to one group are taken within microseconds of each other from one ticket queue, by waves behind one L2, and only the first of them reads HBM.
@@ -241,7 +241,7 @@ enum {
      * 16, 16 | 8 | 4, 4 at 1080p / 64 spp) -- the grading of the passes, which keeps the end of the launch short, is then untouched; 1 = every pass on
      * its own (round 4); k in [2, 64] = the LAST k passes as one group; 100 + g (g in [2, 64]) = groups of g passes all the way.
      * ptmi_stream_tickets is the order as a pure function. */
-    PTMI_OPT_STREAM_SHORT_PASSES = 13
+    PTMI_OPT_STREAM_PASS_GROUPS = 13
 };
 enum { PTMI_ARITH_EXACT = 0, PTMI_ARITH_CONTRACTED = 1 };
 enum { PTMI_SEED_KEEP_ACCUMULATOR = 0, PTMI_SEED_FROM_RESULT = 1, PTMI_SEED_AUTO = 2 };
@@ -258,7 +258,7 @@ int ptmi_stream_schedule(int n_spp, uint64_t n_pixels, uint64_t lanes, int batch
  * rebuilds: launch 0, 1, 3, 7, 15, ...)?  Returns the state after it. */
 int ptmi_order_schedule(int launches, int stream_form, int *rebuild, int *record);
 /* The order in which ONE of the eight ticket queues of the split kernel hands out its passes x queue_regions items under
- * PTMI_OPT_STREAM_SHORT_PASSES = option, for the schedule first[0 .. passes] of ptmi_stream_schedule: ticket j is (pass_out[j], region_out[j]),
+ * PTMI_OPT_STREAM_PASS_GROUPS = option, for the schedule first[0 .. passes] of ptmi_stream_schedule: ticket j is (pass_out[j], region_out[j]),
  * region = the region's index within the queue.  Every (pass, region) pair appears exactly once.  Pure host arithmetic.  Returns the number of
  * tickets, PTMI_ELIMIT if `capacity` entries do not hold them. */
 int ptmi_stream_tickets(int option, const int32_t *first, int passes, int queue_regions, int32_t *pass_out, int32_t *region_out, int capacity);

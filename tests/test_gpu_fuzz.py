@@ -236,7 +236,7 @@ def test_random_glass_scenes_tree_walk_and_stream_form(ctx, pkg, ora):
                 ctx.set_option(B.OPT_STREAM_BATCH, int(r.choice([0, 0, 1, 2, 5])))    # samples per item: several passes over the start hits
                 ctx.set_option(B.OPT_STREAM_GRADED, int(r.choice([1, 1, 0])))          # graded passes (the default) or round 3's uniform ones
                 ctx.set_option(B.OPT_GLASS_BATCH, int(r.choice([0, 0, 2, 8, 64])))     # GLASS hits parked in their lanes (the default: off)
-                ctx.set_option(B.OPT_STREAM_SHORT_PASSES, int(r.choice([0, 0, 1, 2, 3, 102, 103, 164])))   # the ticket order: groups of equal-size passes (default), pass by pass, fixed groups
+                ctx.set_option(B.OPT_STREAM_PASS_GROUPS, int(r.choice([0, 0, 1, 2, 3, 102, 103, 164])))   # the ticket order: groups of equal-size passes (default), pass by pass, fixed groups
                 ctx.upload_state(*start)
                 ctx.reset_stats()
                 ctx.render(cam, limit, spp, pkg.STREAMS)
@@ -263,4 +263,4 @@ def test_random_glass_scenes_tree_walk_and_stream_form(ctx, pkg, ora):
             ctx.set_option(B.OPT_SPP_CHUNKS, 0)
             ctx.set_option(B.OPT_STREAM_GRADED, 1)
             ctx.set_option(B.OPT_GLASS_BATCH, 0)
-            ctx.set_option(B.OPT_STREAM_SHORT_PASSES, 0)
+            ctx.set_option(B.OPT_STREAM_PASS_GROUPS, 0)

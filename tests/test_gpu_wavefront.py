@@ -292,7 +292,7 @@ def test_the_split_kernels_scheduling_knobs_change_no_ray_and_no_seed(ctx, pkg, 
 
 @pytest.mark.parametrize("order", [1, 2, 3, 102, 104, 164])
 def test_the_ticket_order_changes_no_ray_and_no_seed(ctx, pkg, ora, order):
-    """PTMI_OPT_STREAM_SHORT_PASSES: pass by pass (1), the last two or three passes as one group, pairs, groups of four behind two passes
+    """PTMI_OPT_STREAM_PASS_GROUPS: pass by pass (1), the last two or three passes as one group, pairs, groups of four behind two passes
     in pass order, everything region by region (164) -- six graded passes of 3, 2, 2, 2, 2, 2 samples at this size.  Every item is handed out
     exactly once whatever the order: counts and RNG planes equal the oracle's, colours within the tolerance of the undefined order of additions."""
     B = pkg.binding
@@ -300,12 +300,12 @@ def test_the_ticket_order_changes_no_ray_and_no_seed(ctx, pkg, ora, order):
     cam = pkg.world.initial_camera()
     w, h, spp = 128, 72, 13
     start = initial_planes(ora, w, h)
-    ctx.set_option(B.OPT_STREAM_SHORT_PASSES, order)
+    ctx.set_option(B.OPT_STREAM_PASS_GROUPS, order)
     try:
-        assert ctx.get_option(B.OPT_STREAM_SHORT_PASSES) == order
+        assert ctx.get_option(B.OPT_STREAM_PASS_GROUPS) == order
         got, st = render(ctx, pkg, scene, cam, w, h, spp, start, stream_form=True)
     finally:
-        ctx.set_option(B.OPT_STREAM_SHORT_PASSES, 0)
+        ctx.set_option(B.OPT_STREAM_PASS_GROUPS, 0)
     want, live, dropped, steps = ora.render_streams_wavefront(scene[0], scene[1], cam, w, h, CAP, spp, start)
     for a, b in zip(got[3:], want[3:]):
         assert np.array_equal(a, b)
@@ -347,12 +347,12 @@ def test_options_of_the_stream_form_are_range_checked_and_visible(pkg):
     B = pkg.binding
     with pkg.Context(0) as c:
         defaults = {B.OPT_STREAM_TAIL: -1, B.OPT_ORDERED_PASSES: 0, B.OPT_GLASS_BATCH: 0, B.OPT_STREAM_GRADED: 1, B.OPT_SNAPSHOT_BUDGET_MB: 0,
-                    B.OPT_STREAM_SHORT_PASSES: 0}
+                    B.OPT_STREAM_PASS_GROUPS: 0}
         for opt, value in defaults.items():
             assert c.get_option(opt) == value
         for opt, bad in ((B.OPT_STREAM_TAIL, -2), (B.OPT_STREAM_TAIL, 1001), (B.OPT_ORDERED_PASSES, -1), (B.OPT_ORDERED_PASSES, 65),
                          (B.OPT_GLASS_BATCH, 65), (B.OPT_STREAM_GRADED, 2), (B.OPT_SNAPSHOT_BUDGET_MB, -1), (B.OPT_SNAPSHOT_BUDGET_MB, (1 << 20) + 1),
-                         (B.OPT_STREAM_SHORT_PASSES, -1), (B.OPT_STREAM_SHORT_PASSES, 65), (B.OPT_STREAM_SHORT_PASSES, 101), (B.OPT_STREAM_SHORT_PASSES, 165)):
+                         (B.OPT_STREAM_PASS_GROUPS, -1), (B.OPT_STREAM_PASS_GROUPS, 65), (B.OPT_STREAM_PASS_GROUPS, 101), (B.OPT_STREAM_PASS_GROUPS, 165)):
             with pytest.raises(pkg.PtmiError) as e:
                 c.set_option(opt, bad)
             assert e.value.code == B.PTMI_EINVAL

@@ -71,7 +71,7 @@ def test_the_dispatch_order_is_rebuilt_before_launch_1_2_4_8_and_never_after_the
 
 
 def test_every_ticket_order_hands_out_every_item_exactly_once(pkg):
-    """PTMI_OPT_STREAM_SHORT_PASSES (ptmi_stream_tickets): whatever the option and the schedule, the tickets of a queue are a permutation of
+    """PTMI_OPT_STREAM_PASS_GROUPS (ptmi_stream_tickets): whatever the option and the schedule, the tickets of a queue are a permutation of
     {passes} x {the queue's regions} -- no item twice, none missing."""
     T, S = pkg.binding.stream_tickets, pkg.binding.stream_schedule
     schedules = [S(64, 1920 * 1080, LANES), S(512, 3840 * 270, LANES), S(64, 1920 * 1080, LANES, graded=False), S(13, 128 * 72, LANES), S(1, 10, LANES),

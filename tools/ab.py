@@ -43,11 +43,11 @@ for _k in (1, 2, 4, 5, 6, 8, 12, 16):
     WORKLOADS["c4_part_c%d" % _k] = ("s16", "inline", "auto", {"SPP_CHUNKS": _k}, C4_PART)
     WORKLOADS["c4_part_streams_c%d" % _k] = ("s16", "streams", "auto", {"SPP_CHUNKS": _k}, C4_PART)
 for _k in (102, 103, 104, 106, 107, 113, 164):                               # ... groups of k - 100 passes all the way
-    WORKLOADS["glass_stream_s%d" % _k] = ("glass", "streams", "stream", {"STREAM_SHORT_PASSES": _k}, None)
-    WORKLOADS["c5_stream_s%d" % _k] = ("glass", "streams", "stream", {"STREAM_SHORT_PASSES": _k}, C5_PART)
-for _k in (1, 2, 3, 4, 5, 6, 7, 8):                           # PTMI_OPT_STREAM_SHORT_PASSES: the last k passes region by region
-    WORKLOADS["glass_stream_s%d" % _k] = ("glass", "streams", "stream", {"STREAM_SHORT_PASSES": _k}, None)
-    WORKLOADS["c5_stream_s%d" % _k] = ("glass", "streams", "stream", {"STREAM_SHORT_PASSES": _k}, C5_PART)
+    WORKLOADS["glass_stream_s%d" % _k] = ("glass", "streams", "stream", {"STREAM_PASS_GROUPS": _k}, None)
+    WORKLOADS["c5_stream_s%d" % _k] = ("glass", "streams", "stream", {"STREAM_PASS_GROUPS": _k}, C5_PART)
+for _k in (1, 2, 3, 4, 5, 6, 7, 8):                           # PTMI_OPT_STREAM_PASS_GROUPS: the last k passes region by region
+    WORKLOADS["glass_stream_s%d" % _k] = ("glass", "streams", "stream", {"STREAM_PASS_GROUPS": _k}, None)
+    WORKLOADS["c5_stream_s%d" % _k] = ("glass", "streams", "stream", {"STREAM_PASS_GROUPS": _k}, C5_PART)
 for _k in (4, 8, 16, 32, 64):
     WORKLOADS["glass_stream_b%d" % _k] = ("glass", "streams", "stream", {"STREAM_BATCH": _k}, None)
     WORKLOADS["s16_stream_b%d" % _k] = ("s16", "streams", "stream", {"STREAM_BATCH": _k}, None)

@@ -13,7 +13,7 @@ against the product, which are the terms:
     product - skip_item_atomics      what the three colour atomics at every item's end cost in fetches and write-backs
     product - skip_ring_atomics      ... and the atomics of rays taken from the ring
     product - skip_item_costs        ... and the cost record of an item (one atomic on a word all XCDs share; pass 0's items only since round 5)
-    pass_by_pass - product           what the ticket order saves: PTMI_OPT_STREAM_SHORT_PASSES = 1 is round 4's order, every region's records from HBM once per pass
+    pass_by_pass - product           what the ticket order saves: PTMI_OPT_STREAM_PASS_GROUPS = 1 is round 4's order, every region's records from HBM once per pass
     one_group, groups_of_2 / 3, short_2 / 3    other ticket orders
     uniform_4x16                     four passes instead of six: what a pass costs
 """
@@ -34,12 +34,12 @@ DEFAULT_WORKLOAD = ["--scene", "glass", "--algorithm", "streams", "--streams-for
 # name -> (extra compile flags of a measurement build or None, bench options)
 VARIANTS = collections.OrderedDict([
     ("product", (None, [])),                                                     # tickets in groups of equal-size passes (automatic)
-    ("pass_by_pass", (None, ["--option", "STREAM_SHORT_PASSES=1"])),             # round 4's order
-    ("short_2", (None, ["--option", "STREAM_SHORT_PASSES=2"])),
-    ("short_3", (None, ["--option", "STREAM_SHORT_PASSES=3"])),
-    ("groups_of_2", (None, ["--option", "STREAM_SHORT_PASSES=102"])),
-    ("groups_of_3", (None, ["--option", "STREAM_SHORT_PASSES=103"])),
-    ("one_group", (None, ["--option", "STREAM_SHORT_PASSES=164"])),
+    ("pass_by_pass", (None, ["--option", "STREAM_PASS_GROUPS=1"])),             # round 4's order
+    ("short_2", (None, ["--option", "STREAM_PASS_GROUPS=2"])),
+    ("short_3", (None, ["--option", "STREAM_PASS_GROUPS=3"])),
+    ("groups_of_2", (None, ["--option", "STREAM_PASS_GROUPS=102"])),
+    ("groups_of_3", (None, ["--option", "STREAM_PASS_GROUPS=103"])),
+    ("one_group", (None, ["--option", "STREAM_PASS_GROUPS=164"])),
     ("uniform_4x16", (None, ["--option", "STREAM_GRADED=0"])),
     ("skip_item_atomics", (["-DPTMI_TRAFFIC_SKIP=1"], [])),
     ("skip_ring_atomics", (["-DPTMI_TRAFFIC_SKIP=2"], [])),
