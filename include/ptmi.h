@@ -58,8 +58,9 @@ enum { PTMI_STREAMS = 0, PTMI_INLINE = 1 };
  * refraction ray.  The reference only announces such materials (src/Scene/Trace.hs:109-118, :306-307, :327-328),
  * so GLASS has no reference semantics; it is accepted by PTMI_STREAMS only (Inline cannot split rays,
  * src/Scene/Trace.hs:62-67).  By DEFAULT a scene with GLASS is rendered by the per-pixel TREE WALK (deterministic, bit-exact
- * against the oracle: one adder per colour word); the stream ("wavefront") form -- BASELINE configs[4]'s path, as fast, colours
- * through float atomics -- is PTMI_OPT_STREAMS_FORM = PTMI_FORM_STREAM.  See DESIGN.md 5.4 / 5.5. */
+ * against the oracle: one adder per colour word); the stream ("wavefront") form -- BASELINE configs[4]'s path; within 3 % of the
+ * tree walk either way (slower at 1080p / 64 spp, faster on a part of a 4K image at 512 spp), colours through float atomics in no defined
+ * order -- is PTMI_OPT_STREAMS_FORM = PTMI_FORM_STREAM.  See DESIGN.md 5.4 / 5.5. */
 enum { PTMI_MATTE = 0, PTMI_GLOSSY = 1, PTMI_GLASS = 2 };
 
 #define PTMI_MAX_PRIMITIVES 1024   /* spheres + planes staged in LDS per workgroup */
