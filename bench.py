@@ -590,7 +590,10 @@ def main():
         if n1_ms is not None:
             out["one_gpu_same_workload"] = {"ms_per_step": round(n1_ms, 3),
                                             "value": round(nominal_per_step / (n1_ms * 1e-3) / 1e6, 1),
-                                            "note": "the whole image on rank 0's GPU alone, best of 3, outside the timed region"}
+                                            "note": "the whole image on rank 0's GPU alone, best of 3, outside the timed region -- the one-GPU figure of THIS "
+                                                    "workload (C4, strong scaling).  The N = 1 line of a scale series is the headline workload C2 (BASELINE "
+                                                    "configs[1], 1080p / 64 spp), whose launches are 58 times shorter: a ratio of this line's value to that "
+                                                    "line's compares two workloads; `python bench.py --gpus 1 --scaling strong` prints C4 on one GPU as a line of its own"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, spheres, planes, cam, width, height)
         if is_c2 and not args.no_also and not args.variant:
