@@ -50,3 +50,22 @@ def test_bench_strong_scaling_rehearsal_gathers_the_one_context_image():
     assert max(r["elapsed_ms_per_step"] for r in ranks) == pytest.approx(out["ms_per_step"], rel=1e-3)
     # ... and names the binary that produced it
     assert out["binary_build_id"] == out["source_hash_now"]
+
+
+def test_bench_weak_scaling_rehearsal_two_ranks():
+    """`--scaling weak` (every rank renders 1920x1080 pixels of a 1920 x 2160 image: per-GPU work fixed, the mode whose N-series is ONE workload
+    per GPU with the N = 1 line) through the same pre-check, gather and image comparison, two ranks on the one card over gloo."""
+    env = dict(os.environ, PTMI_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scaling", "weak", "--spp", "4",
+           "--steps", "2", "--warmup", "1", "--check-image"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["width"] == 1920 and out["config"]["height"] == 2160 and out["config"]["rows_per_gpu"] == 1080
+    assert out["gathered_image_equals_one_context"] is True
+    assert out["collective"]["gathered_image_equals_one_context_at_4_spp"] is True
+    assert [r["rows"] for r in out["collective"]["per_rank"]] == [1080, 1080]
+    # whole-job throughput: both ranks' pixels over the slowest rank's time
+    assert out["value"] == pytest.approx(1920 * 2160 * 4 * 8 * 2 / (out["ms_per_step"] * 2 * 1e-3) / 1e6, rel=1e-3)
