@@ -177,12 +177,12 @@ def also_measurements(pkg, torch):
     out = []
     rooflines = streams_rooflines(pkg)
 
-    def run(name, scene, width, height, spp, limit, algorithm, part_of=0, stripe=10, stream_form=False, warm=3, steps=3, note=None, profile=None):
+    def run(name, scene, width, height, spp, limit, algorithm, part_of=0, stripe=10, stream_form=False, warm=3, steps=3, note=None, profile=None, part=0):
         sp, pl = scenes[scene]
         with pkg.Context(0) as c:
             c.set_scene(sp, pl)
             if part_of > 1:
-                c.set_partition(stripe, part_of, 0)
+                c.set_partition(stripe, part_of, part)
             c.resize(width, height)
             if stream_form:
                 c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
@@ -217,6 +217,9 @@ def also_measurements(pkg, torch):
     run("C4, one part of 8 (10-row stripes): what one rank of the 8-GPU job renders", "s16", 3840, 2160, 1024, BOUNCE_LIMIT, pkg.INLINE, part_of=8)
     run("C5, one part of 8: glass scene, 3840x2160, 512 spp, render Streams, per-pixel tree walk (the default with GLASS)", "glass", 3840, 2160, 512, BOUNCE_LIMIT, pkg.STREAMS, part_of=8, warm=9, profile="c5_tree")
     run("C5, one part of 8, stream ('wavefront') form: start-hit regions, graded passes, child rings (BASELINE configs[4]'s path)", "glass", 3840, 2160, 512, BOUNCE_LIMIT, pkg.STREAMS, part_of=8, stream_form=True, warm=9, profile="c5_stream")
+    # the part that bounds the 8-GPU job: under the tree walk part 6 of the 10-row stripes is the slowest in every run of tools/part_bound.py (profiles/r05_c5_part.json)
+    run("C5, the slowest part of 8 (part 6), tree walk", "glass", 3840, 2160, 512, BOUNCE_LIMIT, pkg.STREAMS, part_of=8, part=6, warm=9)
+    run("C5, part 6 of 8, stream form", "glass", 3840, 2160, 512, BOUNCE_LIMIT, pkg.STREAMS, part_of=8, part=6, stream_form=True, warm=9)
     run("C2 through render Streams, per-pixel chain", "s16", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, warm=9, steps=5, profile="streams")
     run("C2 through render Streams, stream form", "s16", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, stream_form=True, warm=9, steps=5, profile="s16_stream")
     run("glass scene, 1920x1080, 64 spp, render Streams, tree walk", "glass", 1920, 1080, 64, BOUNCE_LIMIT, pkg.STREAMS, warm=9, steps=5, profile="glass_tree")
