@@ -119,6 +119,8 @@ __device__ __forceinline__ unsigned int xcc_id()
     return (unsigned int)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;     // HW_REG_XCC_ID, bits [3:0]
 }
 __device__ __forceinline__ bool chunks_left(const ChunkCursor &c) { return c.tries < 8u; }
+template <bool GROUPS>      // GROUPS: the kernel may be handed a group table (the split kernel).  The pixels kernel's ordered passes never are, and the scan it
+                            // would never run still cost it 1 % as code in its loop (4.34 -> 4.30 ms on C2 through Streams, round 5): compiled out there
 __device__ __forceinline__ void next_chunk(ChunkCursor &c, const ItemArgs &it)
 {
     // A chunk is a WHOLE region (64 slots, or 128 where a glass primary hit contributes two records).  Until round 4 a 128-slot region was two
@@ -139,7 +141,7 @@ __device__ __forceinline__ void next_chunk(ChunkCursor &c, const ItemArgs &it)
         j = (unsigned int)__builtin_amdgcn_readfirstlane((int)j);
         if (n == 0u || j / n >= (unsigned int)it.passes) { ++c.tries; continue; }
         unsigned int k;
-        decode_ticket(j, n, it.group_first, it.groups, c.pass, k);
+        decode_ticket(j, n, GROUPS ? it.group_first : nullptr, it.groups, c.pass, k);
         const unsigned int s_pos = k >> 2, r = k & 3u;
         c.region = (s_pos * 8u + q) * 4u + r;
         c.first = c.region * it.hits.region_slots;

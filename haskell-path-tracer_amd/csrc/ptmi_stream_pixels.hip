@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
     // waves leave as they end: ptmi_api.cpp)
     cur.n_positions = it.n_positions;
     if (it.tail_start) { const unsigned int t = *it.tail_start; cur.n_positions = t < it.n_positions ? t : it.n_positions; }
-    next_chunk(cur, it);
+    next_chunk<false>(cur, it);
     diag::TailProbe probe; probe.begin();                     // (diagnostic builds: ptmi_diag.h)
 
     bool busy = false, pending = false, has_ray = false, over = false, unpublished = false;
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
                 s = -1; busy = true; over = true; pending = false; has_ray = false;
             }
             cur.taken += take;
-            if (cur.taken >= cur.len) next_chunk(cur, it);
+            if (cur.taken >= cur.len) next_chunk<false>(cur, it);
             probe.refill_end(take);
         }
         if (!__any(busy) && !chunks_left(cur)) break;      // (no lane busy, chunks left: nothing below has a lane to run for; the next trip refills)

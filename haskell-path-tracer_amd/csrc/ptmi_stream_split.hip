@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
     auto get = [&](int k) { return mine[k * kRenderBlock]; };
 
     ChunkCursor cur; cur.home = xcc_id(); cur.tries = 0; cur.n_positions = it.n_positions;
-    next_chunk(cur, it);
+    next_chunk<true>(cur, it);
     unsigned int ring_head = 0, ring_n = 0;                   // wave-uniform
     unsigned int spill_head = 0, spill_n = 0;                 // wave-uniform: the wave's spill queue, records [w kSpill, (w + 1) kSpill) of it.spill
     unsigned int blk = w * kFirstBlock, blk_end = blk + kFirstBlock;   // wave-uniform: the overflow block being filled
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                 busy = true;
             }
             cur.taken += take;
-            if (cur.taken >= cur.len) next_chunk(cur, it);
+            if (cur.taken >= cur.len) next_chunk<true>(cur, it);
             // (Tried and dropped, round 4: touching the records of the NEXT refill a trip early -- 8 or 16 lanes load one word each: 8.21 / 8.25
             // ms against 8.09; taking the next chunk one chunk early to touch all of its records and then their seed snapshots: 8.16; taking only
             // its TICKET and record count early, so that the switch to the next chunk waits for nothing: 8.01 against 7.93, C5 part 30.0 against
