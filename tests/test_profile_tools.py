@@ -85,6 +85,9 @@ def test_the_documents_and_the_committed_profiles_name_one_binary():
     summaries, the part bounds, the traffic terms) and the fuzz record must carry that same build id -- a table of one binary next to a profile of
     another is the kind of evidence round 4's verdict took apart."""
     import re
+    # the measured tables of DESIGN.md are GENERATED from the committed profiles (tools/design_tables.py): they must be what the profiles say
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "design_tables.py"), "r05", "--check"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     ids = set(re.findall(r"`ptmi_build_id\(\)` = `([0-9a-f]{16})`", design))
     assert len(ids) == 1, ids
