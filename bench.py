@@ -119,11 +119,12 @@ def valu_accounting(pkg, kernel_ms):
     of the run (two boxes of the pool at 2.28 and 2.36 GHz spent the same cycles): profiles/rNN_valu_roofline.json holds,
     for the C2 launch, the VALU wave-instructions per launch by category (PMC), the issue cycles their class costs assign
     to that mix (a lower bound), the SIMD cycles the launch took (GRBM_GUI_ACTIVE / 8 XCDs) and the active-lane fraction.
-    frac = issue cycles needed / SIMD cycles taken, both from that profile; `stale` says whether the kernel sources have
-    changed since the profile was taken (source_hash); implied_clock_ghz = the shader clock this run's launch time implies
+    frac = issue cycles needed / SIMD cycles taken, both from that profile; `stale` says whether the compiled CODE has
+    changed since the profile was taken (the profile names the ptmi_build_id() of the binary it was taken on; comment edits keep
+    that id: _build.code_id); implied_clock_ghz = the shader clock this run's launch time implies
     for the same cycle count -- outside 2.1-2.5 GHz the profile no longer describes the binary."""
     d, name = None, None
-    for tag in ("r05", "r04", "r03", "r02"):
+    for tag in ("r06", "r05", "r04", "r03", "r02"):
         d = load_json("%s_valu_roofline.json" % tag)
         if d:
             name = "profiles/%s_valu_roofline.json" % tag
@@ -133,7 +134,7 @@ def valu_accounting(pkg, kernel_ms):
     try:
         measured = float(d["measured_cycles_in_profile"])
         implied = measured / (d["n_simds"] * kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
-        now = pkg._build.source_hash()
+        now = pkg.load_library().build_id.split("+")[0]
         return {"min_issue_cycles": round(d["min_issue_cycles"]), "measured_cycles": round(measured),
                 "frac": round(d["min_issue_cycles"] / measured, 4),
                 "frac_with_v_fma_f32_at_2_cycles": d.get("frac_with_v_fma_f32_at_2_cycles"),
@@ -144,8 +145,8 @@ def valu_accounting(pkg, kernel_ms):
                 "avg_issue_cycles_per_instr": round(d["avg_issue_cycles_per_instr"], 3),
                 "implied_clock_ghz": round(implied, 3) if implied else None,
                 "profile_clock_ghz": d["clock_ghz"], "source": name,
-                "profile_source_hash": d.get("source_hash"), "source_hash_now": now,
-                "stale": d.get("source_hash") != now}
+                "profile_build_id": d.get("build_id", d.get("source_hash")), "build_id_now": now,
+                "stale": d.get("build_id", d.get("source_hash")) != now}
     except Exception:
         return None
 
@@ -153,15 +154,15 @@ def valu_accounting(pkg, kernel_ms):
 def streams_rooflines(pkg):
     """{workload key: the VALU issue accounting of its kernel} from the newest profiles/rNN_valu_roofline_streams.json
     (tools/valu_roofline.py streams TAG: the accounting of `roofline.valu`, for the Streams kernels), with `stale` by the same hash rule."""
-    for tag in ("r05", "r04", "r03"):
+    for tag in ("r06", "r05", "r04", "r03"):
         d = load_json("%s_valu_roofline_streams.json" % tag)
         if d:
-            now = pkg._build.source_hash()
+            now = pkg.load_library().build_id.split("+")[0]
             return {key: {"kernel": a["kernel"], "valu_issue_frac": a["frac_in_profile"], "valu_issue_frac_priced_with_measured_opcode_costs": a["priced_with_measured_rates"]["frac"],
                           "active_lane_frac": a["active_lane_frac"], "simd_cycles_per_valu_instr": a["measured_simd_cycles_per_instr"],
                           "valu_wave_instr_per_call": round(a["valu_wave_instr_per_launch"]), "hbm_MB_per_call": a.get("hbm_MB_per_call"),
-                          "kernel_us_in_profile": a["kernel_us_in_profile"], "source": a["source"], "profile_source_hash": a.get("source_hash"),
-                          "stale": a.get("source_hash") != now} for key, a in d.items()}
+                          "kernel_us_in_profile": a["kernel_us_in_profile"], "source": a["source"], "profile_build_id": a.get("build_id", a.get("source_hash")),
+                          "stale": a.get("build_id", a.get("source_hash")) != now} for key, a in d.items() if "refused" not in a}
     return {}
 
 
@@ -570,9 +571,11 @@ def main():
             "live_bounce_fraction": round(live_total / (nominal_per_step * args.steps), 4) if args.algorithm == "inline" else None,
             "live_Mbounces_per_s": round(live_total / elapsed / 1e6, 1),
             "roofline": roofline,
-            # which binary produced these numbers: the id linked into the loaded libptmi.so (ptmi_build_id) and the hash of the sources
-            # beside it now -- binding.open_library has already refused the library if they differ
-            "binary_build_id": pkg.load_library().build_id, "source_hash_now": pkg._build.source_hash(),
+            # which binary produced these numbers: the id linked into the loaded libptmi.so (ptmi_build_id: a hash over its compiled code) and
+            # the id the sources beside it compile to now -- binding.open_library has already refused the library if they differ;
+            # source_text_hash only says whether any byte of the sources (comments included) has moved since the link
+            "binary_build_id": pkg.load_library().build_id, "code_id_now": pkg._build.code_id(),
+            "source_text_hash": pkg._build.source_hash(), "binary_linked_from_text": pkg._build.read_source_hash(pkg._build.LIB),
             "ramp": {"spp_per_launch": ramp_spp, "launches": ramp_launches},
         }
         if collective is not None:

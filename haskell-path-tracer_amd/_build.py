@@ -1,5 +1,8 @@
 """Builds libptmi.so (HIP kernels + C ABI) for gfx950, in-tree, with hipcc.
 
+The library names itself by its CODE (ptmi_build_id() = code_id(): a hash over the compiled objects' allocated sections), not by
+the text it was compiled from: profiles and fuzz records stay valid across comment and documentation edits.
+
 One translation unit per kernel family (csrc/ptmi_*.hip over the shared csrc/ptmi_device.h), compiled in parallel into
 build/obj/<flags key>/ and linked; an edit recompiles the units whose sources or headers moved (their -MD dependency files).
 The Inline unit is compiled a second time with contracted arithmetic (a labelled measurement mode, PTMI_OPT_ARITHMETIC).
@@ -22,8 +25,9 @@ LIB = os.path.join(HERE, "libptmi.so")
 ABLATIONS_LIB = os.path.join(HERE, "libptmi_ablations.so")   # the same library with the ablation kernels of DESIGN.md 5.2 (tests, measurements)
 OBJ_ROOT = os.path.join(ROOT, "build", "obj")
 HOST_SOURCES = ["ptmi_api.cpp", "ptmi_stage.cpp", "ptmi_group.cpp"]
-BUILD_ID_UNIT = "ptmi_build_id.cpp"                          # ptmi_build_id(): compiled at every link with -DPTMI_BUILD_ID=<what the library was built from>
+BUILD_ID_UNIT = "ptmi_build_id.cpp"                          # ptmi_build_id(): compiled at every link with -DPTMI_BUILD_ID=<the code the library holds>
 BUILD_ID_MARKER = b"PTMI_BUILD_ID="                          # ... behind this marker in the binary, so that the file can be asked without loading it
+SOURCE_HASH_MARKER = b"PTMI_SOURCE_HASH="                    # ... and the hash of the source TEXT it was linked from (staleness only, see source_hash)
 INLINE_UNIT = "ptmi_inline.hip"                              # also the contracted-arithmetic object
 KERNEL_UNITS = [INLINE_UNIT, "ptmi_streams_chain.hip", "ptmi_streams_tree.hip", "ptmi_stream_primary.hip", "ptmi_stream_pixels.hip",
                 "ptmi_stream_split.hip", "ptmi_small.hip"]
@@ -35,6 +39,7 @@ COMPILE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=of
                  "-fno-fast-math", "-fno-slp-vectorize", "-DPTMI_SINCOS_FUSED=1", "-Wall", "-pthread"]
 LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-ldl"]
 FLAGS = COMPILE_FLAGS + ["-shared", "-ldl"]                  # (what tools that compile a single unit start from)
+RECIPE = "cwd=csrc,cuid=unit+flags"                          # how _compile invokes the compiler, as far as the object depends on it
 JOBS = max(1, min(8, os.cpu_count() or 1))
 
 
@@ -46,36 +51,92 @@ def hipcc_path():
 
 
 def source_hash():
-    """sha256 over the kernel sources, the headers and the build flags: what a binary is built FROM and what a profile of
-    it is a profile OF.  The library carries it (ptmi_build_id(), include/ptmi.h), binding.open_library refuses a library
-    that carries another one, bench.py prints both, and profiles/*_valu_roofline.json name the one they were taken on."""
-    h = hashlib.sha256(" ".join(COMPILE_FLAGS + LINK_FLAGS).encode())
+    """sha256 over the TEXT of the kernel sources, the headers and the build flags.  It answers one question only -- "has any
+    byte moved since this library was linked?" (is_stale's fast path) -- and names nothing: a comment edit changes it.  What a
+    binary IS, and what a profile of it is a profile OF, is code_id() below."""
+    h = hashlib.sha256(" ".join(COMPILE_FLAGS + LINK_FLAGS + [RECIPE]).encode())
     for f in sorted(SOURCES + HEADERS):
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
 
 
-def build_id(extra_flags=()):
-    """What ptmi_build_id() of a library built NOW from these sources with these extra flags returns: the source hash, and
-    behind a '+' the extra flags of a non-default build (ablations, diagnostic builds)."""
+def object_code_hash(obj):
+    """sha256 over the ALLOCATED sections of one ELF object (name, then contents): host .text / .rodata / .data, and .hip_fatbin --
+    the gfx950 code objects.  Symbol tables, string tables, relocations and .comment are left out, so an object says the same
+    after a comment edit, a re-flowed header or a renamed static helper; it says something else as soon as an instruction, a
+    constant or a kernel's name (the fatbin carries them; profiles are keyed by them) moves.  Units are compiled from within
+    csrc/ under their bare names (_compile), so no path of the checkout is in the object either."""
+    with open(obj, "rb") as fh:
+        data = fh.read()
+    if data[:4] != b"\x7fELF" or data[4] != 2 or data[5] != 1:
+        raise RuntimeError("%s is not a little-endian ELF64 object" % obj)
+    shoff = int.from_bytes(data[0x28:0x30], "little")
+    shentsize, shnum, shstrndx = (int.from_bytes(data[o:o + 2], "little") for o in (0x3A, 0x3C, 0x3E))
+
+    def header(i):
+        b = data[shoff + i * shentsize: shoff + (i + 1) * shentsize]
+        return (int.from_bytes(b[0:4], "little"), int.from_bytes(b[4:8], "little"), int.from_bytes(b[8:16], "little"),
+                int.from_bytes(b[24:32], "little"), int.from_bytes(b[32:40], "little"))     # name, type, flags, offset, size
+    _, _, _, str_off, str_size = header(shstrndx)
+    names = data[str_off:str_off + str_size]
+    h = hashlib.sha256()
+    for i in range(shnum):
+        name, typ, flags, off, size = header(i)
+        if not flags & 2 or typ == 8:                       # SHF_ALLOC only; SHT_NOBITS has no bytes
+            continue
+        h.update(names[name:names.index(b"\0", name)] + b"\0" + size.to_bytes(8, "little") + data[off:off + size])
+    return h.hexdigest()
+
+
+def code_id_of(objs):
+    """The id of a library linked from these objects: sha256 over (unit name, object_code_hash) in name order, 16 hex digits."""
+    h = hashlib.sha256()
+    for obj in sorted(objs, key=os.path.basename):
+        h.update(os.path.basename(obj).encode() + b"\0" + object_code_hash(obj).encode() + b"\0")
+    return h.hexdigest()[:16]
+
+
+def _flag_suffix(extra_flags=()):
     extra = sorted(extra_flags)
-    return source_hash() + ("+" + ",".join(f[2:] if f.startswith("-D") else f for f in extra) if extra else "")
+    return "+" + ",".join(f[2:] if f.startswith("-D") else f for f in extra) if extra else ""
+
+
+def code_id(extra_flags=(), verbose=False):
+    """What ptmi_build_id() of a library built NOW from these sources with these extra flags returns: the hash of the COMPILED
+    code (object_code_hash of every unit; units whose sources moved are recompiled first, the others come from the object
+    cache), and behind a '+' the extra flags of a non-default build (ablations, diagnostic builds).  Profiles, fuzz records and
+    soaks name this id: it survives comment, documentation and rename-only edits, and nothing else."""
+    return code_id_of(_compile_units(list(extra_flags), verbose, False)) + _flag_suffix(extra_flags)
+
+
+def build_id(extra_flags=()):
+    """code_id under its old name (what ptmi_build_id() of a fresh build returns)."""
+    return code_id(extra_flags)
+
+
+def _read_marked(lib, marker):
+    try:
+        with open(lib, "rb") as fh, mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ) as m:
+            at = m.find(marker)
+            if at < 0:
+                return None
+            at += len(marker)
+            end = m.find(b"\0", at, at + 512)
+            return m[at:end].decode("ascii", "replace") if end > at else None
+    except (OSError, ValueError):
+        return None
 
 
 def read_build_id(lib):
     """The id a built library carries, read from the FILE (no dlopen: a library of the same name may already be mapped), or
     None for a missing file or one without the marker (a build from before ptmi_build_id existed)."""
-    try:
-        with open(lib, "rb") as fh, mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ) as m:
-            at = m.find(BUILD_ID_MARKER)
-            if at < 0:
-                return None
-            at += len(BUILD_ID_MARKER)
-            end = m.find(b"\0", at, at + 512)
-            return m[at:end].decode("ascii", "replace") if end > at else None
-    except (OSError, ValueError):
-        return None
+    return _read_marked(lib, BUILD_ID_MARKER)
+
+
+def read_source_hash(lib):
+    """source_hash() of the text a built library was linked from (read from the file), or None."""
+    return _read_marked(lib, SOURCE_HASH_MARKER)
 
 
 def _all_deps():
@@ -83,9 +144,28 @@ def _all_deps():
 
 
 def is_stale(lib=LIB, extra_flags=()):
-    """A library is current iff it CARRIES the id of the present sources and flags -- file times say nothing about a binary that
-    travelled (the .so files ship to the GPU box with the snapshot; a checkout or a copy resets every mtime)."""
-    return read_build_id(lib) != build_id(extra_flags)
+    """A library is current iff it was linked from the present source text and flags (the fast path: no compiler runs), or -- the
+    text having moved -- it still CARRIES the id of the code the present sources compile to (a comment was edited: code_id
+    recompiles the touched units, nothing is relinked).  File times say nothing about a binary that travelled (the .so files
+    ship to the GPU box with the snapshot; a checkout or a copy resets every mtime)."""
+    carried = read_build_id(lib)
+    if carried is None or not carried.endswith(_flag_suffix(extra_flags)) or ("+" in carried) != bool(list(extra_flags)):
+        return True
+    if read_source_hash(lib) == source_hash():
+        return False
+    return carried != code_id(extra_flags)
+
+
+def matches_sources(lib):
+    """True iff the library at `lib` holds the code the sources beside this file compile to, under whatever extra flags its id
+    names: binding.open_library's question."""
+    carried = read_build_id(lib)
+    if carried is None:
+        return False
+    if read_source_hash(lib) == source_hash():
+        return True
+    extra = [f if f.startswith("-") else "-D" + f for f in carried.split("+", 1)[1].split(",")] if "+" in carried else []
+    return carried == code_id(extra)
 
 
 def _deps_of(obj, src):
@@ -97,7 +177,8 @@ def _deps_of(obj, src):
     with open(dep) as fh:
         words = fh.read().replace("\\\n", " ").split()
     root = os.path.realpath(ROOT)
-    files = [os.path.realpath(w) for w in words[1:] if not w.endswith(":") and os.path.exists(w)]
+    words = [os.path.join(CSRC, w) for w in words[1:] if not w.endswith(":")]      # (the units are compiled from within csrc/)
+    files = [os.path.realpath(w) for w in words if os.path.exists(w)]
     return sorted(set(f for f in files if f.startswith(root + os.sep)) | {os.path.realpath(src)})
 
 
@@ -119,10 +200,15 @@ def _compile(src, obj, flags, verbose=False, force=False):
             if fh.read().strip() == _digest(_deps_of(obj, src), flags):
                 return obj
     tmp = "%s.tmp.%d" % (obj, os.getpid())
-    cmd = [hipcc_path()] + flags + ["-MD", "-MF", tmp + ".d", "-MT", obj, "-c", src, "-o", tmp]
+    # compiled from WITHIN csrc/ under the unit's bare name: the device code object records the name the compiler was given, and
+    # an object must not depend on where the checkout lies (object_code_hash)
+    # ... nor on the name of its temporary output: clang derives the compilation unit's id (a symbol's name, host and device side) from
+    # its command line unless it is given one -- the unit's name and flags, hashed
+    cuid = hashlib.sha256((os.path.basename(obj) + " " + " ".join(flags)).encode()).hexdigest()[:16]
+    cmd = [hipcc_path()] + flags + ["-cuid=" + cuid, "-MD", "-MF", tmp + ".d", "-MT", obj, "-c", os.path.relpath(src, CSRC), "-o", tmp]
     if verbose:
-        print(" ".join(cmd), flush=True)
-    res = subprocess.run(cmd, capture_output=True, text=True)
+        print("(cd %s && %s)" % (CSRC, " ".join(cmd)), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
     if res.returncode != 0:
         for f in (tmp, tmp + ".d"):
             if os.path.exists(f):
@@ -150,12 +236,10 @@ def toolchain_id():
     return _toolchain
 
 
-def _build(out, extra_flags=(), verbose=False, force=False):
-    """Every unit -> object (in parallel, cached per flag set and toolchain), then the link -- with ptmi_build_id.cpp compiled
-    afresh, carrying the id of what was just compiled."""
-    extra = list(extra_flags)
-    ident = build_id(extra)                          # BEFORE compiling: an edit during the build makes the library stale, not wrong
-    key = hashlib.sha256(" ".join(COMPILE_FLAGS + extra + [toolchain_id()]).encode()).hexdigest()[:12]
+def _compile_units(extra, verbose=False, force=False):
+    """Every unit of a build with these extra flags -> its object (in parallel, cached per flag set and toolchain; a cached
+    object is reused while the contents of everything it was compiled from are unchanged)."""
+    key = hashlib.sha256(" ".join(COMPILE_FLAGS + extra + [toolchain_id(), RECIPE]).encode()).hexdigest()[:12]
     obj_dir = os.path.join(OBJ_ROOT, key)
     os.makedirs(obj_dir, exist_ok=True)
     units = HOST_SOURCES + KERNEL_UNITS + (ABLATION_UNITS if "-DPTMI_ABLATIONS" in extra else [])
@@ -165,22 +249,31 @@ def _build(out, extra_flags=(), verbose=False, force=False):
     contracted = [f for f in COMPILE_FLAGS if f != "-ffp-contract=off"] + extra + ["-ffp-contract=fast", "-DPTMI_CONTRACTED_BUILD", "-Dptmi=ptmi_contracted"]
     jobs.append((os.path.join(CSRC, INLINE_UNIT), os.path.join(obj_dir, INLINE_UNIT + ".contracted.o"), contracted))
     with ThreadPoolExecutor(JOBS) as pool:
-        objs = list(pool.map(lambda j: _compile(j[0], j[1], j[2], verbose, force), jobs))
-    id_obj = os.path.join(obj_dir, "%s.%d.o" % (BUILD_ID_UNIT, os.getpid()))
+        return list(pool.map(lambda j: _compile(j[0], j[1], j[2], verbose, force), jobs))
+
+
+def _build(out, extra_flags=(), verbose=False, force=False):
+    """Every unit -> object, then the link -- with ptmi_build_id.cpp compiled afresh, carrying the id of the objects' code
+    (code_id_of) and the hash of the source text they were compiled from."""
+    extra = list(extra_flags)
+    text = source_hash()                             # BEFORE compiling: an edit during the build makes the library stale, not wrong
+    objs = _compile_units(extra, verbose, force)
+    ident = code_id_of(objs) + _flag_suffix(extra)
+    id_obj = os.path.join(os.path.dirname(objs[0]), "%s.%d.o" % (BUILD_ID_UNIT, os.getpid()))
     host_flags = [f for f in COMPILE_FLAGS if not f.startswith("--offload-arch")]
-    res = subprocess.run([hipcc_path()] + host_flags + ['-DPTMI_BUILD_ID="%s"' % ident, "-c", os.path.join(CSRC, BUILD_ID_UNIT), "-o", id_obj],
+    res = subprocess.run([hipcc_path()] + host_flags + ['-DPTMI_BUILD_ID="%s"' % ident, '-DPTMI_SOURCE_HASH="%s"' % text,
+                                                       "-c", os.path.join(CSRC, BUILD_ID_UNIT), "-o", id_obj],
                          capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed on %s:\n" % BUILD_ID_UNIT + res.stdout + res.stderr)
-    objs.append(id_obj)
-    cmd = [hipcc_path()] + LINK_FLAGS + objs + ["-o", out]
+    cmd = [hipcc_path()] + LINK_FLAGS + objs + [id_obj, "-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
     os.remove(id_obj)
     if res.returncode != 0:
         raise RuntimeError("hipcc (link) failed:\n" + res.stdout + res.stderr)
-    if read_build_id(out) != ident:
+    if read_build_id(out) != ident or read_source_hash(out) != text:
         raise RuntimeError("%s does not carry the build id %s it was linked with" % (out, ident))
     return out
 

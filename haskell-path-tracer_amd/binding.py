@@ -105,9 +105,10 @@ _lib = None
 def open_library(path, check_build_id=True):
     """dlopen one libptmi build and type every symbol (a second build -- the ablation library, a diagnostic build -- can be
     open beside the default one: Context(library=...)).
-    The library must have been built from the sources beside this file: its ptmi_build_id() has to start with
-    _build.source_hash() (behind it a diagnostic build names its extra flags).  A binary that travelled with edited sources, or
-    one from an older checkout, is refused here instead of being measured under the wrong name."""
+    The library must hold the code the sources beside this file compile to: either it was linked from this very text, or its
+    ptmi_build_id() -- a hash over the compiled objects' code (_build.code_id) -- is what the sources give now (a comment edit
+    keeps it).  A binary that travelled with edited kernels, or one from an older checkout, is refused here instead of being
+    measured under the wrong name."""
     if not os.path.exists(path):
         raise PtmiError(PTMI_ESTATE, "libptmi.so not built (%s); run __graft_entry__.build()" % path)
     lib = C.CDLL(path)
@@ -115,11 +116,10 @@ def open_library(path, check_build_id=True):
         fn = getattr(lib, name)          # AttributeError if the library does not export it
         fn.restype, fn.argtypes = res, args
     lib.build_id = (lib.ptmi_build_id() or b"").decode("ascii", "replace")
-    if check_build_id:
-        want = _build.source_hash()
-        if lib.build_id.split("+")[0] != want:
-            raise PtmiError(PTMI_ESTATE, "%s was built from other sources: it carries build id %r, the sources here hash to %r; "
-                                         "rebuild it (__graft_entry__.build())" % (path, lib.build_id, want))
+    if check_build_id and not _build.matches_sources(path):
+        raise PtmiError(PTMI_ESTATE, "%s was built from other sources: it carries build id %r (linked from text %r), the sources here "
+                                     "have text hash %r and do not compile to that code; rebuild it (__graft_entry__.build())"
+                        % (path, lib.build_id, _build.read_source_hash(path), _build.source_hash()))
     return lib
 
 

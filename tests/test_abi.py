@@ -61,36 +61,83 @@ def test_version_and_strerror(pkg):
     assert lib.ptmi_strerror(0) == b"ok" and lib.ptmi_strerror(-2) == b"no usable HIP device"
 
 
-def test_library_carries_the_hash_of_the_sources_it_was_built_from(pkg):
-    """ptmi_build_id() of the loaded library == the id read from the file == _build.source_hash() of the sources beside it."""
+def test_library_carries_the_id_of_the_code_it_holds(pkg):
+    """ptmi_build_id() of the loaded library == the id read from the file == _build.code_id(): the hash over the allocated sections
+    of the objects the present sources compile to.  The text hash it was linked from rides along, for staleness only."""
     lib = pkg.load_library()
-    want = pkg._build.source_hash()
+    want = pkg._build.code_id()
     assert re.fullmatch(r"[0-9a-f]{16}", want)
     assert lib.ptmi_build_id().decode() == want == lib.build_id
     assert pkg._build.read_build_id(pkg._build.LIB) == want
-    assert not pkg._build.is_stale()
-    assert pkg._build.build_id(["-DPTMI_ABLATIONS"]) == want + "+PTMI_ABLATIONS"
+    assert pkg._build.read_source_hash(pkg._build.LIB) == pkg._build.source_hash() != want
+    assert not pkg._build.is_stale() and pkg._build.matches_sources(pkg._build.LIB)
+    assert pkg._build.read_build_id(pkg._build.build_ablations_lib()) == pkg._build.code_id(["-DPTMI_ABLATIONS"])
+    assert pkg._build.code_id(["-DPTMI_ABLATIONS"]).endswith("+PTMI_ABLATIONS") and pkg._build.code_id(["-DPTMI_ABLATIONS"]).split("+")[0] != want
+
+
+def _copy_of_the_build(pkg, tmp_path):
+    """The package's build script, kernel sources, header and object cache under another root, imported as a module of its own."""
+    import importlib.util
+    import shutil
+    root = tmp_path / "checkout"
+    shutil.copytree(os.path.join(ROOT, "haskell-path-tracer_amd", "csrc"), root / "haskell-path-tracer_amd" / "csrc")
+    shutil.copytree(os.path.join(ROOT, "include"), root / "include")
+    shutil.copy(os.path.join(ROOT, "haskell-path-tracer_amd", "_build.py"), root / "haskell-path-tracer_amd" / "_build.py")
+    shutil.copytree(pkg._build.OBJ_ROOT, root / "build" / "obj")        # (digests are over contents and repository-relative names: valid in the copy)
+    shutil.copy(pkg._build.LIB, root / "haskell-path-tracer_amd" / "libptmi.so")
+    spec = importlib.util.spec_from_file_location("ptmi_build_copy", str(root / "haskell-path-tracer_amd" / "_build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return root, mod
+
+
+def test_a_comment_edit_keeps_the_build_id_and_a_code_edit_does_not(pkg, tmp_path):
+    """the id names the CODE.  In a copy of the checkout (another path: no path is in an object), a comment added
+    to ptmi_device.h -- every kernel unit includes it and is recompiled, every line of it moves down -- leaves code_id() and the
+    library's standing untouched; one changed constant in one unit changes the id and makes the library stale."""
+    root, b = _copy_of_the_build(pkg, tmp_path)
+    lib = str(root / "haskell-path-tracer_amd" / "libptmi.so")
+    want = pkg._build.code_id()
+    assert b.code_id() == want and not b.is_stale(lib)                       # the copy compiles nothing: its cache came along
+    device_h = root / "haskell-path-tracer_amd" / "csrc" / "ptmi_device.h"
+    text = device_h.read_text()
+    device_h.write_text("// a comment that was not here before,\n/* and a second\n   one */\n" + text.replace("// ", "//  ", 3))
+    small = root / "haskell-path-tracer_amd" / "csrc" / "ptmi_small.hip"
+    assert b.source_hash() != pkg._build.source_hash()                        # the TEXT moved ...
+    assert b.code_id() == want                                                # ... the code did not (eight units recompiled to find out)
+    assert not b.is_stale(lib) and b.matches_sources(lib)
+    src = small.read_text()
+    assert "255.0f" in src
+    small.write_text(src.replace("255.0f", "254.0f", 1))                       # ptmi_present's scale: one constant of one kernel
+    changed = b.code_id()
+    assert changed != want and re.fullmatch(r"[0-9a-f]{16}", changed)
+    assert b.is_stale(lib) and not b.matches_sources(lib)
 
 
 def test_a_library_built_from_other_sources_is_refused(pkg, tmp_path):
-    """A binary whose id is not the hash of the sources here (it travelled with edited sources, or comes from another checkout)
-    is refused by the binding and counts as stale for the build, whatever its file time says."""
+    """A binary that holds other code than the sources here compile to (it travelled with edited kernels, or comes from another
+    checkout) is refused by the binding and counts as stale for the build, whatever its file time says."""
     import shutil
-    want = pkg._build.source_hash().encode()
+    want = pkg._build.code_id().encode()
+    text = pkg._build.source_hash().encode()
     blob = open(pkg._build.LIB, "rb").read()
-    marker = pkg._build.BUILD_ID_MARKER + want
-    assert blob.count(marker) == 1
+    marker, text_marker = pkg._build.BUILD_ID_MARKER + want, pkg._build.SOURCE_HASH_MARKER + text
+    assert blob.count(marker) == 1 and blob.count(text_marker) == 1
     foreign = bytes(reversed(want)) if bytes(reversed(want)) != want else b"0" * 16
     other = tmp_path / "libptmi_foreign.so"
-    other.write_bytes(blob.replace(marker, pkg._build.BUILD_ID_MARKER + foreign))
+    other.write_bytes(blob.replace(marker, pkg._build.BUILD_ID_MARKER + foreign).replace(text_marker, pkg._build.SOURCE_HASH_MARKER + b"f" * 16))
     os.utime(other, (2 ** 31, 2 ** 31))                      # newer than every source: an mtime rule would call it current
     assert pkg._build.read_build_id(str(other)) == foreign.decode()
-    assert pkg._build.is_stale(str(other))
+    assert pkg._build.is_stale(str(other)) and not pkg._build.matches_sources(str(other))
     with pytest.raises(pkg.PtmiError) as e:
         pkg.binding.open_library(str(other))
     assert e.value.code == pkg.binding.PTMI_ESTATE and foreign.decode() in str(e.value)
     lib = pkg.binding.open_library(str(other), check_build_id=False)       # (the explicit way round the check, for archaeology)
     assert lib.build_id == foreign.decode()
+    same_code = tmp_path / "libptmi_edited_comments.so"                      # the right code under a stale text hash: accepted (a comment was edited)
+    same_code.write_bytes(blob.replace(text_marker, pkg._build.SOURCE_HASH_MARKER + b"e" * 16))
+    assert not pkg._build.is_stale(str(same_code))
+    assert pkg.binding.open_library(str(same_code)).build_id == want.decode()
     assert pkg._build.read_build_id(str(tmp_path / "missing.so")) is None
     shutil.copy(__file__, tmp_path / "not_a_library.so")
     assert pkg._build.read_build_id(str(tmp_path / "not_a_library.so")) is None

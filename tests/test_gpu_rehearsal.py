@@ -49,7 +49,7 @@ def test_bench_strong_scaling_rehearsal_gathers_the_one_context_image():
     assert col["render_only_ms_per_step"] > 0 and isinstance(col["gather_hidden_frac"], float)
     assert max(r["elapsed_ms_per_step"] for r in ranks) == pytest.approx(out["ms_per_step"], rel=1e-3)
     # ... and names the binary that produced it
-    assert out["binary_build_id"] == out["source_hash_now"]
+    assert out["binary_build_id"] == out["code_id_now"]
 
 
 def test_bench_weak_scaling_rehearsal_two_ranks():

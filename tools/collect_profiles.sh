@@ -15,8 +15,8 @@ for w in c2 streams glass_tree glass_stream s16_stream c5_tree c5_stream; do
     cp "$ROOT"/gpurun_out/pmc_$w/stats/*/*_kernel_stats.csv "$ROOT/profiles/${TAG}_kernel_stats_$w.csv"
 done
 cp "$SRC/valu_rates.json" "$ROOT/profiles/${TAG}_valu_rates.json"
-PTMI_PROFILE_SOURCE_HASH=$(cat "$SRC/source_hash.txt" 2>/dev/null) python3 "$ROOT/tools/valu_roofline.py" "$ROOT/profiles/${TAG}_pmc_c2.json" "$ROOT/profiles/${TAG}_valu_rates.json" "$TAG" > /dev/null
-PTMI_PROFILE_SOURCE_HASH=$(cat "$SRC/source_hash.txt" 2>/dev/null) python3 "$ROOT/tools/valu_roofline.py" streams "$TAG"
+PTMI_PROFILE_BUILD_ID=$(cat "$SRC/build_id.txt" 2>/dev/null) python3 "$ROOT/tools/valu_roofline.py" "$ROOT/profiles/${TAG}_pmc_c2.json" "$ROOT/profiles/${TAG}_valu_rates.json" "$TAG" > /dev/null
+PTMI_PROFILE_BUILD_ID=$(cat "$SRC/build_id.txt" 2>/dev/null) python3 "$ROOT/tools/valu_roofline.py" streams "$TAG"
 python3 - "$ROOT" "$TAG" <<'PY'
 import json, sys
 root, tag = sys.argv[1], sys.argv[2]

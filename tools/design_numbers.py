@@ -25,7 +25,7 @@ def main():
     b = load("%s_bench.json" % tag)
     r = b["roofline"]
     by_prefix = lambda p: next(e for e in b["also"] if e["workload"].startswith(p))      # noqa: E731
-    print("source hash of the profiles: %s; clock under the render kernel %.2f GHz" % (load("%s_valu_roofline.json" % tag).get("source_hash", "?"), load("%s_valu_roofline.json" % tag).get("clock_ghz", 0)))
+    print("build id of the profiled binary: %s; clock under the render kernel %.2f GHz" % (load("%s_valu_roofline.json" % tag).get("build_id", load("%s_valu_roofline.json" % tag).get("source_hash", "?")), load("%s_valu_roofline.json" % tag).get("clock_ghz", 0)))
     print()
     print("| Config | Device | Msamples/s | ms per step (kernel) | algorithmic GB/s (% of 8 TB/s) | note |")
     print("| C2 -- this round's run | 1x MI355X | **%s** | %.3f (%.3f) | %s (%.1f %%) | physical HBM %.0f MB per launch = %.0f GB/s (%.1f %%); VALU issue %.3f |"

@@ -14,7 +14,7 @@ cd /tmp; export TMPDIR=/tmp; cd "$ROOT"
 
 if [ "$PART" != "b" ]; then
 # 0. what this profile is a profile OF: the hash of kernel sources, headers and flags (bench.py says `stale` when they have moved on)
-python3 -c "import __graft_entry__ as g; print(g.load_package()._build.source_hash())" > "$OUT/source_hash.txt"
+python3 -c "import __graft_entry__ as g; print(g.load_package()._build.code_id())" > "$OUT/build_id.txt"
 # 1. the bench line as the driver runs it (N = 1, defaults), cpu_baseline included; C4 on one GPU (the N > 1 workload)
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.log"; echo "bench rc=$?"
 python3 bench.py --scaling strong --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c4_one_gpu.json" 2>> "$OUT/bench.log"; echo "bench C4 rc=$?"

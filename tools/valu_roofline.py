@@ -101,7 +101,7 @@ def streams(tag):
     """valu_roofline.py streams TAG -> profiles/<TAG>_valu_roofline_streams.json: the same accounting for the Streams kernels."""
     rates = json.load(open(os.path.join(ROOT, "profiles", "%s_valu_rates.json" % tag)))
     ops8 = rates["results"]["waves_per_simd_8"]["ops"]
-    source_hash = os.environ.get("PTMI_PROFILE_SOURCE_HASH") or graft.load_package()._build.source_hash()
+    fallback_id = os.environ.get("PTMI_PROFILE_BUILD_ID") or graft.load_package()._build.code_id()
     out = {}
     for key, kernel in STREAMS.items():
         path = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (tag, key))
@@ -135,16 +135,21 @@ def streams(tag):
         try:
             check_against_bench(name, rec, bench)
         except NotTheWorkload as e:
+            # a refused workload stays in the file, with the reason: bench.py leaves it out of `also[*].roofline`, and a reader of the
+            # tracked profile sees why (it used to vanish without a trace)
             print("REFUSED %s: %s" % (key, e), file=sys.stderr)
+            out[key] = {"refused": str(e), "kernel": name, "source": "profiles/%s_pmc_%s.json" % (tag, key)}
             continue
         a = account(name, rec, ops8)
         a.update({"workload": bench.get("workload"), "source": "profiles/%s_pmc_%s.json + profiles/%s_valu_rates.json" % (tag, key, tag),
                   "bench_kernel_us_under_rocprof": round(bench["kernel_ms_under_rocprof"] * 1e3, 1),
                   # the id the PROFILED binary carried (its bench line printed ptmi_build_id()); else what the profile round recorded
-                  "source_hash": (bench.get("binary_build_id") or source_hash).split("+")[0]})
+                  "build_id": (bench.get("binary_build_id") or fallback_id).split("+")[0]})
         out[key] = a
     json.dump(out, open(os.path.join(ROOT, "profiles", "%s_valu_roofline_streams.json" % tag), "w"), indent=1)
     for key, a in out.items():
+        if "refused" in a:
+            continue
         print("%-13s %-40s issue frac %.3f  active lanes %.3f  cycles / instr %.3f  HBM MB / call %s" % (
             key, a["kernel"][:40], a["frac_in_profile"], a["active_lane_frac"], a["measured_simd_cycles_per_instr"], a["hbm_MB_per_call"]))
 
@@ -164,7 +169,7 @@ def main():
                 "source": "rocprofv3 --pmc passes of tools/pmc_kernels.sh c2 (means over all launches of the run) + build/valu_rates",
                 "bench_kernel_us_under_rocprof": round(bench["kernel_ms_under_rocprof"] * 1e3, 1),
                 # the id the PROFILED binary carried (its bench line printed ptmi_build_id()); else what tools/profile_round.sh recorded
-                "source_hash": (bench.get("binary_build_id") or os.environ.get("PTMI_PROFILE_SOURCE_HASH") or graft.load_package()._build.source_hash()).split("+")[0]})
+                "build_id": (bench.get("binary_build_id") or os.environ.get("PTMI_PROFILE_BUILD_ID") or graft.load_package()._build.code_id()).split("+")[0]})
     path = os.path.join(ROOT, "profiles", "%s_valu_roofline.json" % tag)
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
