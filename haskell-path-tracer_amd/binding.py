@@ -14,11 +14,12 @@ from . import _build
 from .world import CAMERA_DTYPE, PLANE_DTYPE, SPHERE_DTYPE, INLINE, STREAMS
 
 OPT_STREAMS_SEED_RULE, OPT_STREAM_STEP_CAP, OPT_STREAM_CAPACITY, OPT_STREAMS_FORM, OPT_STREAM_BATCH, OPT_SPP_CHUNKS, OPT_ARITHMETIC = 1, 2, 3, 4, 5, 6, 7
-OPT_STREAM_TAIL, OPT_ORDERED_PASSES, OPT_GLASS_BATCH, OPT_STREAM_GRADED, OPT_SNAPSHOT_BUDGET_MB, OPT_STREAM_PASS_GROUPS = 8, 9, 10, 11, 12, 13
+OPT_STREAM_TAIL, OPT_ORDERED_PASSES, OPT_GLASS_BATCH, OPT_STREAM_GRADED, OPT_SNAPSHOT_BUDGET_MB, OPT_STREAM_PASS_GROUPS, OPT_CHAIN_SLOTS = 8, 9, 10, 11, 12, 13, 14
+CHAIN_CONSUME = 1
 ARITH_EXACT, ARITH_CONTRACTED = 0, 1
 SEED_KEEP_ACCUMULATOR, SEED_FROM_RESULT, SEED_AUTO = 0, 1, 2
 FORM_AUTO, FORM_STREAM = 0, 1
-PTMI_OK, PTMI_EINVAL, PTMI_ENODEVICE, PTMI_EHIP, PTMI_ENOMEM, PTMI_ESTATE, PTMI_ELIMIT = 0, -1, -2, -3, -4, -5, -6
+PTMI_OK, PTMI_EINVAL, PTMI_ENODEVICE, PTMI_EHIP, PTMI_ENOMEM, PTMI_ESTATE, PTMI_ELIMIT, PTMI_ESTALE = 0, -1, -2, -3, -4, -5, -6, -7
 
 # every symbol include/ptmi.h declares: name -> (restype, argtypes)
 _f32p, _u32p, _i32p, _i64p, _vp = (C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_int32),
@@ -29,6 +30,11 @@ class Stats(C.Structure):
     _fields_ = [("live_bounces", C.c_uint64), ("nominal_bounces", C.c_uint64), ("samples", C.c_uint64),
                 ("last_render_ms", C.c_float), ("stream_iterations", C.c_uint32), ("stream_rays_dropped", C.c_uint64),
                 ("stream_rays_truncated", C.c_uint64), ("stream_rays_spilled", C.c_uint64), ("stream_rays_overflowed", C.c_uint64)]
+
+
+class ChainStats(C.Structure):
+    _fields_ = [("states_on_device", C.c_uint32), ("states_on_host", C.c_uint32), ("device_slots", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("renders_chained", C.c_uint64), ("renders_in_place", C.c_uint64), ("renders_uploaded", C.c_uint64), ("evictions", C.c_uint64), ("fetches", C.c_uint64)]
 
 
 SYMBOLS = {
@@ -60,6 +66,12 @@ SYMBOLS = {
     "ptmi_synchronize": (C.c_int, [_vp]),
     "ptmi_render_blocks": (C.c_int, [_vp, C.c_int]),
     "ptmi_render1": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp] + [_vp] * 14),
+    "ptmi_render1_chained": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int] + [_vp] * 7 + [C.POINTER(C.c_uint64)] + [_vp] * 7),
+    "ptmi_chain_init_output": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "ptmi_chain_reseed": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_int, _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
+    "ptmi_chain_fetch": (C.c_int, [_vp, C.c_uint64] + [_vp] * 7),
+    "ptmi_chain_release": (C.c_int, [_vp, C.c_uint64]),
+    "ptmi_chain_info": (C.c_int, [_vp, C.POINTER(ChainStats)]),
     "ptmi_present": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "ptmi_snapshot_color": (C.c_int, [_vp, _vp, _vp]),
     "ptmi_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
@@ -330,6 +342,49 @@ class Context:
         self._check(self._lib.ptmi_render1(self._h, _ptr(cam), algorithm, bounce_limit, width, height,
                                            _ptr(sx), _ptr(sy), *[_ptr(a) for a in ins], *[_ptr(a) for a in outs]))
         return tuple(outs)
+
+    # -- the closure, chained (device residency behind compileFor's pure type) ----------
+    def render1_chained(self, camera, bounce_limit, width, height, token=0, planes_in=None, algorithm=INLINE, consume=False, fetch=()):
+        """One application of the closure to the state `token` names (or, if the context does not hold it, to the seven host planes
+        planes_in).  Returns (new token, {plane name: array} for the names in `fetch`, a subset of r g b sa sb sc sctr)."""
+        cam = np.ascontiguousarray(camera, dtype=CAMERA_DTYPE)
+        n = width * height
+        ins = [None] * 7
+        if planes_in is not None:
+            ins = [_host(a, np.float32, n) for a in planes_in[:3]] + [_host(a, np.uint32, n) for a in planes_in[3:]]
+        names = "r g b sa sb sc sctr".split()
+        outs = [np.empty((height, width), np.float32 if i < 3 else np.uint32) if names[i] in fetch else None for i in range(7)]
+        tok = C.c_uint64(0)
+        self._check(self._lib.ptmi_render1_chained(self._h, _ptr(cam), algorithm, bounce_limit, width, height, C.c_uint64(int(token)),
+                                                   CHAIN_CONSUME if consume else 0, *[_ptr(a) for a in ins], C.byref(tok), *[_ptr(a) for a in outs]))
+        return int(tok.value), {nm: a for nm, a in zip(names, outs) if a is not None}
+
+    def chain_init_output(self, width, height, seed0):
+        tok = C.c_uint64(0)
+        self._check(self._lib.ptmi_chain_init_output(self._h, width, height, C.c_uint64(seed0), C.byref(tok)))
+        return int(tok.value)
+
+    def chain_reseed(self, seed0, width, height, token=0, colour_in=None, consume=False):
+        ins = [None] * 3 if colour_in is None else [_host(a, np.float32, width * height) for a in colour_in]
+        tok = C.c_uint64(0)
+        self._check(self._lib.ptmi_chain_reseed(self._h, C.c_uint64(seed0), width, height, C.c_uint64(int(token)), CHAIN_CONSUME if consume else 0,
+                                                *[_ptr(a) for a in ins], C.byref(tok)))
+        return int(tok.value)
+
+    def chain_fetch(self, token, width, height, planes="r g b sa sb sc sctr"):
+        names = "r g b sa sb sc sctr".split()
+        want = planes.split() if isinstance(planes, str) else list(planes)
+        outs = [np.empty((height, width), np.float32 if i < 3 else np.uint32) if names[i] in want else None for i in range(7)]
+        self._check(self._lib.ptmi_chain_fetch(self._h, C.c_uint64(int(token)), *[_ptr(a) for a in outs]))
+        return tuple(a for a in outs if a is not None)
+
+    def chain_release(self, token):
+        self._check(self._lib.ptmi_chain_release(self._h, C.c_uint64(int(token))))
+
+    def chain_info(self):
+        st = ChainStats()
+        self._check(self._lib.ptmi_chain_info(self._h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in ChainStats._fields_}
 
     def present(self, iterations, rgb32f=True, rgba8=True):
         """graphicsLoop + fs.glsl: interleaved colour / iterations as float RGB and/or 8-bit RGBA."""

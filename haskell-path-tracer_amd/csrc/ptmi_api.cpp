@@ -9,7 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -125,6 +127,21 @@ struct ptmi_ctx {
     int opt_graded = 1;                        // PTMI_OPT_STREAM_GRADED: the split kernel's passes shrink towards the end of the launch
     int opt_snapshot_mb = 0;                   // PTMI_OPT_SNAPSHOT_BUDGET_MB: 0 = an eighth of the device's memory
     int opt_pass_groups = 0;                  // PTMI_OPT_STREAM_PASS_GROUPS: 0 = automatic, 1 = off, k = the last k passes are handed out region by region
+
+    // The chained closure (ptmi_render1_chained): the RenderResults the caller holds tokens for.  A state's seven planes are one device
+    // block (carve), or -- once it had to make room -- one host block of the same layout.  Blocks of released states wait in chain_free.
+    struct ChainState {
+        uint64_t token = 0;
+        int width = 0, height = 0;
+        void *block = nullptr;                 // device
+        std::unique_ptr<char[]> host;          // evicted: planes_bytes(n) bytes, carve's layout
+    };
+    std::vector<ChainState> chain;             // in token order (oldest first)
+    std::vector<std::pair<size_t, void *>> chain_free;   // (bytes, device block)
+    uint64_t chain_serial = 0;                 // this context's number in the process: the upper bits of its tokens
+    uint64_t chain_counter = 0;
+    int opt_chain_slots = 0;                   // PTMI_OPT_CHAIN_SLOTS: 0 = automatic
+    ptmi_chain_stats chain_stats{};
 };
 
 namespace {
@@ -823,6 +840,159 @@ int check_render_args(ptmi_ctx *c, const ptmi_camera *camera, int algorithm, int
     return PTMI_OK;
 }
 
+
+// ---- the chained closure: states under tokens (include/ptmi.h, "the closure, chained") ----------------------------------------
+// Token = (the context's serial number << 40) | a counter that starts at 1: never 0, never reused, another context's never matches.
+uint64_t chain_new_token(ptmi_ctx *c) { return (c->chain_serial << 40) | (++c->chain_counter & ((1ull << 40) - 1)); }
+
+int chain_find(ptmi_ctx *c, uint64_t token)
+{
+    if (token == 0) return -1;
+    for (size_t i = c->chain.size(); i-- > 0;)              // (the newest states are the ones asked for)
+        if (c->chain[i].token == token) return (int)i;
+    return -1;
+}
+
+int chain_slots(const ptmi_ctx *c, size_t bytes)
+{
+    if (c->opt_chain_slots > 0) return c->opt_chain_slots;
+    const size_t fit = (c->device_memory / 16) / (bytes ? bytes : 1);
+    return fit < 3 ? 3 : (fit > 64 ? 64 : (int)fit);
+}
+
+// A device block of `bytes` for a new state.  In this order: a block a released state left behind; a fresh allocation while fewer than
+// PTMI_OPT_CHAIN_SLOTS blocks exist; the block of the OLDEST state still on the device (but `keep`), whose planes first move to host
+// memory the library owns -- a state is never lost, only served from further away.
+int chain_take_block(ptmi_ctx *c, size_t bytes, uint64_t keep, void **out)
+{
+    for (size_t i = 0; i < c->chain_free.size(); ++i)
+        if (c->chain_free[i].first == bytes) { *out = c->chain_free[i].second; c->chain_free.erase(c->chain_free.begin() + (long)i); return PTMI_OK; }
+    if (!c->chain_free.empty()) {                            // blocks of another image size: of no use any more
+        PTMI_HIP(c, hipStreamSynchronize(c->stream));
+        for (auto &fb : c->chain_free) (void)hipFree(fb.second);
+        c->chain_free.clear();
+    }
+    size_t on_device = 0;
+    for (const ptmi_ctx::ChainState &st : c->chain) on_device += st.block ? 1 : 0;
+    if ((int)on_device < chain_slots(c, bytes)) {
+        if (hipMalloc(out, bytes) == hipSuccess) return PTMI_OK;
+        (void)hipGetLastError();                             // the device is full before the budget is: make room instead
+    }
+    for (ptmi_ctx::ChainState &st : c->chain) {
+        if (!st.block || st.token == keep) continue;
+        const size_t st_bytes = planes_bytes((size_t)st.width * st.height);
+        st.host.reset(new (std::nothrow) char[st_bytes]);
+        if (!st.host) return fail(c, PTMI_ENOMEM, "no host memory for a state of the chained closure that has to leave the device");
+        const CopySpan whole{st.block, st.host.get(), st_bytes};
+        PTMI_HIP(c, copy_to_host(c, &whole, 1));             // (drains the stream: nothing still reads the block)
+        ++c->chain_stats.evictions;
+        void *block = st.block;
+        st.block = nullptr;
+        if (st_bytes == bytes) { *out = block; return PTMI_OK; }
+        (void)hipFree(block);
+        PTMI_HIP(c, hipMalloc(out, bytes));
+        return PTMI_OK;
+    }
+    PTMI_HIP(c, hipMalloc(out, bytes));                       // nothing to move out (the budget is below what one call needs): allocate all the same
+    return PTMI_OK;
+}
+
+void chain_drop(ptmi_ctx *c, int idx)
+{
+    ptmi_ctx::ChainState &st = c->chain[(size_t)idx];
+    if (st.block) c->chain_free.emplace_back(planes_bytes((size_t)st.width * st.height), st.block);     // stream-ordered reuse: no wait
+    c->chain.erase(c->chain.begin() + idx);
+}
+
+// The state a chained call WRITES: token_in's planes in a block of its own (device-to-device copy, or in place when the caller gives the
+// input up), or -- token_in not held -- the caller's host planes uploaded (`planes_in`: seven pointers, or three with colour_only).  On
+// success *out_idx is a fresh entry at the end of c->chain, on the device, under a new token.
+int chain_begin(ptmi_ctx *c, int width, int height, uint64_t token_in, int flags, const void *const *planes_in, bool colour_only, int *out_idx)
+{
+    if (width <= 0 || height <= 0) return fail(c, PTMI_EINVAL, "width and height must be positive");
+    if (flags & ~PTMI_CHAIN_CONSUME) return fail(c, PTMI_EINVAL, "unknown flag");
+    const size_t n = (size_t)width * height, bytes = planes_bytes(n);
+    int in = chain_find(c, token_in);
+    if (in >= 0 && (c->chain[(size_t)in].width != width || c->chain[(size_t)in].height != height))
+        return fail(c, PTMI_EINVAL, "the token names a state of another image size");
+    ptmi_ctx::ChainState fresh;
+    fresh.width = width; fresh.height = height;
+    if (in < 0) {                                            // the copy path: the RenderResult comes from the host
+        const int n_planes = colour_only ? 3 : 7;
+        for (int i = 0; i < n_planes; ++i)
+            if (!planes_in || !planes_in[i])
+                return fail(c, PTMI_ESTALE, token_in ? "the token names no state this context holds, and no host planes were given to take its place"
+                                                     : "neither a token nor host planes were given");
+        if (int rc = chain_take_block(c, bytes, 0, &fresh.block)) return rc;
+        const Planes p = carve(fresh.block, n);
+        void *dev[7] = {p.r, p.g, p.b, p.sa, p.sb, p.sc, p.sctr};
+        CopySpan spans[7];
+        for (int i = 0; i < n_planes; ++i) spans[i] = CopySpan{dev[i], const_cast<void *>(planes_in[i]), n * 4};
+        hipError_t e = copy_to_device(c, spans, n_planes);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // the caller's planes are borrowed for the call only
+        if (e != hipSuccess) { c->chain_free.emplace_back(bytes, fresh.block); PTMI_HIP(c, e); }
+        ++c->chain_stats.renders_uploaded;
+    } else if (flags & PTMI_CHAIN_CONSUME) {                 // the caller gives the input up: its block becomes the output
+        ptmi_ctx::ChainState &src = c->chain[(size_t)in];
+        if (!src.block) {                                    // (it had moved to the host: back first)
+            if (int rc = chain_take_block(c, bytes, src.token, &src.block)) return rc;
+            const CopySpan whole{src.block, src.host.get(), bytes};
+            hipError_t e = copy_to_device(c, &whole, 1);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { c->chain_free.emplace_back(bytes, src.block); src.block = nullptr; PTMI_HIP(c, e); }
+            src.host.reset();
+        }
+        fresh.block = src.block;
+        src.block = nullptr;
+        c->chain.erase(c->chain.begin() + in);
+        ++c->chain_stats.renders_chained; ++c->chain_stats.renders_in_place;
+    } else {                                                 // the input stands: the sample is rendered into a copy
+        if (int rc = chain_take_block(c, bytes, token_in, &fresh.block)) return rc;
+        in = chain_find(c, token_in);                        // (the vector did not move, but be sure)
+        const ptmi_ctx::ChainState &src = c->chain[(size_t)in];
+        hipError_t e;
+        if (src.block) e = hipMemcpyAsync(fresh.block, src.block, bytes, hipMemcpyDeviceToDevice, c->stream);
+        else {
+            const CopySpan whole{fresh.block, src.host.get(), bytes};
+            e = copy_to_device(c, &whole, 1);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+        if (e != hipSuccess) { c->chain_free.emplace_back(bytes, fresh.block); PTMI_HIP(c, e); }
+        ++c->chain_stats.renders_chained;
+    }
+    fresh.token = chain_new_token(c);
+    c->chain.push_back(std::move(fresh));
+    *out_idx = (int)c->chain.size() - 1;
+    return PTMI_OK;
+}
+
+// (a call that fails after chain_begin must not leave a half-made state under a token nobody was told)
+void chain_abandon(ptmi_ctx *c, int idx) { chain_drop(c, idx); }
+
+int chain_download(ptmi_ctx *c, const ptmi_ctx::ChainState &st, void *const dst[7])
+{
+    const size_t n = (size_t)st.width * st.height;
+    bool any = false;
+    for (int i = 0; i < 7; ++i) any |= dst[i] != nullptr;
+    if (!any) return PTMI_OK;
+    ++c->chain_stats.fetches;
+    if (st.block) {
+        const Planes p = carve(st.block, n);
+        const void *src[7] = {p.r, p.g, p.b, p.sa, p.sb, p.sc, p.sctr};
+        CopySpan spans[7];
+        int k = 0;
+        for (int i = 0; i < 7; ++i)
+            if (dst[i]) spans[k++] = CopySpan{const_cast<void *>(src[i]), dst[i], n * 4};
+        PTMI_HIP(c, copy_to_host(c, spans, k));              // stream-ordered behind the renders; returns with the planes filled
+        return PTMI_OK;
+    }
+    const Planes p = carve(st.host.get(), n);
+    const void *src[7] = {p.r, p.g, p.b, p.sa, p.sb, p.sc, p.sctr};
+    for (int i = 0; i < 7; ++i)
+        if (dst[i]) std::memcpy(dst[i], src[i], n * 4);
+    return PTMI_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -839,6 +1009,7 @@ const char *ptmi_strerror(int code)
     case PTMI_ENOMEM: return "out of memory";
     case PTMI_ESTATE: return "call order violated";
     case PTMI_ELIMIT: return "scene exceeds PTMI_MAX_PRIMITIVES";
+    case PTMI_ESTALE: return "the token names no state this context holds";
     default: return "unknown error";
     }
 }
@@ -858,6 +1029,8 @@ int ptmi_create(ptmi_ctx **out, int device)
     ptmi_ctx *c = new (std::nothrow) ptmi_ctx;
     if (!c) return fail(nullptr, PTMI_ENOMEM, "host allocation failed");
     c->device = device;
+    static std::atomic<uint64_t> contexts_made{0};
+    c->chain_serial = ++contexts_made;
     auto bail = [&](hipError_t err, const char *what) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);
         ptmi_destroy(c);
@@ -922,6 +1095,8 @@ void ptmi_destroy(ptmi_ctx *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_snap) (void)hipEventDestroy(c->ev_snap);
     if (c->d_region_done) (void)hipFree(c->d_region_done);
+    for (ptmi_ctx::ChainState &st : c->chain) if (st.block) (void)hipFree(st.block);
+    for (auto &fb : c->chain_free) (void)hipFree(fb.second);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1140,6 +1315,9 @@ int ptmi_set_option(ptmi_ctx *c, int option, int64_t value)
     case PTMI_OPT_STREAM_PASS_GROUPS:
         if (value < 0 || value > 164 || (value > 64 && value < 102)) return fail(c, PTMI_EINVAL, "pass groups must be 0 (automatic), 1 (every pass on its own), k in [2, 64] or 100 + g, g in [2, 64]");
         c->opt_pass_groups = (int)value; return PTMI_OK;
+    case PTMI_OPT_CHAIN_SLOTS:
+        if (value != 0 && (value < 2 || value > 4096)) return fail(c, PTMI_EINVAL, "chain slots must be 0 (automatic) or in [2, 4096]");
+        c->opt_chain_slots = (int)value; return PTMI_OK;
     default: return fail(c, PTMI_EINVAL, "unknown option");
     }
 }
@@ -1163,6 +1341,7 @@ int ptmi_get_option(ptmi_ctx *c, int option, int64_t *value)
     case PTMI_OPT_STREAM_GRADED: *value = c->opt_graded; return PTMI_OK;
     case PTMI_OPT_STREAM_PASS_GROUPS: *value = c->opt_pass_groups; return PTMI_OK;
     case PTMI_OPT_SNAPSHOT_BUDGET_MB: *value = c->opt_snapshot_mb; return PTMI_OK;
+    case PTMI_OPT_CHAIN_SLOTS: *value = c->opt_chain_slots; return PTMI_OK;
     default: return fail(c, PTMI_EINVAL, "unknown option");
     }
 }
@@ -1317,6 +1496,102 @@ int ptmi_render1(ptmi_ctx *c, const ptmi_camera *camera, int algorithm, int boun
     CopySpan out[7];
     for (int i = 0; i < 7; ++i) out[i] = CopySpan{dev[i], dst[i], n * 4};
     PTMI_HIP(c, copy_to_host(c, out, 7));           // stream-ordered behind the kernel; returns with the planes filled
+    return PTMI_OK;
+}
+
+int ptmi_render1_chained(ptmi_ctx *c, const ptmi_camera *camera, int algorithm, int bounce_limit, int width, int height,
+                         uint64_t token_in, int flags,
+                         const float *r_in, const float *g_in, const float *b_in,
+                         const uint32_t *sa_in, const uint32_t *sb_in, const uint32_t *sc_in, const uint32_t *sctr_in,
+                         uint64_t *token_out,
+                         float *r_out, float *g_out, float *b_out,
+                         uint32_t *sa_out, uint32_t *sb_out, uint32_t *sc_out, uint32_t *sctr_out)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!token_out) return fail(c, PTMI_EINVAL, "token_out is NULL");
+    *token_out = 0;
+    if (int rc = check_render_args(c, camera, algorithm, bounce_limit, 1)) return rc;
+    PTMI_HIP(c, hipSetDevice(c->device));
+    const void *const planes_in[7] = {r_in, g_in, b_in, sa_in, sb_in, sc_in, sctr_in};
+    int idx = -1;
+    if (int rc = chain_begin(c, width, height, token_in, flags, planes_in, false, &idx)) return rc;
+    const Planes p = carve(c->chain[(size_t)idx].block, (size_t)width * height);
+    if (int rc = launch_render(c, p, camera, algorithm, bounce_limit, 1, width, height, height, height, 1, 0, nullptr, nullptr)) { chain_abandon(c, idx); return rc; }
+    void *const dst[7] = {r_out, g_out, b_out, sa_out, sb_out, sc_out, sctr_out};
+    if (int rc = chain_download(c, c->chain[(size_t)idx], dst)) { chain_abandon(c, idx); return rc; }
+    *token_out = c->chain[(size_t)idx].token;
+    return PTMI_OK;
+}
+
+int ptmi_chain_init_output(ptmi_ctx *c, int width, int height, uint64_t seed0, uint64_t *token_out)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!token_out) return fail(c, PTMI_EINVAL, "token_out is NULL");
+    *token_out = 0;
+    if (width <= 0 || height <= 0) return fail(c, PTMI_EINVAL, "width and height must be positive");
+    PTMI_HIP(c, hipSetDevice(c->device));
+    ptmi_ctx::ChainState fresh;
+    fresh.width = width; fresh.height = height;
+    const size_t n = (size_t)width * height;
+    if (int rc = chain_take_block(c, planes_bytes(n), 0, &fresh.block)) return rc;
+    const hipError_t e = launch_seed(carve(fresh.block, n), width, height, height, 1, 0, seed0, true, c->stream);
+    if (e != hipSuccess) { c->chain_free.emplace_back(planes_bytes(n), fresh.block); PTMI_HIP(c, e); }
+    fresh.token = chain_new_token(c);
+    *token_out = fresh.token;
+    c->chain.push_back(std::move(fresh));
+    return PTMI_OK;
+}
+
+int ptmi_chain_reseed(ptmi_ctx *c, uint64_t seed0, int width, int height, uint64_t token_in, int flags,
+                      const float *r_in, const float *g_in, const float *b_in, uint64_t *token_out)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!token_out) return fail(c, PTMI_EINVAL, "token_out is NULL");
+    *token_out = 0;
+    PTMI_HIP(c, hipSetDevice(c->device));
+    const void *const planes_in[7] = {r_in, g_in, b_in, nullptr, nullptr, nullptr, nullptr};
+    int idx = -1;
+    if (int rc = chain_begin(c, width, height, token_in, flags, planes_in, true, &idx)) return rc;
+    const hipError_t e = launch_seed(carve(c->chain[(size_t)idx].block, (size_t)width * height), width, height, height, 1, 0, seed0, false, c->stream);
+    if (e != hipSuccess) { chain_abandon(c, idx); PTMI_HIP(c, e); }
+    *token_out = c->chain[(size_t)idx].token;
+    return PTMI_OK;
+}
+
+int ptmi_chain_fetch(ptmi_ctx *c, uint64_t token, float *r, float *g, float *b, uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    const int idx = chain_find(c, token);
+    if (idx < 0) return fail(c, PTMI_ESTALE, "the token names no state this context holds");
+    PTMI_HIP(c, hipSetDevice(c->device));
+    void *const dst[7] = {r, g, b, sa, sb, sc, sctr};
+    return chain_download(c, c->chain[(size_t)idx], dst);
+}
+
+int ptmi_chain_release(ptmi_ctx *c, uint64_t token)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    const int idx = chain_find(c, token);
+    if (idx >= 0) chain_drop(c, idx);
+    return PTMI_OK;
+}
+
+int ptmi_chain_info(ptmi_ctx *c, ptmi_chain_stats *out)
+{
+    if (!c) return PTMI_EINVAL;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!out) return fail(c, PTMI_EINVAL, "out is NULL");
+    *out = c->chain_stats;
+    out->states_on_device = out->states_on_host = 0;
+    for (const ptmi_ctx::ChainState &st : c->chain) { if (st.block) ++out->states_on_device; else ++out->states_on_host; }
+    out->width = c->chain.empty() ? 0 : (uint32_t)c->chain.back().width;
+    out->height = c->chain.empty() ? 0 : (uint32_t)c->chain.back().height;
+    out->device_slots = (uint32_t)chain_slots(c, planes_bytes((size_t)(out->width ? out->width : 1) * (out->height ? out->height : 1)));
     return PTMI_OK;
 }
 

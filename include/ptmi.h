@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define PTMI_VERSION 500   /* 0.5.0: ptmi_build_id; ptmi_debug_counters writes 64 words again (as in 0.3) and ptmi_debug_counters_n takes a
+#define PTMI_VERSION 600   /* 0.6.0: the chained closure (ptmi_render1_chained, ptmi_chain_*: device residency behind compileFor's pure type), PTMI_ESTALE,
+                            * option 14; ptmi_build_id names the compiled code, not the source text.  0.5.0: ptmi_build_id; ptmi_debug_counters writes 64 words again (as in 0.3) and ptmi_debug_counters_n takes a
                             * capacity; option 13 and ptmi_stream_tickets; the stream form's overflow streams grow instead of dropping children;
                             * no option is read from the environment any more.  (0.4.0: options 8-12, ptmi_stream_schedule.) */
 
@@ -47,7 +48,8 @@ enum {
     PTMI_EHIP      = -3,   /* a HIP runtime call failed; message in ptmi_last_error          */
     PTMI_ENOMEM    = -4,   /* device or host allocation failed                                */
     PTMI_ESTATE    = -5,   /* call order violated (render before set_scene / resize ...)     */
-    PTMI_ELIMIT    = -6    /* scene larger than PTMI_MAX_PRIMITIVES                           */
+    PTMI_ELIMIT    = -6,   /* scene larger than PTMI_MAX_PRIMITIVES                           */
+    PTMI_ESTALE    = -7    /* a token names no state this context holds (released, consumed, or another context's) */
 };
 
 /* data Algorithm = Streams | Inline                       (src/Scene/Trace.hs:68) */
@@ -242,7 +244,11 @@ enum {
      * 16, 16 | 8 | 4, 4 at 1080p / 64 spp) -- the grading of the passes, which keeps the end of the launch short, is then untouched; 1 = every pass on
      * its own (round 4); k in [2, 64] = the LAST k passes as one group; 100 + g (g in [2, 64]) = groups of g passes all the way.
      * ptmi_stream_tickets is the order as a pure function. */
-    PTMI_OPT_STREAM_PASS_GROUPS = 13
+    PTMI_OPT_STREAM_PASS_GROUPS = 13,
+    /* PTMI_OPT_CHAIN_SLOTS: how many states of the chained closure (ptmi_render1_chained below) may stay on the DEVICE at a time; the oldest one
+     * beyond that moves to host memory the library owns (nothing is lost; ptmi_chain_fetch serves it from there).  0 (default) = automatic: what
+     * a sixteenth of the device's memory holds, at least 3, at most 64; otherwise k in [2, 4096]. */
+    PTMI_OPT_CHAIN_SLOTS = 14
 };
 enum { PTMI_ARITH_EXACT = 0, PTMI_ARITH_CONTRACTED = 1 };
 enum { PTMI_SEED_KEEP_ACCUMULATOR = 0, PTMI_SEED_FROM_RESULT = 1, PTMI_SEED_AUTO = 2 };
@@ -308,6 +314,57 @@ int ptmi_render1(ptmi_ctx *ctx, const ptmi_camera *camera, int algorithm, int bo
                  const uint32_t *sa_in, const uint32_t *sb_in, const uint32_t *sc_in, const uint32_t *sctr_in,
                  float *r_out, float *g_out, float *b_out,
                  uint32_t *sa_out, uint32_t *sb_out, uint32_t *sc_out, uint32_t *sctr_out);
+
+/* ---- the closure, chained: device residency behind compileFor's pure type ------------------------------------------------
+ * `dewit = runN (render config) screenPixels` (app/Main.hs:190) is a pure function of arrays, and on the reference's own GPU backend
+ * those arrays LIVE ON THE DEVICE: runN leaves its result there and copies it to the host lazily, when somebody reads it
+ * (graphicsLoop, app/Main.hs:350), and an argument that is a previous result is found on the device again and not uploaded.
+ * ptmi_render1 above moves all seven planes both ways on every call (1.07 ms per sample at 800x600 around a 0.03-ms kernel);
+ * these entry points give the closure runN's behaviour.  A STATE is one RenderResult (seven planes, width x height) held by the
+ * context under a TOKEN (never 0, never reused, meaningless to other contexts).  To the caller a state is an immutable value:
+ *   - ptmi_render1_chained(token_in) renders ONE sample from the state token_in names into a NEW state and returns its token; the
+ *     input state stands as it was, for ptmi_chain_fetch or for another call (rendering twice from one token gives the same planes
+ *     twice -- the closure is a function).  Nothing crosses PCIe; the call only enqueues.
+ *   - if token_in names no state the context holds (0; a released token; a RenderResult that came from elsewhere), the seven host
+ *     planes r_in .. sctr_in are uploaded instead -- ptmi_render1's copy path; if they are NULL too: PTMI_ESTALE.
+ *   - planes_out: each may be NULL; the ones given are downloaded at once (the call then waits for the render).  A lazy consumer
+ *     passes none and calls ptmi_chain_fetch when somebody reads a plane: colour for graphicsLoop, all seven on demand.
+ *   - a state is held until ptmi_chain_release(token) (a Haskell finalizer, a C++ destructor), or until a call CONSUMES it
+ *     (PTMI_CHAIN_CONSUME: the caller gives up token_in with the call; the sample is then rendered in place, without the
+ *     device-to-device copy that otherwise keeps the input intact -- the cost of a resident ptmi_render).  At most
+ *     PTMI_OPT_CHAIN_SLOTS states stay on the device; older ones move to host memory the library owns and are served from there.
+ * Any thread; calls are serialised by the context's mutex like all others.  The resident planes of ptmi_resize / ptmi_render and
+ * their partition are a separate matter and untouched. */
+enum { PTMI_CHAIN_CONSUME = 1 };
+int ptmi_render1_chained(ptmi_ctx *ctx, const ptmi_camera *camera, int algorithm, int bounce_limit, int width, int height,
+                         uint64_t token_in, int flags,
+                         const float *r_in, const float *g_in, const float *b_in,
+                         const uint32_t *sa_in, const uint32_t *sb_in, const uint32_t *sc_in, const uint32_t *sctr_in,
+                         uint64_t *token_out,
+                         float *r_out, float *g_out, float *b_out,
+                         uint32_t *sa_out, uint32_t *sb_out, uint32_t *sc_out, uint32_t *sctr_out);
+/* run <$> initialOutput (src/Util.hs:204-205; app/Main.hs:155, :306) as a state: colour 0, RNG from seed0 (ptmi_init_output's seeding). */
+int ptmi_chain_init_output(ptmi_ctx *ctx, int width, int height, uint64_t seed0, uint64_t *token_out);
+/* run <$> reseed acc (src/Util.hs:134-135; app/Main.hs:231): a NEW state with token_in's colour and fresh RNG states from seed0.  If
+ * token_in is not held the three colour planes r_in, g_in, b_in (host) are uploaded instead.  flags: PTMI_CHAIN_CONSUME as above. */
+int ptmi_chain_reseed(ptmi_ctx *ctx, uint64_t seed0, int width, int height, uint64_t token_in, int flags,
+                      const float *r_in, const float *g_in, const float *b_in, uint64_t *token_out);
+/* The planes of a held state into host memory; NULL pointers are skipped.  Waits for the renders that produce the state. */
+int ptmi_chain_fetch(ptmi_ctx *ctx, uint64_t token, float *r, float *g, float *b,
+                     uint32_t *sa, uint32_t *sb, uint32_t *sc, uint32_t *sctr);
+/* The caller will not name this token again.  Releasing a token that is not held (already released or consumed) is PTMI_OK. */
+int ptmi_chain_release(ptmi_ctx *ctx, uint64_t token);
+typedef struct ptmi_chain_stats {
+    uint32_t states_on_device, states_on_host;    /* held now */
+    uint32_t device_slots;                         /* PTMI_OPT_CHAIN_SLOTS in force */
+    uint32_t width, height;                        /* of the newest state (0 when none is held) */
+    uint64_t renders_chained;                      /* ptmi_render1_chained / ptmi_chain_reseed calls that found their input on the device ... */
+    uint64_t renders_in_place;                     /* ... of which PTMI_CHAIN_CONSUME spared the copy                                         */
+    uint64_t renders_uploaded;                     /* calls that took the copy path (host planes in)                                           */
+    uint64_t evictions;                            /* states moved to host memory to make room                                                 */
+    uint64_t fetches;                              /* ptmi_chain_fetch calls and planes_out downloads                                          */
+} ptmi_chain_stats;
+int ptmi_chain_info(ptmi_ctx *ctx, ptmi_chain_stats *out);
 
 /* ---- present (what graphicsLoop + fs.glsl do with the result) ------------------- */
 /* graphicsLoop interleaves the three colour planes (`V.zipWith3 V3 r g b`, app/Main.hs:351), uploads them

@@ -57,7 +57,7 @@ def test_binding_constants_equal_the_headers_enumerators(pkg):
 
 def test_version_and_strerror(pkg):
     lib = pkg.load_library()
-    assert lib.ptmi_version() == 500
+    assert lib.ptmi_version() == 600
     assert lib.ptmi_strerror(0) == b"ok" and lib.ptmi_strerror(-2) == b"no usable HIP device"
 
 
