@@ -213,6 +213,45 @@ def also_measurements(pkg, torch):
 
     run("C0: 800x600, mainScene, limit 15, render Inline, 1 spp per call (the reference's own configuration; compileFor's closure)", "main", 800, 600, 1, 15, pkg.INLINE, warm=40, steps=20)
     run("C0 at 30 spp per call (the reference's batch size, app/Main.hs:209-211)", "main", 800, 600, 30, 15, pkg.INLINE, warm=20, steps=10)
+
+    def closure(name, chained, calls, note):
+        """C0 through compileFor's closure itself -- one call = one sample, RenderResult in, RenderResult out: `chained` on
+        ptmi_render1_chained (the result stays on the device under a token, the next call finds it there; the input token is released 32
+        calls late, as a Haskell finalizer would), else on ptmi_render1 (seven host planes each way per call).  Wall clock per call over
+        `calls` calls, the queue drained at the end."""
+        sp, pl = scenes["main"]
+        with pkg.Context(0) as c:
+            c.set_scene(sp, pl)
+            if chained:
+                toks = [c.chain_init_output(800, 600, SEED0)]
+                def one():
+                    toks.append(c.render1_chained(cam, 15, 800, 600, toks[-1])[0])
+                    if len(toks) > 33:
+                        c.chain_release(toks.pop(0))
+            else:
+                c.resize(800, 600)
+                c.init_output(SEED0)
+                state = {"p": list(c.download_state())}
+                def one():
+                    state["p"] = list(c.render1(cam, 15, 800, 600, state["p"]))
+            for _ in range(40 if chained else 5):
+                one()
+            c.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                one()
+            c.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3 / calls
+            info = c.chain_info() if chained else None
+        rec = {"workload": name, "ms_per_step": round(ms, 4), "kernel_ms": None, "steps": calls, "note": note,
+               "Msamples_per_s": round(800 * 600 * 15 / (ms * 1e-3) / 1e6, 1)}
+        if info:
+            rec["chain"] = {k: info[k] for k in ("renders_chained", "renders_uploaded", "evictions", "states_on_device", "states_on_host")}
+        out.append(rec)
+    closure("C0 through the compatible closure, chained (ptmi_render1_chained: compileFor's pure type, results left on the device; what haskell/patches/Main.hs.diff wires)",
+            True, 400, "wall clock per closure call; nothing is fetched (graphicsLoop's read of three colour planes costs ~0.27 ms when it happens)")
+    closure("C0 through the compatible closure, copying (ptmi_render1: seven host planes in and out per call; the closure until 0.5)",
+            False, 30, "wall clock per closure call, PCIe both ways inside")
     run("C3: 3840x2160, 256 spp, limit 8, S16, render Inline", "s16", 3840, 2160, 256, BOUNCE_LIMIT, pkg.INLINE)
     run("C4: 3840x2160, 1024 spp, limit 8, S16, render Inline, the whole image on one GPU", "s16", 3840, 2160, 1024, BOUNCE_LIMIT, pkg.INLINE, warm=2)
     run("C4, one part of 8 (10-row stripes): what one rank of the 8-GPU job renders", "s16", 3840, 2160, 1024, BOUNCE_LIMIT, pkg.INLINE, part_of=8)

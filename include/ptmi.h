@@ -387,7 +387,8 @@ int ptmi_reset_stats(ptmi_ctx *ctx);
  * -DPTMI_PHASE_STATS and the others listed in csrc/ptmi_diag.h -- add their statistics, see tools/phase_stats.py).
  * ptmi_debug_counters writes the first 64 words (its contract since 0.3; 0.4 wrote 256 into the same argument and overran a
  * caller built against 0.3); ptmi_debug_counters_n writes min(capacity, 256) words and returns how many, or a negative code.
- * Both synchronise the launch stream. */
+ * A caller built against 0.4 that passes a 256-word buffer to ptmi_debug_counters gets PTMI_OK and words 64 to 255 LEFT AS THEY WERE:
+ * it must move to ptmi_debug_counters_n to see the diagnostic builds' statistics.  Both synchronise the launch stream. */
 int ptmi_debug_counters(ptmi_ctx *ctx, uint32_t out[64]);
 int ptmi_debug_counters_n(ptmi_ctx *ctx, uint32_t *out, int capacity);
 

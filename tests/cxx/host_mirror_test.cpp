@@ -2,6 +2,7 @@
 // way app/Main.hs uses the original: compileFor -> initialOutput -> apply the closure -> reseed, at the
 // reference's native 800x600 / 15 bounces / mainScene, and checks the result against the CPU oracle
 // (test infrastructure) bit for bit.  Built and run by tests/test_host_cxx.py.
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 
@@ -17,6 +18,22 @@ static bool same(const void *a, const void *b, size_t bytes, const char *what)
     return false;
 }
 
+// the oracle's working copy of a RenderResult: seven host planes it renders into
+struct Planes7 {
+    std::vector<float> r, g, b;
+    std::vector<uint32_t> a, b2, c, counter;
+    explicit Planes7(const RenderResult &v) : r(v.r()), g(v.g()), b(v.b()), a(v.sfc_a()), b2(v.sfc_b()), c(v.sfc_c()), counter(v.sfc_counter()) {}
+    bool equals(const RenderResult &v, const char *what) const
+    {
+        bool ok = true;
+        const size_t bytes = r.size() * 4;
+        ok &= same(r.data(), v.r().data(), bytes, what); ok &= same(g.data(), v.g().data(), bytes, what); ok &= same(b.data(), v.b().data(), bytes, what);
+        ok &= same(a.data(), v.sfc_a().data(), bytes, what); ok &= same(b2.data(), v.sfc_b().data(), bytes, what);
+        ok &= same(c.data(), v.sfc_c().data(), bytes, what); ok &= same(counter.data(), v.sfc_counter().data(), bytes, what);
+        return ok;
+    }
+};
+
 int main()
 {
     try {
@@ -24,10 +41,8 @@ int main()
         Device dev(0, W, H, World::mainScene());
         const CompiledFunction compute = compileFor(dev, Trace::Algorithm::Inline);   // app/Main.hs:154
         const Camera camera = World::initialCamera();
-        RenderResult seeds = Util::initialOutput(dev, 0x5EED1234ull);                  // app/Main.hs:155
+        const RenderResult seeds = Util::initialOutput(dev, 0x5EED1234ull);            // app/Main.hs:155
 
-        // oracle-side copy of the initial state and scene
-        RenderResult want = seeds;
         std::vector<ora_sphere> sp; std::vector<ora_plane> pl;
         for (const Sphere &s : World::mainScene().spheres)
             sp.push_back(ora_sphere{{s.position.x, s.position.y, s.position.z}, s.radius,
@@ -38,58 +53,101 @@ int main()
                                    {p.material.color.x, p.material.color.y, p.material.color.z}, p.material.illuminance,
                                    p.material.brdf.tag, p.material.brdf.parameter});
         const ora_scene scene{sp.data(), (int)sp.size(), pl.data(), (int)pl.size()};
-        const ora_camera ocam{{camera.position.x, camera.position.y, camera.position.z},
-                              {camera.rotation.x, camera.rotation.y, camera.rotation.z}, camera.fov};
+        auto oracle_camera = [](const Camera &c) { return ora_camera{{c.position.x, c.position.y, c.position.z}, {c.rotation.x, c.rotation.y, c.rotation.z}, c.fov}; };
+        auto oracle_samples = [&](Planes7 &p, const Camera &c, int n) {
+            const ora_camera oc = oracle_camera(c);
+            ora_render_inline(&scene, &oc, W, H, 15, n, nullptr, nullptr, p.r.data(), p.g.data(), p.b.data(),
+                              p.a.data(), p.b2.data(), p.c.data(), p.counter.data(), ora_max_threads());
+        };
         bool ok = true;
         {   // genSeeds made deterministic: device seeding == oracle seeding
             std::vector<uint32_t> a(W * H), b(W * H), c(W * H), d(W * H);
             ora_gen_seeds(0x5EED1234ull, 0, (int64_t)W * H, a.data(), b.data(), c.data(), d.data());
-            ok &= same(a.data(), seeds.sfc_a.data(), a.size() * 4, "seed plane a");
-            ok &= same(d.data(), seeds.sfc_counter.data(), d.size() * 4, "seed plane counter");
+            ok &= same(a.data(), seeds.sfc_a().data(), a.size() * 4, "seed plane a");
+            ok &= same(d.data(), seeds.sfc_counter().data(), d.size() * 4, "seed plane counter");
         }
         // value = compute' initialCamera (0, seeds), then once more   (app/Main.hs:157, :209-211)
+        Planes7 want(seeds);
         std::pair<int, RenderResult> value{0, seeds};
         value = compute(camera, value);
         value = compute(camera, value);
         ok &= value.first == 2;
-        ora_render_inline(&scene, &ocam, W, H, 15, 2, nullptr, nullptr, want.r.data(), want.g.data(), want.b.data(),
-                          want.sfc_a.data(), want.sfc_b.data(), want.sfc_c.data(), want.sfc_counter.data(), ora_max_threads());
-        ok &= same(want.r.data(), value.second.r.data(), want.r.size() * 4, "r");
-        ok &= same(want.g.data(), value.second.g.data(), want.g.size() * 4, "g");
-        ok &= same(want.b.data(), value.second.b.data(), want.b.size() * 4, "b");
-        ok &= same(want.sfc_a.data(), value.second.sfc_a.data(), want.sfc_a.size() * 4, "sfc a");
-        ok &= same(want.sfc_b.data(), value.second.sfc_b.data(), want.sfc_b.size() * 4, "sfc b");
-        ok &= same(want.sfc_c.data(), value.second.sfc_c.data(), want.sfc_c.size() * 4, "sfc c");
-        ok &= same(want.sfc_counter.data(), value.second.sfc_counter.data(), want.sfc_counter.size() * 4, "sfc counter");
+        ok &= !value.second.onHost();                                // nothing has come down yet
+        oracle_samples(want, camera, 2);
+        ok &= want.equals(value.second, "closure, 2 samples");
+        const Planes7 after2 = want;
         // reseed keeps the colour (Util.hs:134-135)
         const RenderResult reseeded = Util::reseed(dev, 99, value.second);
-        ok &= same(reseeded.r.data(), value.second.r.data(), reseeded.r.size() * 4, "colour after reseed");
-        ok &= std::memcmp(reseeded.sfc_a.data(), value.second.sfc_a.data(), reseeded.sfc_a.size() * 4) != 0;
+        ok &= same(reseeded.r().data(), value.second.r().data(), reseeded.r().size() * 4, "colour after reseed");
+        ok &= std::memcmp(reseeded.sfc_a().data(), value.second.sfc_a().data(), reseeded.sfc_a().size() * 4) != 0;
+
+        // ---- the closure as computationLoop drives it, with the values left on the device:
+        // 100 single-sample calls, a reseed, a camera move (fresh initialOutput, moved camera, three samples) == the oracle;
+        // intermediate values die as the loop goes on (their tokens are released by the last copy's destructor).
+        {
+            std::pair<int, RenderResult> v{0, seeds};
+            Planes7 ref(seeds);
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int k = 0; k < 100; ++k) v = compute(camera, v);
+            dev.check(ptmi_synchronize(dev.get()));
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 100.0;
+            std::printf("chained closure: %.1f us per call (800x600, 100 calls, nothing fetched)\n", us);
+            oracle_samples(ref, camera, 100);
+            ok &= v.first == 100 && ref.equals(v.second, "closure, 100 chained samples");
+            ptmi_chain_stats info{};
+            dev.check(ptmi_chain_info(dev.get(), &info));
+            ok &= info.renders_uploaded == 0 && info.evictions == 0;                // every input was found on the device
+            if (info.renders_uploaded != 0 || info.evictions != 0) std::printf("MISMATCH: %llu uploads, %llu evictions in the chain\n", (unsigned long long)info.renders_uploaded, (unsigned long long)info.evictions);
+            // run <$> reseed acc (app/Main.hs:231), then a sample
+            v.second = Util::reseed(dev, 4242, v.second);
+            ora_gen_seeds(4242, 0, (int64_t)W * H, ref.a.data(), ref.b2.data(), ref.c.data(), ref.counter.data());
+            v = compute(camera, v);
+            oracle_samples(ref, camera, 1);
+            ok &= ref.equals(v.second, "closure, reseed + 1 sample");
+            // the camera moves: emptyOutput <- initialOutput; compute updatedCamera (0, emptyOutput)   (app/Main.hs:306-319)
+            Camera moved = camera;
+            moved.position.x += 0.75f; moved.rotation.x += 0.1f;
+            std::pair<int, RenderResult> m{0, Util::initialOutput(dev, 7)};
+            Planes7 mref(m.second);
+            for (int k = 0; k < 3; ++k) m = compute(moved, m);
+            oracle_samples(mref, moved, 3);
+            ok &= m.first == 3 && mref.equals(m.second, "closure, camera move + 3 samples");
+            // an input that is NOT a result of this device: host planes (a result from elsewhere), and another device context's result
+            const RenderResult from_host = RenderResult::fromHost(W, H, after2.r, after2.g, after2.b, after2.a, after2.b2, after2.c, after2.counter);
+            std::pair<int, RenderResult> h = compute(camera, std::make_pair(2, from_host));
+            Planes7 href = after2;
+            oracle_samples(href, camera, 1);
+            ok &= h.first == 3 && href.equals(h.second, "closure on host planes (copy path)");
+            dev.check(ptmi_chain_info(dev.get(), &info));
+            ok &= info.renders_uploaded == 1;
+            {
+                Device other(0, W, H, World::mainScene());
+                const RenderResult theirs = compileFor(other, Trace::Algorithm::Inline)(camera, std::make_pair(0, Util::initialOutput(other, 0x5EED1234ull))).second;
+                const RenderResult ours = compute(camera, std::make_pair(1, theirs)).second;     // their token means nothing here: the planes travel
+                ok &= after2.equals(ours, "closure on another context's result (copy path)");
+            }
+            // the copying closure (ptmi_render1) gives the same planes
+            const RenderResult copied = compileForCopying(dev, Trace::Algorithm::Inline)(camera, std::make_pair(2, from_host)).second;
+            ok &= copied.onHost() && href.equals(copied, "compileForCopying");
+        }
+
         // ---- the resident flow at the same size (INTEGRATION.md "resident wiring"): computationLoop's batching
         // (single samples up to 100 iterations, then doTimes batchSize, app/Main.hs:208-211), a reseed in between
         // (:231), the read-outs graphicsLoop needs (:346-351) -- against the oracle doing the same sample by sample.
         {
             Resident res(dev, Trace::Algorithm::Inline);
             res.reset(0x5EED1234ull);
-            RenderResult ref = seeds;
-            auto oracle_samples = [&](int n) {
-                ora_render_inline(&scene, &ocam, W, H, 15, n, nullptr, nullptr, ref.r.data(), ref.g.data(), ref.b.data(),
-                                  ref.sfc_a.data(), ref.sfc_b.data(), ref.sfc_c.data(), ref.sfc_counter.data(), ora_max_threads());
-            };
+            Planes7 ref(seeds);
             res.compute(camera); res.compute(camera); res.compute(camera);          // three single samples
             res.compute(camera, 30);                                                 // doTimes 30
-            oracle_samples(33);
+            oracle_samples(ref, camera, 33);
             ok &= res.iterations() == 33;
-            RenderResult got = res.value();
-            ok &= same(ref.r.data(), got.r.data(), ref.r.size() * 4, "resident r after 33 samples");
-            ok &= same(ref.sfc_c.data(), got.sfc_c.data(), ref.sfc_c.size() * 4, "resident sfc c after 33 samples");
+            ok &= ref.equals(res.value(), "resident, 33 samples");
             res.reseed(4242);                                                        // run <$> reseed acc
-            ora_gen_seeds(4242, 0, (int64_t)W * H, ref.sfc_a.data(), ref.sfc_b.data(), ref.sfc_c.data(), ref.sfc_counter.data());
+            ora_gen_seeds(4242, 0, (int64_t)W * H, ref.a.data(), ref.b2.data(), ref.c.data(), ref.counter.data());
             res.compute(camera, 7);
-            oracle_samples(7);
-            got = res.value();
-            ok &= same(ref.g.data(), got.g.data(), ref.g.size() * 4, "resident g after reseed + 7");
-            ok &= same(ref.sfc_a.data(), got.sfc_a.data(), ref.sfc_a.size() * 4, "resident sfc a after reseed + 7");
+            oracle_samples(ref, camera, 7);
+            ok &= ref.equals(res.value(), "resident, reseed + 7");
             std::vector<float> cr, cg, cb, rgb; std::vector<uint8_t> rgba;
             res.colour(cr, cg, cb);
             ok &= same(ref.b.data(), cb.data(), cb.size() * 4, "colour planes for graphicsLoop");
@@ -109,7 +167,8 @@ int main()
         }
         // error behaviour: exception with a code, like a Haskell exception out of runN
         try { Device bad(1 << 20); ok = false; } catch (const PtmiError &e) { ok &= e.code == PTMI_ENODEVICE; }
-        std::printf(ok ? "host mirror OK (800x600, 15 bounces: closure flow 2 samples, resident flow 40 samples with batching, reseed and present -- bit-identical to the oracle)\n" : "host mirror FAILED\n");
+        std::printf(ok ? "host mirror OK (800x600, 15 bounces: chained closure 2 + 100 samples with reseed, camera move and foreign inputs, copying closure, "
+                         "resident flow 40 samples with batching, reseed and present -- bit-identical to the oracle)\n" : "host mirror FAILED\n");
         return ok ? 0 : 1;
     } catch (const PtmiError &e) {
         std::printf("PtmiError %d: %s\n", e.code, e.what());
