@@ -627,17 +627,25 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
     // children found no room the planes are put back, the streams doubled (up to kMaxStreamRaysPerPixel rays per pixel, or to what the device
     // still has) and the launch and its levels run again.  The capacity a call reached is kept for later calls.  Only with GLASS: nothing else emits.
     const size_t plane_bytes = n * sizeof(float);
-    if (c->has_glass) {
-        if (3 * plane_bytes > c->colour_backup_bytes) {
+    // (only while a redo is possible: with the streams at kMaxStreamRaysPerPixel already the drops would stand, and nothing is copied aside.
+    // The recorded quad costs of the launch are part of what a redo must take back: the failed attempt's items added theirs.)
+    const size_t cost_bytes = a.quad_cost ? (size_t)quad_positions(a.width, a.rows_local) * sizeof(unsigned int) : 0;
+    const bool can_redo = c->has_glass && cap_rays < kMaxStreamRaysPerPixel;
+    if (can_redo) {
+        if (3 * plane_bytes + cost_bytes > c->colour_backup_bytes) {
             PTMI_HIP(c, hipStreamSynchronize(c->stream));
             if (c->colour_backup) { (void)hipFree(c->colour_backup); c->colour_backup = nullptr; c->colour_backup_bytes = 0; }
-            PTMI_HIP(c, hipMalloc(&c->colour_backup, 3 * plane_bytes));
-            c->colour_backup_bytes = 3 * plane_bytes;
+            PTMI_HIP(c, hipMalloc(&c->colour_backup, 3 * plane_bytes + cost_bytes));
+            c->colour_backup_bytes = 3 * plane_bytes + cost_bytes;
         }
         char *bk = static_cast<char *>(c->colour_backup);
         PTMI_HIP(c, hipMemcpyAsync(bk, a.planes.r, plane_bytes, hipMemcpyDeviceToDevice, c->stream));
         PTMI_HIP(c, hipMemcpyAsync(bk + plane_bytes, a.planes.g, plane_bytes, hipMemcpyDeviceToDevice, c->stream));
         PTMI_HIP(c, hipMemcpyAsync(bk + 2 * plane_bytes, a.planes.b, plane_bytes, hipMemcpyDeviceToDevice, c->stream));
+        if (cost_bytes) PTMI_HIP(c, hipMemcpyAsync(bk + 3 * plane_bytes, a.quad_cost, cost_bytes, hipMemcpyDeviceToDevice, c->stream));
+    } else if (c->colour_backup && !c->has_glass) {          // the scene lost its GLASS: the three planes' worth of memory goes back
+        PTMI_HIP(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->colour_backup); c->colour_backup = nullptr; c->colour_backup_bytes = 0;
     }
     unsigned long long overflowed = 0;
     for (int attempt = 0;; ++attempt) {
@@ -673,11 +681,19 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
             if (int rc = read_counters(level + 1)) return rc;
         }
         const unsigned int dropped = raw[(size_t)kLvDropped * kCounterStride];
-        if (!c->has_glass || dropped == 0u || cap_rays >= kMaxStreamRaysPerPixel) break;
-        // ---- children were dropped: longer streams, the planes put back, once more
-        const int grown = cap_rays * 2 < kMaxStreamRaysPerPixel ? cap_rays * 2 : kMaxStreamRaysPerPixel;
-        size_t need = n * (size_t)grown;
-        if (need < floor_slots) need = floor_slots;
+        if (!can_redo || dropped == 0u || cap_rays >= kMaxStreamRaysPerPixel) break;
+        // ---- children were dropped: longer streams, the planes put back, once more.  "Longer" must be true: the block may be larger than
+        // rays-per-pixel x pixels says (the floor of the waves' static blocks, a block left over from a larger image, a lowered
+        // PTMI_OPT_STREAM_CAPACITY), and a redo into streams of the same length drops the same children again -- so the capacity doubles until
+        // it asks for more than is there; if even kMaxStreamRaysPerPixel does not, the drops stand, counted.
+        int grown = cap_rays;
+        size_t need = 0;
+        do {
+            grown = grown * 2 < kMaxStreamRaysPerPixel ? grown * 2 : kMaxStreamRaysPerPixel;
+            need = n * (size_t)grown;
+            if (need < floor_slots) need = floor_slots;
+        } while (need <= capacity && grown < kMaxStreamRaysPerPixel);
+        if (need <= capacity) { c->grown_capacity = grown; break; }
         if (need > 0xfffffff0ull) break;
         if (need > c->queue_capacity) {
             void *bigger = nullptr;
@@ -692,6 +708,7 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
         PTMI_HIP(c, hipMemcpyAsync(a.planes.r, bk, plane_bytes, hipMemcpyDeviceToDevice, c->stream));
         PTMI_HIP(c, hipMemcpyAsync(a.planes.g, bk + plane_bytes, plane_bytes, hipMemcpyDeviceToDevice, c->stream));
         PTMI_HIP(c, hipMemcpyAsync(a.planes.b, bk + 2 * plane_bytes, plane_bytes, hipMemcpyDeviceToDevice, c->stream));
+        if (cost_bytes) PTMI_HIP(c, hipMemcpyAsync(a.quad_cost, bk + 3 * plane_bytes, cost_bytes, hipMemcpyDeviceToDevice, c->stream));
         // every counter of the call starts over -- but for the split pixels' count, which the primary kernel wrote and which is not run again
         const unsigned int split_pixels = raw[(size_t)kLvSplitPixels * kCounterStride];
         PTMI_HIP(c, hipMemsetAsync(c->d_qcount, 0, (size_t)kLvWords * sizeof(unsigned int), c->stream));
@@ -1151,6 +1168,7 @@ int ptmi_resize(ptmi_ctx *c, int width, int height)
     PTMI_HIP(c, hipSetDevice(c->device));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
     if (c->owned_block) { (void)hipFree(c->owned_block); c->owned_block = nullptr; }
+    if (c->colour_backup) { (void)hipFree(c->colour_backup); c->colour_backup = nullptr; c->colour_backup_bytes = 0; }   // (sized by the old image)
     c->width = width; c->height = height;
     c->rows_local = rows_of_part(height, effective_stripe(c), c->n_parts, c->part);
     c->use_bound = false;
@@ -1284,7 +1302,13 @@ int ptmi_set_option(ptmi_ctx *c, int option, int64_t value)
         c->opt_step_cap = (int)value; return PTMI_OK;
     case PTMI_OPT_STREAM_CAPACITY:
         if (value < 1 || value > 64) return fail(c, PTMI_EINVAL, "stream capacity must be in [1, 64] rays per pixel-sample");
-        c->opt_capacity = (int)value; c->grown_capacity = 0; return PTMI_OK;
+        c->opt_capacity = (int)value; c->grown_capacity = 0;
+        if (c->queue_block) {                                // "starts over from the value given": the streams are carved anew by the next call
+            PTMI_HIP(c, hipSetDevice(c->device));
+            PTMI_HIP(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(c->queue_block); c->queue_block = nullptr; c->queue_capacity = 0;
+        }
+        return PTMI_OK;
     case PTMI_OPT_STREAMS_FORM:
         if (value != PTMI_FORM_AUTO && value != PTMI_FORM_STREAM) return fail(c, PTMI_EINVAL, "unknown Streams form");
         c->opt_form = (int)value; return PTMI_OK;
