@@ -185,8 +185,7 @@ def also_measurements(pkg, torch):
             if part_of > 1:
                 c.set_partition(stripe, part_of, part)
             c.resize(width, height)
-            if stream_form:
-                c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+            c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM if stream_form else B.FORM_PIXEL)     # (each line names its form: AUTO would pick the stream form for a glass part)
             c.init_output(SEED0)
             c.set_timing(True)
             for _ in range(warm):
@@ -255,8 +254,8 @@ def also_measurements(pkg, torch):
     run("C3: 3840x2160, 256 spp, limit 8, S16, render Inline", "s16", 3840, 2160, 256, BOUNCE_LIMIT, pkg.INLINE)
     run("C4: 3840x2160, 1024 spp, limit 8, S16, render Inline, the whole image on one GPU", "s16", 3840, 2160, 1024, BOUNCE_LIMIT, pkg.INLINE, warm=2)
     run("C4, one part of 8 (10-row stripes): what one rank of the 8-GPU job renders", "s16", 3840, 2160, 1024, BOUNCE_LIMIT, pkg.INLINE, part_of=8)
-    run("C5, one part of 8: glass scene, 3840x2160, 512 spp, render Streams, per-pixel tree walk (the default with GLASS)", "glass", 3840, 2160, 512, BOUNCE_LIMIT, pkg.STREAMS, part_of=8, warm=9, profile="c5_tree")
-    run("C5, one part of 8, stream ('wavefront') form: start-hit regions, graded passes, child rings (BASELINE configs[4]'s path)", "glass", 3840, 2160, 512, BOUNCE_LIMIT, pkg.STREAMS, part_of=8, stream_form=True, warm=9, profile="c5_stream")
+    run("C5, one part of 8: glass scene, 3840x2160, 512 spp, render Streams, per-pixel tree walk (PTMI_FORM_PIXEL: deterministic, bit-exact against the oracle)", "glass", 3840, 2160, 512, BOUNCE_LIMIT, pkg.STREAMS, part_of=8, warm=9, profile="c5_tree")
+    run("C5, one part of 8, stream ('wavefront') form: start-hit regions, graded passes, child rings (BASELINE configs[4]'s path; what PTMI_FORM_AUTO picks for a glass part at >= 256 spp)", "glass", 3840, 2160, 512, BOUNCE_LIMIT, pkg.STREAMS, part_of=8, stream_form=True, warm=9, profile="c5_stream")
     # the part that bounds the 8-GPU job: under the tree walk part 6 of the 10-row stripes is the slowest in every run of tools/part_bound.py (profiles/r05_c5_part.json)
     run("C5, the slowest part of 8 (part 6), tree walk", "glass", 3840, 2160, 512, BOUNCE_LIMIT, pkg.STREAMS, part_of=8, part=6, warm=9)
     run("C5, part 6 of 8, stream form", "glass", 3840, 2160, 512, BOUNCE_LIMIT, pkg.STREAMS, part_of=8, part=6, stream_form=True, warm=9)
@@ -301,8 +300,9 @@ def main():
     ap.add_argument("--part-of", type=int, default=0,
                     help="one GPU only: render part 0 of this many row-stripe parts of the image (what one rank of an N-GPU job does), "
                          "e.g. C5 per part: --scene glass --algorithm streams --width 3840 --height 2160 --spp 512 --part-of 8")
-    ap.add_argument("--streams-form", choices=["auto", "stream"], default="auto",
-                    help="render Streams: per-pixel kernels (auto) or the stream ('wavefront') form")
+    ap.add_argument("--streams-form", choices=["auto", "stream", "pixel"], default="auto",
+                    help="render Streams: the library's choice (auto: per-pixel kernels, but the stream form for a GLASS scene on one part of a "
+                         "partitioned image at >= 256 spp), the stream ('wavefront') form, or the per-pixel kernels")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="experiments only: ptmi_set_option before the first render, by the binding's name without OPT_ (e.g. STREAM_PASS_GROUPS=2); repeatable")
     ap.add_argument("--library", default=None,
@@ -374,6 +374,9 @@ def main():
     part = StripePartition(height, n_parts, my_part, args.stripe_rows)
     if n_parts > 1:
         ctx.set_partition(args.stripe_rows, n_parts, my_part)
+    # which form of render Streams this run is in (PTMI_FORM_AUTO's rule, include/ptmi.h: the stream form for GLASS on a part at >= 256 spp)
+    in_stream_form = args.algorithm == "streams" and (args.streams_form == "stream" or (
+        args.streams_form == "auto" and args.scene == "glass" and n_parts > 1 and spp >= 256))
     ctx.resize(width, height)
     assert ctx.local_rows == part.local_rows
     color = torch.zeros((3, ctx.local_rows, width), dtype=torch.float32, device="cuda")
@@ -387,8 +390,8 @@ def main():
     assert stream.cuda_stream != 0
     ctx.set_stream(stream.cuda_stream)
     ctx.set_variant(args.variant)
-    if args.streams_form == "stream":
-        ctx.set_option(pkg.binding.OPT_STREAMS_FORM, pkg.binding.FORM_STREAM)
+    if args.streams_form != "auto":
+        ctx.set_option(pkg.binding.OPT_STREAMS_FORM, pkg.binding.FORM_STREAM if args.streams_form == "stream" else pkg.binding.FORM_PIXEL)
     for item in args.option:
         name, value = item.split("=")
         ctx.set_option(getattr(pkg.binding, "OPT_" + name), int(value))
@@ -567,7 +570,7 @@ def main():
         if shape == (3840, 2160, 256, "s16", "inline"):
             config_name = "C3"                                            # BASELINE.json configs[2]
         elif shape == (3840, 2160, 512, "glass", "streams"):
-            config_name = "C5 (%s)" % ("stream form" if args.streams_form == "stream" else "per-pixel tree walk")   # configs[4]
+            config_name = "C5 (%s)" % ("stream form" if in_stream_form else "per-pixel tree walk")   # configs[4]
         else:
             config_name = "experiment"
         if n_parts != world:
@@ -579,7 +582,7 @@ def main():
             workload = ("C2" if world == 1 else "C2 per GPU (1920x1080 pixels each, weak scaling by %s)" % args.weak) if named else config_name
             workload += ": %dx%d image, %d spp per step" % (width, height, spp)
         kernel_name = "render_inline_kernel" if args.algorithm == "inline" else \
-            (("streams_split_kernel (stream form)" if args.scene == "glass" else "streams_pixels_kernel (stream form)") if args.streams_form == "stream" else
+            (("streams_split_kernel (stream form)" if args.scene == "glass" else "streams_pixels_kernel (stream form)") if in_stream_form else
              ("render_streams_tree_kernel" if args.scene == "glass" else "render_streams_kernel"))
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -18,7 +18,7 @@ OPT_STREAM_TAIL, OPT_ORDERED_PASSES, OPT_GLASS_BATCH, OPT_STREAM_GRADED, OPT_SNA
 CHAIN_CONSUME = 1
 ARITH_EXACT, ARITH_CONTRACTED = 0, 1
 SEED_KEEP_ACCUMULATOR, SEED_FROM_RESULT, SEED_AUTO = 0, 1, 2
-FORM_AUTO, FORM_STREAM = 0, 1
+FORM_AUTO, FORM_STREAM, FORM_PIXEL = 0, 1, 2
 PTMI_OK, PTMI_EINVAL, PTMI_ENODEVICE, PTMI_EHIP, PTMI_ENOMEM, PTMI_ESTATE, PTMI_ELIMIT, PTMI_ESTALE = 0, -1, -2, -3, -4, -5, -6, -7
 
 # every symbol include/ptmi.h declares: name -> (restype, argtypes)

@@ -170,6 +170,18 @@ int effective_seed_rule(const ptmi_ctx *c)
     return c->has_glass ? PTMI_SEED_KEEP_ACCUMULATOR : PTMI_SEED_FROM_RESULT;
 }
 
+// PTMI_OPT_STREAMS_FORM resolved: does `render Streams` run in its stream ("wavefront") form?  AUTO: only where it pays and costs nothing that
+// was promised -- a scene with GLASS (no reference semantics, no defined addition order in Accelerate's permute either) on ONE PART of a
+// partitioned image at >= 256 samples per call: the multi-GPU job is as fast as its slowest part, and that part is 5 % faster in the stream
+// form (profiles/r05_c5_part.json: part 6 of C5 29.1 against 30.7 ms; imbalance 1.02 against 1.03-1.14).  n_spp < 0: "for some sample count".
+bool uses_stream_form(const ptmi_ctx *c, int algorithm, int n_parts, int n_spp)
+{
+    if (algorithm != PTMI_STREAMS) return false;
+    if (c->opt_form == PTMI_FORM_STREAM || c->variant == 9) return true;
+    if (c->opt_form == PTMI_FORM_PIXEL) return false;
+    return c->has_glass && n_parts > 1 && (n_spp < 0 || n_spp >= 256);
+}
+
 int effective_stripe(const ptmi_ctx *c) { return c->stripe_rows > 0 ? c->stripe_rows : (c->height > 0 ? c->height : 1); }
 
 int rows_of_part(int height, int stripe, int n_parts, int part)
@@ -472,7 +484,9 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
         int passes = 1;
         if (c->opt_ordered_passes > 0) passes = c->opt_ordered_passes;    // (1 = off: one pass, no hand-off between waves inside the launch)
         else if (c->opt_batch > 0) passes = (n_spp + c->opt_batch - 1) / c->opt_batch;     // PTMI_OPT_STREAM_BATCH: samples per item
-        else if (n < 3ull * lanes && n_spp >= 256) passes = n_spp / 64 < 8 ? n_spp / 64 : 8;
+        // NEVER by itself (since 0.6): the hand-off between passes is fence-free -- measured valid on gfx950, not promised by the memory model
+        // (include/ptmi.h, PTMI_OPT_ORDERED_PASSES) -- and a default must not rest on a soak test.  Until 0.5 `n < 3 lanes && n_spp >= 256`
+        // chose min(n_spp / 64, 8) passes here; the measurements behind that rule, for a caller who sets the option:
         // (few, LONG items per lane: items of >= 64 samples, at most 8 passes.  The kernel of the ordered passes is 3 % slower per trip
         // than the one-pass kernel, and an item costs its refill and its seven stores.  1080p, S16, ms with 1 / 2 / 4 / 8 / 16 / 32 passes:
         // 64 spp 4.46 / 4.62 / 4.63 / 4.84 / 4.83 / 4.86; 256 spp 17.49 / 17.24 / 16.99 / 17.11 / 17.70 / 18.96; 1024 spp 69.7 / 68.1 / 66.0 /
@@ -747,7 +761,7 @@ int launch_render(ptmi_ctx *c, const Planes &planes, const ptmi_camera *camera, 
     a.live_counter = c->d_live; a.work_counter = c->d_work; a.stream_iterations = c->d_iters;
     a.stream_step_cap = c->opt_step_cap; a.seed_from_result = effective_seed_rule(c) == PTMI_SEED_FROM_RESULT;
     a.stream_counters = c->d_stream_counters;
-    const bool stream_form = algorithm == PTMI_STREAMS && (c->opt_form == PTMI_FORM_STREAM || c->variant == 9);
+    const bool stream_form = uses_stream_form(c, algorithm, n_parts, n_spp);
     // Cost-ordered dispatch (ptmi_device.h: lane_pixel): launches with one (camera, scene, shape, limit, algorithm)
     // record what every quad of tiles costs; later launches with the same key dispatch the most expensive quads first
     // (sorted on the device).  Everything is enqueued on the stream; results do not depend on it.
@@ -1310,7 +1324,7 @@ int ptmi_set_option(ptmi_ctx *c, int option, int64_t value)
         }
         return PTMI_OK;
     case PTMI_OPT_STREAMS_FORM:
-        if (value != PTMI_FORM_AUTO && value != PTMI_FORM_STREAM) return fail(c, PTMI_EINVAL, "unknown Streams form");
+        if (value != PTMI_FORM_AUTO && value != PTMI_FORM_STREAM && value != PTMI_FORM_PIXEL) return fail(c, PTMI_EINVAL, "unknown Streams form");
         c->opt_form = (int)value; return PTMI_OK;
     case PTMI_OPT_STREAM_BATCH:
         if (value < 0 || value > 64) return fail(c, PTMI_EINVAL, "stream batch must be in [0, 64] samples");
@@ -1467,7 +1481,7 @@ int ptmi_render_blocks(ptmi_ctx *c, int algorithm)
 {
     if (!c) return PTMI_EINVAL;
     std::lock_guard<std::mutex> lock(c->mu);
-    const bool stream_form = algorithm == PTMI_STREAMS && (c->opt_form == PTMI_FORM_STREAM || c->variant == 9);
+    const bool stream_form = uses_stream_form(c, algorithm, c->n_parts, -1);        // (for some sample count: the automatic choice looks at it)
     const bool ordered = !c->has_glass && (c->opt_batch == 0 || effective_seed_rule(c) == PTMI_SEED_FROM_RESULT);
     return stream_form && !ordered ? 1 : 0;
 }

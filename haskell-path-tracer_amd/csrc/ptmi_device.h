@@ -22,6 +22,11 @@ constexpr size_t kMaxSceneLds = 3 * 1024;  // bytes of staged scene per one-wave
 constexpr int kRenderBlock = 64; // render kernels: one wave per workgroup, so a finished wave's slot is refilled at once (+1 % on C2)
 
 struct HitSel { float t; int idx; bool just; };
+#ifdef PTMI_NO_STAGED_WALK_OTHERS          // (A/B builds: the Streams kernels read the staged scene as S[i], as they did until round 6)
+constexpr bool kStagedWalk = false;
+#else
+constexpr bool kStagedWalk = true;
+#endif
 
 // Correctly rounded binary32 square root (== IEEE sqrtf, which is what the reference's `sqrt`
 // lowers to) without the compiler's always-on denormal scaling: v_sqrt_f32 is within 1 ulp, two
@@ -113,7 +118,11 @@ __device__ __noinline__ HitSel check_hit_exact(ScenePtr S, int ns, int np, V3 o,
 //     one case (a ray or primitive with non-finite numbers) is detected at the end and redone literally.
 //   * spheres are walked two per trip with the two register sets swapping roles, so the prefetch of
 //     the next primitive costs no moves.
-template <typename ScenePtr>
+//   * STAGED = true (the caller has staged the scene in LDS and S points there): the geometry is read off ONE vector register
+//     that holds its LDS address, four spheres per trip, the offsets as immediates.  The address of a wave-uniform LDS read is a
+//     scalar, but ds_read wants it in a VGPR: read as S[i] every ds_read_b128 had a `v_mov_b32 vN, sK` in front of it -- one
+//     VALU issue slot in 22 of the sphere test, 56 M of them per C2 launch (round 6, tools/isa_other.py: C2 2.93 -> 2.86 ms).
+template <bool STAGED = false, typename ScenePtr>
 __device__ __forceinline__ HitSel check_hit(ScenePtr S, int ns, int np, V3 o, V3 d, unsigned int *diag = nullptr)
 {
     float best_key = __builtin_nanf("");
@@ -133,27 +142,62 @@ __device__ __forceinline__ HitSel check_hit(ScenePtr S, int ns, int np, V3 o, V3
             const float t = tca - sqrt_rn(x);                // min t0 t1 == t0 (thc >= 0 or NaN)
             const bool just = cand && !(t < 0.0f);
             const float key = just ? t : kInfinite;          // maybe infinite fst
+            // (as a masked block -- s_and_saveexec, two v_mov, s_or exec -- not as three selects: the selects cost C2 + 1.6 %, round 6)
             if (!(best_key <= key)) { best_key = key; best_idx = i; best_just = just; }
         }
     };
 
-    float4 ga = S[0], gb;
+    float4 ga, gb;
     int i = 0;
-    for (; i + 1 < ns; i += 2) {
-        gb = S[i + 1];
-        sphere(ga, i);
-        ga = S[i + 2];                                       // S has readable elements past the geometry
-        sphere(gb, i + 1);
-    }
-    if (i < ns) {
-        gb = S[i + 1];
-        sphere(ga, i);
-        ga = gb;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) const float4 *Staged;
+    Staged P = nullptr;
+    if constexpr (STAGED) {
+        unsigned int lds_at = (unsigned int)(uintptr_t)&S[0];    // the low half of a generic LDS address is the LDS offset
+        asm volatile("" : "+v"(lds_at));                          // ... kept in a VGPR: the loads below take it with immediate offsets
+        P = (Staged)(uintptr_t)lds_at;
+        ga = P[0];
+        for (; i + 3 < ns; i += 4) {
+            gb = P[1]; sphere(ga, i);
+            ga = P[2]; sphere(gb, i + 1);
+            gb = P[3]; sphere(ga, i + 2);
+            ga = P[4]; sphere(gb, i + 3);                         // S has readable elements past the geometry
+            P += 4;
+        }
+        for (; i + 1 < ns; i += 2) {
+            gb = P[1]; sphere(ga, i);
+            ga = P[2]; sphere(gb, i + 1);
+            P += 2;
+        }
+        if (i < ns) {
+            gb = P[1];
+            sphere(ga, i);
+            ga = gb;
+            P += 1;
+        }
+    } else
+#endif
+    {
+        ga = S[0];
+        for (; i + 1 < ns; i += 2) {
+            gb = S[i + 1];
+            sphere(ga, i);
+            ga = S[i + 2];                                       // S has readable elements past the geometry
+            sphere(gb, i + 1);
+        }
+        if (i < ns) {
+            gb = S[i + 1];
+            sphere(ga, i);
+            ga = gb;
+        }
     }
     for (int j = 0; j < np; ++j) {
         // distanceTo @Plane (Intersection.hs:57-62); ga holds (px, py, pz, 0)
-        const float4 gn = S[ns + 2 * j + 1];
-        const float4 g_next = S[ns + 2 * j + 2];
+        float4 gn, g_next;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (STAGED) { gn = P[2 * j + 1]; g_next = P[2 * j + 2]; } else
+#endif
+        { gn = S[ns + 2 * j + 1]; g_next = S[ns + 2 * j + 2]; }
         const V3 nor = mk(gn.x, gn.y, gn.z);
         const float denom = dot(d, nor);
         const bool cand = !(denom > 1e-6f);

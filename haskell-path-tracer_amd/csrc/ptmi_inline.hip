@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_INLINE_WAVES) render_inline
             // block restarts every `over` lane on its pixel's next sample, from the cached primary hit, with the rotation axis
             // and half-angle scale that every first shade of the pixel uses; then one full shade and one trace for all.  A
             // sample whose path ends by a certain freeze -- 64 % of them on C2 -- costs k-1 full shades and k-1 traces.
-            const HitSel h0 = check_hit(S, ns, np, origin, primary);
+            const HitSel h0 = check_hit<LDS_SCENE>(S, ns, np, origin, primary);
             if (!h0.just) {
                 if (n_spp > 0) acc = mk(0.0f, 0.0f, 0.0f) + acc;     // every sample: result 0, seed untouched
             } else {
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_INLINE_WAVES) render_inline
                     }
                     phase.end_a(); phase.round_c(has_ray);
                     if (has_ray) {
-                        const HitSel h = check_hit(S, ns, np, pos, d, diag::sphere_counters(a.work_counter));
+                        const HitSel h = check_hit<LDS_SCENE>(S, ns, np, pos, d, diag::sphere_counters(a.work_counter));
                         has_ray = false;
                         if (h.just) {
                             hit_record(S, ns, h.idx, pos, d, h.t, pos, normal);

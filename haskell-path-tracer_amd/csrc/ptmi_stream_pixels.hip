@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
         }
         if (has_ray) {
             longest = steps + 1u > longest ? steps + 1u : longest;     // the traceStep this ray belongs to
-            const HitSel h = check_hit(S, ns, np, pos, d);
+            const HitSel h = check_hit<LDS_SCENE && kStagedWalk>(S, ns, np, pos, d);
             has_ray = false;
             if (h.just) {
                 hit_record(S, ns, h.idx, pos, d, h.t, pos, normal);

@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_SPLIT_WAVES) streams_split_
                 has_ray = false;
             } else {
                 deepest = depth + 1u > deepest ? depth + 1u : deepest;
-                const HitSel h = check_hit(S, ns, np, o, d);
+                const HitSel h = check_hit<LDS_SCENE && kStagedWalk>(S, ns, np, o, d);
                 has_ray = false;
                 if (h.just) {
                     hit_record(S, ns, h.idx, o, d, h.t, o, normal);
@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_LEVEL_WAVES) streams_level_
                 has_ray = false;
             } else {
                 deepest = depth + 1u > deepest ? depth + 1u : deepest;
-                const HitSel h = check_hit(S, ns, np, o, d);
+                const HitSel h = check_hit<LDS_SCENE && kStagedWalk>(S, ns, np, o, d);
                 has_ray = false;
                 if (h.just) {
                     hit_record(S, ns, h.idx, o, d, h.t, o, normal);

@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_STREAMS_WAVES) render_strea
                     else has_ray = true;
                 }
                 if (has_ray) {
-                    const HitSel h = check_hit(S, ns, np, pos, d);
+                    const HitSel h = check_hit<LDS_SCENE && kStagedWalk>(S, ns, np, pos, d);
                     has_ray = false;
                     if (h.just) {
                         hit_record(S, ns, h.idx, pos, d, h.t, pos, normal);

@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                 glass_children(mk(ma0.x, ma0.y, ma0.z), glass_constants_of<LDS_SCENE>(mb0), pos, normal, primary, mk(1.0f, 1.0f, 1.0f), pixel_seed, ko, kd, kt, ks);
                 for (int k = 0; k < 2; ++k) {
                     const V3 ro = k == 0 ? ko[0] : ko[1], rd = k == 0 ? kd[0] : kd[1], rt = k == 0 ? kt[0] : kt[1];
-                    const HitSel h = check_hit(S, ns, np, ro, rd);
+                    const HitSel h = check_hit<LDS_SCENE && kStagedWalk>(S, ns, np, ro, rd);
                     if (h.just) {
                         V3 hp, hn;
                         hit_record(S, ns, h.idx, ro, rd, h.t, hp, hn);
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_TREE_WAVES) render_streams_
                 if (has_ray) {
                     probe.trace();
                     deepest = steps + 1u > deepest ? steps + 1u : deepest;
-                    const HitSel h = check_hit(S, ns, np, pos, d);
+                    const HitSel h = check_hit<LDS_SCENE && kStagedWalk>(S, ns, np, pos, d);
                     has_ray = false;
                     if (h.just) {
                         hit_record(S, ns, h.idx, pos, d, h.t, pos, normal);

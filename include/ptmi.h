@@ -59,10 +59,10 @@ enum { PTMI_STREAMS = 0, PTMI_INLINE = 1 };
  * PTMI_GLASS is a build-defined EXTENSION (parameter = index of refraction): a hit spawns a reflection and a
  * refraction ray.  The reference only announces such materials (src/Scene/Trace.hs:109-118, :306-307, :327-328),
  * so GLASS has no reference semantics; it is accepted by PTMI_STREAMS only (Inline cannot split rays,
- * src/Scene/Trace.hs:62-67).  By DEFAULT a scene with GLASS is rendered by the per-pixel TREE WALK (deterministic, bit-exact
- * against the oracle: one adder per colour word); the stream ("wavefront") form -- BASELINE configs[4]'s path; within 3 % of the
- * tree walk either way (slower at 1080p / 64 spp, faster on a part of a 4K image at 512 spp), colours through float atomics in no defined
- * order -- is PTMI_OPT_STREAMS_FORM = PTMI_FORM_STREAM.  See DESIGN.md 5.4 / 5.5. */
+ * src/Scene/Trace.hs:62-67).  On one GPU a scene with GLASS is rendered by the per-pixel TREE WALK (deterministic, bit-exact
+ * against the oracle: one adder per colour word); one PART of a partitioned image at >= 256 samples per call by the stream ("wavefront")
+ * form -- BASELINE configs[4]'s path: faster where the job is bounded by its slowest part, colours through float atomics in no defined
+ * order.  PTMI_OPT_STREAMS_FORM chooses explicitly.  See DESIGN.md 5.5. */
 enum { PTMI_MATTE = 0, PTMI_GLOSSY = 1, PTMI_GLASS = 2 };
 
 #define PTMI_MAX_PRIMITIVES 1024   /* spheres + planes staged in LDS per workgroup */
@@ -181,9 +181,17 @@ enum {
      * device's memory allows; only beyond that are children dropped and counted in ptmi_stats.stream_rays_dropped.  ptmi_get_option returns
      * the capacity in force (what the context has grown to); setting the option starts over from the value given. */
     PTMI_OPT_STREAM_CAPACITY = 3,
-    /* PTMI_FORM_AUTO (default): the per-pixel kernels (one lane walks its pixel's rays; with GLASS: its ray trees).
+    /* PTMI_FORM_PIXEL: the per-pixel kernels (one lane walks its pixel's rays; with GLASS: its ray trees) -- deterministic, bit-exact against the
+     * oracle also with GLASS (a colour word has one adder).
      * PTMI_FORM_STREAM: the stream ("wavefront") form -- the start hits of the pixels as a compacted list, persistent waves whose
-     * lanes take items from it by ballot + prefix, refraction children compacted into a ring per wave; ONE launch per call. */
+     * lanes take items from it by ballot + prefix, refraction children compacted into a ring per wave; ONE launch per call.  With GLASS a
+     * pixel's contributions are added through float atomics in no defined order (as Accelerate's permute): colours agree with the per-pixel
+     * kernels to 1e-4, the RNG planes exactly.
+     * PTMI_FORM_AUTO (default): PIXEL -- except for a scene with GLASS on a PARTITIONED context (ptmi_set_partition with more than one part:
+     * one rank of a multi-GPU job) at 256 samples per call or more, where it is STREAM: there the job is as fast as its slowest part, and the
+     * stream form is 5 % faster on that part and evens the parts out (BASELINE configs[4]: 29.1 against 30.7 ms on the bounding part, imbalance
+     * 1.02 against 1.03-1.14; at 1080p / 64 spp on one GPU it is 1 % slower, so nothing changes there).  A caller who wants the tree walk's
+     * bit-exactness on such a part sets PTMI_FORM_PIXEL. */
     PTMI_OPT_STREAMS_FORM = 4,
     /* Stream form only: how many samples of a pixel make one item.  0 (default) = automatic: without GLASS a pixel's whole sample
      * chain stays in one lane, in order (bit-identical to the per-pixel kernels; few long items are cut into ORDERED passes, still
@@ -215,12 +223,12 @@ enum {
     /* PTMI_OPT_ORDERED_PASSES: scenes without GLASS: a pixel's samples cut into this many ORDERED passes inside the one launch; the pixel's
      * seven words are handed from the lane that rendered pass p to whichever lane -- of any wave, on any XCD -- takes pass p + 1, through
      * write-through (sc1) stores, a counter that moves after the storing wave's vmcnt(0), and sc1 loads after the poll.  That hand-off
-     * uses NO FENCE: it is the "valid form" of MI355X_MICROARCH.md, MEASURED valid on gfx950 (3 billion hand-offs compared bit for bit,
-     * profiles/r03_soak_ordered_passes.json) -- not a promise of the HSA memory model.  0 (default) = automatic (only for parts of an
-     * image at >= 256 spp, where it is worth 5-8 %), 1 = OFF: one pass per launch, no hand-off between waves at all -- what a caller
-     * who wants only architecturally guaranteed synchronisation sets -- k in [2, 64] = k passes.  1 also overrides PTMI_OPT_STREAM_BATCH
-     * for scenes without GLASS.  (Until 0.4 the environment variables PTMI_ORDERED_PASSES / PTMI_STREAM_TAIL overrode these two options at
-     * creation; nothing is read from the environment any more: a stray variable cannot change scheduling behind the caller's back.) */
+     * uses NO FENCE: it is the "valid form" of MI355X_MICROARCH.md, MEASURED valid on gfx950 (5 billion hand-offs compared bit for bit,
+     * profiles/r05_soak_ordered_passes.json) -- not a promise of the HSA memory model.  Since 0.6 it is therefore NEVER chosen automatically:
+     * 0 (default) and 1 = one pass per launch, no hand-off between waves at all -- only architecturally guaranteed synchronisation;
+     * k in [2, 64] = k passes, the caller's explicit choice (worth 5-8 % for one of 8 parts of a 4K image at >= 256 spp, where a lane sees
+     * fewer than three pixels).  1 also overrides PTMI_OPT_STREAM_BATCH for scenes without GLASS.  (Until 0.4 the environment variables
+     * PTMI_ORDERED_PASSES / PTMI_STREAM_TAIL overrode these two options at creation; nothing is read from the environment any more.) */
     PTMI_OPT_ORDERED_PASSES = 9,
     /* PTMI_OPT_GLASS_BATCH: scenes with GLASS: a GLASS hit waits in its lane until this many lanes of its wave hold one (or the wave has
      * nothing else to shade or trace), so that the refraction block runs for that many lanes at a time.  0 (default) = automatic,
@@ -252,7 +260,7 @@ enum {
 };
 enum { PTMI_ARITH_EXACT = 0, PTMI_ARITH_CONTRACTED = 1 };
 enum { PTMI_SEED_KEEP_ACCUMULATOR = 0, PTMI_SEED_FROM_RESULT = 1, PTMI_SEED_AUTO = 2 };
-enum { PTMI_FORM_AUTO = 0, PTMI_FORM_STREAM = 1 };
+enum { PTMI_FORM_AUTO = 0, PTMI_FORM_STREAM = 1, PTMI_FORM_PIXEL = 2 };
 int ptmi_set_option(ptmi_ctx *ctx, int option, int64_t value);
 /* The passes the stream form's split kernel (GLASS, or PTMI_OPT_STREAM_BATCH under PTMI_SEED_KEEP_ACCUMULATOR) cuts n_spp samples into
  * for n_pixels held pixels on `lanes` persistent lanes (64 x 4 x 6 x compute units): pass p renders samples [first[p], first[p + 1]).
@@ -420,8 +428,11 @@ int ptmi_group_synchronize(ptmi_group *group);
 int ptmi_group_download_color(ptmi_group *group, float *r, float *g, float *b);
 /* The whole image's colour planes into DEVICE planes [height][width] on member `root`'s device: RCCL grouped
  * ncclSend / ncclRecv over xGMI (every peer has its own link to the root), then a stitch kernel.  Synchronous.  The
- * caller's current HIP device is left as it was.  (Exercised with one physical device only so far -- a member's planes
- * travelling through ncclSend / ncclRecv to itself; more than one device has not been available to this build.) */
+ * caller's current HIP device is left as it was.  (What has run: on real RCCL, one member sending to itself; with 3 and 8 members
+ * sharing one device, the whole n > 1 call sequence -- every root, unequal row counts, members without rows, communicator reuse, an
+ * error inside the group -- against a test-only stand-in for librccl that turns paired sends and receives into device copies
+ * (tests/test_gpu_group_rccl_stub.py: the host logic).  Between PHYSICAL devices, over xGMI, it has never run: no box this build has
+ * seen holds two GPUs; tests/test_group.py arms itself on the first one that does.) */
 int ptmi_group_gather_color(ptmi_group *group, int root, float *r_device, float *g_device, float *b_device);
 int ptmi_group_get_stats(ptmi_group *group, ptmi_stats *sum);  /* sums (maxima for the time and step fields) over the members */
 /* The partition's arithmetic, usable without a device: rows part `part` holds, and the image row of one of them. */

@@ -170,7 +170,7 @@ def test_c5_glass_4k_512spp_one_part_of_8(pkg, ora, form, part):
         c.set_scene(sp, pl)
         c.set_partition(10, 8, part)
         c.resize(W4K, H4K)
-        c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM if form == "stream" else B.FORM_AUTO)
+        c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM if form == "stream" else B.FORM_PIXEL)   # (AUTO would pick the stream form here: a part, GLASS, 512 spp)
         rows = c.global_rows()
         c.init_output(0x5EED1234)
         start = c.download_state()
@@ -271,16 +271,16 @@ def test_c2_stream_form_equals_the_per_pixel_kernel_at_full_size(pkg):
 
 
 def test_ordered_passes_off_equals_ordered_passes_on_for_a_striped_4k_part_at_256_spp(pkg):
-    """PTMI_OPT_ORDERED_PASSES: one of 8 parts (10-row stripes) of a 4K image at 256 spp through the stream form of Streams is where the
-    ordered passes are chosen automatically (fewer than 3 pixels per lane, >= 256 spp): a pixel's seven words are handed from lane to
-    lane, across waves and XCDs, by the fence-free write-through / poll / sc1-load hand-off -- MEASURED valid on gfx950, not an
-    architectural promise (include/ptmi.h).  A caller who wants none of it sets the option to 1 (off: one pass, no hand-off inside the
-    launch): all seven planes must be the same, bit for bit, as with the automatic choice and as with 8 forced passes."""
+    """PTMI_OPT_ORDERED_PASSES: one of 8 parts (10-row stripes) of a 4K image at 256 spp through the stream form of Streams is where ordered
+    passes pay (fewer than 3 pixels per lane, >= 256 spp): a pixel's seven words are handed from lane to lane, across waves and XCDs, by the
+    fence-free write-through / poll / sc1-load hand-off -- MEASURED valid on gfx950, not an architectural promise (include/ptmi.h), and
+    therefore never chosen automatically since 0.6: 0 (the default) is one pass, like 1.  All seven planes must be the same, bit for bit,
+    with the default, with 1 and with 4 and 8 passes the caller asks for."""
     B = pkg.binding
     sp, pl = pkg.world.scene16()
     cam = pkg.world.initial_camera()
-    planes = {}
-    for setting in (0, 1, 8):
+    planes, ms = {}, {}
+    for setting in (0, 1, 4, 8):
         with pkg.Context(0) as c:
             c.set_scene(sp, pl)
             c.set_partition(10, 8, 3)
@@ -288,12 +288,63 @@ def test_ordered_passes_off_equals_ordered_passes_on_for_a_striped_4k_part_at_25
             c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
             c.set_option(B.OPT_ORDERED_PASSES, setting)
             c.init_output(0x5EED1234)
+            c.set_timing(True)
             for _ in range(2):                                   # (the second launch runs in the recorded dispatch order)
                 c.render(cam, 8, 256, pkg.STREAMS)
             planes[setting] = c.download_state()
-            live = c.stats()["live_bounces"]
+            st = c.stats()
+            live, ms[setting] = st["live_bounces"], st["last_render_ms"]
         if setting:
-            assert_planes_equal(planes[setting], planes[0], "ordered passes = %d against automatic" % setting)
+            assert_planes_equal(planes[setting], planes[0], "ordered passes = %d against the default" % setting)
             assert live == live0
         else:
             live0 = live
+    print("ordered passes 0 / 1 / 4 / 8: %s ms" % " / ".join("%.2f" % ms[k] for k in (0, 1, 4, 8)))
+    assert abs(ms[0] - ms[1]) < 0.1 * ms[1]                      # the default IS one pass (the automatic choice used to be 4 here: 5-8 % faster)
+
+
+def test_form_auto_takes_the_stream_form_for_a_glass_part_at_256_spp_and_nowhere_else(pkg):
+    """PTMI_FORM_AUTO: a scene with GLASS on ONE PART of a partitioned image at >= 256 samples per call runs in the
+    stream form -- the multi-GPU job is bounded by its slowest part, which is 5 % faster there -- and everywhere else in the per-pixel
+    kernels.  Told apart by what the forms promise: the tree walk is deterministic (AUTO == PIXEL bit for bit where AUTO means PIXEL), the
+    stream form adds a pixel's contributions in no defined order (AUTO == STREAM's RNG planes exactly, colours within 1e-4 of PIXEL's,
+    and not all bits equal)."""
+    B = pkg.binding
+    sp, pl = pkg.world.glass_scene()
+    cam = pkg.world.initial_camera()
+    w, h = 640, 400
+
+    def render(form, spp, parts):
+        with pkg.Context(0) as c:
+            c.set_scene(sp, pl)
+            if parts > 1:
+                c.set_partition(10, parts, 1)
+            c.resize(w, h)
+            c.set_option(B.OPT_STREAMS_FORM, form)
+            c.init_output(0xABCD)
+            blocks = c.render_blocks(pkg.STREAMS)
+            c.render(cam, 8, spp, pkg.STREAMS)
+            st = c.stats()
+            assert st["stream_rays_dropped"] == 0
+            return c.download_state(), blocks
+
+    def same(a, b):
+        return all(np.array_equal(x.view(np.uint32), y.view(np.uint32)) for x, y in zip(a, b))
+
+    # a part, GLASS, 256 spp: the stream form
+    auto, auto_blocks = render(B.FORM_AUTO, 256, 4)
+    pixel, pixel_blocks = render(B.FORM_PIXEL, 256, 4)
+    stream, stream_blocks = render(B.FORM_STREAM, 256, 4)
+    assert auto_blocks and stream_blocks and not pixel_blocks
+    assert same(auto[3:], stream[3:]) and same(auto[3:], pixel[3:])                          # RNG planes: exact in every form
+    assert not same(auto[:3], pixel[:3])                                                     # ... the colours went through float atomics
+    for a, b in zip(auto[:3], pixel[:3]):
+        assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) <= 1e-4
+    # below 256 spp, or the whole image: the per-pixel tree walk, bit for bit
+    for spp, parts in ((255, 4), (256, 1), (16, 1)):
+        a, _ = render(B.FORM_AUTO, spp, parts)
+        p, _ = render(B.FORM_PIXEL, spp, parts)
+        assert same(a, p), (spp, parts)
+    with pkg.Context(0) as c:
+        with pytest.raises(pkg.PtmiError):
+            c.set_option(B.OPT_STREAMS_FORM, 3)

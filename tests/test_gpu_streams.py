@@ -221,9 +221,9 @@ def test_stream_iterations_is_per_launch(ctx, pkg, ora, stream_form):
 @pytest.mark.parametrize("spp", [256, 32])
 def test_stream_form_on_the_parts_of_a_striped_image(pkg, spp):
     """What one rank of a multi-GPU job renders through the stream form: a part of a row-striped image (8 parts, 10-row
-    stripes) -- at 256 spp, where the form cuts the pixels' sample chains into ordered passes by itself (few, long items per lane:
-    4 passes), and at 32 spp, where a pixel's chain is one item and the second launch leaves the cheap end of the part's dispatch
-    order to the per-pixel kernel.  Every part: all seven planes bit-identical to the per-pixel chain kernel on the same part, which
+    stripes) -- at 256 spp, with the pixels' sample chains cut into four ordered passes (PTMI_OPT_ORDERED_PASSES = 4: few, long items per
+    lane; the caller's explicit choice since 0.6, never automatic), and at 32 spp, where a pixel's chain is one item and the second launch
+    leaves the cheap end of the part's dispatch order to the per-pixel kernel.  Every part: all seven planes bit-identical to the per-pixel chain kernel on the same part, which
     the oracle pins; the parts together hold every row of the image once."""
     B = pkg.binding
     sp, pl = pkg.world.scene16()
@@ -238,6 +238,8 @@ def test_stream_form_on_the_parts_of_a_striped_image(pkg, spp):
                 c.resize(w, h)
                 c.init_output(0xC0FFEE)
             stream.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+            if spp >= 256:
+                stream.set_option(B.OPT_ORDERED_PASSES, 4)
             assert chain.local_rows == stream.local_rows == h // n_parts
             for launch in range(3):
                 chain.render(cam, 8, spp, pkg.STREAMS)

@@ -36,6 +36,8 @@ for _k in (1, 2, 4, 6, 8, 12, 16):                          # PTMI_OPT_SPP_CHUNK
     WORKLOADS["c5_tree_c%d" % _k] = ("glass", "streams", "auto", {"SPP_CHUNKS": _k}, C5_PART)
 for _k in (0, 50, 100, 150, 200, 250, 300, 400, 500):      # PTMI_OPT_STREAM_TAIL (thousandths of the recorded cost left to the per-pixel kernel)
     WORKLOADS["s16_stream_t%d" % _k] = ("s16", "streams", "stream", {"STREAM_TAIL": _k}, None)
+WORKLOADS["c2_v17"] = ("s16", "inline", "auto", {"VARIANT": 17}, None)     # render Inline with the scene through scalar loads instead of LDS (ptmi_set_variant 17)
+WORKLOADS["c2_main"] = ("main", "inline", "auto", {}, None)                # ... on mainScene (7 primitives)
 C4_PART = (3840, 2160, 1024, 8)     # one of 8 parts of BASELINE configs[3]
 WORKLOADS["c4_part"] = ("s16", "inline", "auto", {}, C4_PART)
 WORKLOADS["c4_part_streams"] = ("s16", "streams", "auto", {}, C4_PART)
@@ -69,15 +71,18 @@ def one(lib, names, width=1920, height=1080, spp=64, repeats=7):
     for k, name in enumerate([names[0]] + list(names)):
         scene, alg, form, options, shape = WORKLOADS[name]
         w, h, n_spp, parts = shape if shape else (width, height, spp, 1)
-        sp, pl = {"s16": pkg.world.scene16, "glass": pkg.world.glass_scene}[scene]()
+        sp, pl = {"s16": pkg.world.scene16, "glass": pkg.world.glass_scene, "main": pkg.world.main_scene}[scene]()
         with pkg.Context(0) as c:
             c.set_scene(sp, pl)
             if parts > 1:
                 c.set_partition(10, parts, 0)
             c.resize(w, h)
-            c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM if form == "stream" else B.FORM_AUTO)
+            c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM if form == "stream" else B.FORM_PIXEL)   # ("auto" workloads are the per-pixel kernels, also on a part)
             for opt, value in options.items():
-                c.set_option(getattr(B, "OPT_" + opt), value)
+                if opt == "VARIANT":
+                    c.set_variant(value)
+                else:
+                    c.set_option(getattr(B, "OPT_" + opt), value)
             c.init_output(0x5EED1234)
             algorithm = pkg.INLINE if alg == "inline" else pkg.STREAMS
             t_end = time.perf_counter() + 0.25

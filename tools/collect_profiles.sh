@@ -1,7 +1,7 @@
 #!/bin/bash
 # collect_profiles.sh TAG -- after tools/profile_round.sh ran on the GPU box: summarise and copy into profiles/ (tracked).
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/gpurun_out/prof_$TAG
 cp "$SRC/bench.json" "$ROOT/profiles/${TAG}_bench.json"

@@ -55,8 +55,7 @@ def measure(pkg, scene, cam, args, algorithm, form, chunk_list, partition=None, 
         if partition:
             c.set_partition(*partition)
         c.resize(args.width, args.height)
-        if form == "stream":
-            c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+        c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM if form == "stream" else B.FORM_PIXEL)
         c.init_output(0x5EED1234)
         for _ in range(warm):                                  # the dispatch order is rebuilt before launch 1, 2, 4, 8: none inside the timed ones
             c.render(cam, LIMIT, args.spp, algorithm)

@@ -4,7 +4,7 @@
 # then, back in the container:  bash tools/collect_profiles.sh r05   (copies the summaries into profiles/).
 # Counters are collected in their own passes (rocprofv3 --pmc with --kernel-trace only), the program itself after `--`.
 set -o pipefail
-TAG=${1:-r05}
+TAG=${1:-r06}
 PART=${2:-all}    # all | a (bench lines, kernel traces, PMC passes: ~10 min) | b (rates, part bounds, statistics builds, traffic terms: ~10 min) -- two gpurun calls of <= 1200 s
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
@@ -18,7 +18,7 @@ python3 -c "import __graft_entry__ as g; print(g.load_package()._build.code_id()
 # 1. the bench line as the driver runs it (N = 1, defaults), cpu_baseline included; C4 on one GPU (the N > 1 workload)
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.log"; echo "bench rc=$?"
 python3 bench.py --scaling strong --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c4_one_gpu.json" 2>> "$OUT/bench.log"; echo "bench C4 rc=$?"
-python3 bench.py --scene glass --algorithm streams --width 3840 --height 2160 --spp 512 --part-of 8 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c5_part.json" 2>> "$OUT/bench.log"; echo "bench C5 part rc=$?"
+python3 bench.py --scene glass --algorithm streams --streams-form pixel --width 3840 --height 2160 --spp 512 --part-of 8 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c5_part.json" 2>> "$OUT/bench.log"; echo "bench C5 part rc=$?"
 python3 bench.py --scene glass --algorithm streams --streams-form stream --width 3840 --height 2160 --spp 512 --part-of 8 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c5_part_stream.json" 2>> "$OUT/bench.log"; echo "bench C5 part, stream form rc=$?"
 # the kernel trace of the driver's own command (default steps): its mean for render_inline_kernel must agree with roofline.kernel_ms
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_default" --output-format csv -- python3 bench.py --no-cpu-baseline --no-also > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats_default.log"; echo "stats rc=$?"
@@ -30,7 +30,7 @@ bash tools/pmc_kernels.sh streams --algorithm streams > "$OUT/pmc_streams.log" 2
 bash tools/pmc_kernels.sh glass_tree --scene glass --algorithm streams > "$OUT/pmc_glass_tree.log" 2>&1; echo "pmc glass tree rc=$?"
 bash tools/pmc_kernels.sh glass_stream --scene glass --algorithm streams --streams-form stream > "$OUT/pmc_glass_stream.log" 2>&1; echo "pmc glass stream rc=$?"
 bash tools/pmc_kernels.sh s16_stream --algorithm streams --streams-form stream > "$OUT/pmc_s16_stream.log" 2>&1; echo "pmc s16 stream rc=$?"
-bash tools/pmc_kernels.sh c5_tree --scene glass --algorithm streams --width 3840 --height 2160 --spp 512 --part-of 8 > "$OUT/pmc_c5_tree.log" 2>&1; echo "pmc c5 tree rc=$?"
+bash tools/pmc_kernels.sh c5_tree --scene glass --algorithm streams --streams-form pixel --width 3840 --height 2160 --spp 512 --part-of 8 > "$OUT/pmc_c5_tree.log" 2>&1; echo "pmc c5 tree rc=$?"
 bash tools/pmc_kernels.sh c5_stream --scene glass --algorithm streams --streams-form stream --width 3840 --height 2160 --spp 512 --part-of 8 > "$OUT/pmc_c5_stream.log" 2>&1; echo "pmc c5 stream rc=$?"
 
 fi
