@@ -201,6 +201,7 @@ __device__ __forceinline__ HitSel check_hit(ScenePtr S, int ns, int np, V3 o, V3
         const V3 nor = mk(gn.x, gn.y, gn.z);
         const float denom = dot(d, nor);
         const bool cand = !(denom > 1e-6f);
+        diag::plane_test(diag, cand);
         if (__any(cand)) {
             const float t = dot(mk(ga.x, ga.y, ga.z) - o, nor) / denom;
             const bool just = cand && !(t < 0.0f);

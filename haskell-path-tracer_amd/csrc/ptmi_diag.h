@@ -36,7 +36,8 @@ PTMI_PROBE unsigned int wave_max(unsigned int v)
     return v;
 }
 
-// ---- check_hit: [16] sphere tests (per wave), [17] ... that took the square-root path, [18] candidate lanes, [19] active lanes
+// ---- check_hit: [16] sphere tests (per wave), [17] ... that took the square-root path, [18] candidate lanes, [19] active lanes,
+// [20] plane tests (per wave), [21] ... that took the division path
 #ifdef PTMI_SPHERE_STATS
 PTMI_PROBE unsigned int *sphere_counters(unsigned int *work_counter) { return work_counter; }
 PTMI_PROBE void sphere_test(unsigned int *wc, bool cand)
@@ -49,23 +50,40 @@ PTMI_PROBE void sphere_test(unsigned int *wc, bool cand)
         atomicAdd(wc + 19, (unsigned int)__builtin_popcountll(am));
     }
 }
+PTMI_PROBE void plane_test(unsigned int *wc, bool cand)
+{
+    const unsigned long long cm = __ballot(cand), am = __ballot(1);
+    if (wc && (threadIdx.x & 63) == (int)__builtin_ctzll(am)) {
+        atomicAdd(wc + 20, 1u);
+        if (cm) atomicAdd(wc + 21, 1u);
+    }
+}
 #else
 PTMI_PROBE unsigned int *sphere_counters(unsigned int *) { return nullptr; }
 PTMI_PROBE static void sphere_test(unsigned int *, bool) {}
+PTMI_PROBE static void plane_test(unsigned int *, bool) {}
 #endif
 
 // ---- render Inline: [1] lane-trips, [2..4] lane participations in the shade round(s) and the trace round, [5] trips of the wave's
 // slowest lane x 64 (what the wave paid for), [6] shades finished by the frozen-shade shortcut, [8..13] wave cycles per round (u64;
-// the waves of a SIMD interleave, so these are shares, not costs)
+// the waves of a SIMD interleave, so these are shares, not costs); WAVE-level executions of the loop's blocks (how often a wave runs
+// the block, whatever its lanes: what instruction counts multiply with, tools/isa_other.py): [24] trips, [25] the frozen check (any lane
+// pending at the top), [26] the frozen finish (any lane), [27] the restart block (any lane over), [28] the full shade (any lane pending),
+// [29] the trace (any lane with a ray)
 struct PhaseProbe {
 #ifdef PTMI_PHASE_STATS
     unsigned int iter = 0, a = 0, b = 0, c = 0, f = 0;
+    unsigned int w_trip = 0, w_check = 0, w_finish = 0, w_restart = 0, w_shade = 0, w_trace = 0;     // wave-level (uniform across the lanes that count)
+    bool froze = false;
     unsigned long long cyc_a = 0, cyc_b = 0, cyc_c = 0, t_prev = 0;
-    PTMI_PROBE void trip() { ++iter; t_prev = __builtin_amdgcn_s_memtime(); }
+    PTMI_PROBE void trip() { ++iter; ++w_trip; froze = false; t_prev = __builtin_amdgcn_s_memtime(); }
     PTMI_PROBE void round_a(bool on) { if (on) ++a; }
     PTMI_PROBE void round_b(bool on) { if (on) ++b; }
-    PTMI_PROBE void round_c(bool on) { if (on) ++c; }
-    PTMI_PROBE void frozen() { ++f; }
+    PTMI_PROBE void round_c(bool on) { if (on) ++c; if (__any(on)) ++w_trace; }
+    PTMI_PROBE void frozen() { ++f; froze = true; }
+    PTMI_PROBE void check(bool pending) { if (__any(pending)) ++w_check; }
+    PTMI_PROBE void restart(bool over) { if (__any(froze)) ++w_finish; if (__any(over)) ++w_restart; }
+    PTMI_PROBE void shade(bool pending) { if (__any(pending)) ++w_shade; }
     PTMI_PROBE void end_a() { const unsigned long long t = __builtin_amdgcn_s_memtime(); cyc_a += t - t_prev; t_prev = t; }
     PTMI_PROBE void end_b() { const unsigned long long t = __builtin_amdgcn_s_memtime(); cyc_b += t - t_prev; t_prev = t; }
     PTMI_PROBE void end_c() { cyc_c += __builtin_amdgcn_s_memtime() - t_prev; }
@@ -78,6 +96,12 @@ struct PhaseProbe {
             atomicAdd(reinterpret_cast<unsigned long long *>(wc + 8), cyc_a);
             atomicAdd(reinterpret_cast<unsigned long long *>(wc + 10), cyc_b);
             atomicAdd(reinterpret_cast<unsigned long long *>(wc + 12), cyc_c);
+            // (a lane that entered the loop late or left it early counted fewer wave-level events than the wave ran: the wave's figure is the
+            // maximum over its lanes; the first active lane adds it)
+        }
+        const unsigned int wt = wave_max(w_trip), wk = wave_max(w_check), wf = wave_max(w_finish), wr = wave_max(w_restart), ws = wave_max(w_shade), wc_ = wave_max(w_trace);
+        if (first_active_lane()) {
+            atomicAdd(wc + 24, wt); atomicAdd(wc + 25, wk); atomicAdd(wc + 26, wf); atomicAdd(wc + 27, wr); atomicAdd(wc + 28, ws); atomicAdd(wc + 29, wc_);
         }
     }
     PTMI_PROBE void flush_lanes_only(unsigned int *wc) { atomicAdd(wc + 1, iter); atomicAdd(wc + 2, a); atomicAdd(wc + 3, b); atomicAdd(wc + 4, c); }
@@ -87,6 +111,9 @@ struct PhaseProbe {
     PTMI_PROBE static void round_b(bool) {}
     PTMI_PROBE static void round_c(bool) {}
     PTMI_PROBE static void frozen() {}
+    PTMI_PROBE static void check(bool) {}
+    PTMI_PROBE static void restart(bool) {}
+    PTMI_PROBE static void shade(bool) {}
     PTMI_PROBE static void end_a() {}
     PTMI_PROBE static void end_b() {}
     PTMI_PROBE static void end_c() {}

@@ -118,6 +118,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_INLINE_WAVES) render_inline
                     phase.trip(); phase.round_a(pending || over);
                     float4 mb = M[2 * idx + 1];
                     V3 axis = mk(0.0f, 0.0f, 0.0f); float hk = 0.0f;
+                    phase.check(pending);
                     if (pending) {
                         bounce_axis(mb, normal, d, axis, hk);
                         const float4 ma = M[2 * idx];
@@ -128,6 +129,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_INLINE_WAVES) render_inline
                             pending = false; over = true;
                         }
                     }
+                    phase.restart(over);
                     if (over) {                                        // next sample of this pixel
                         // \(new, seed') (old, _) -> (new + old, seed') -- once a sample has been rendered (the first time round
                         // the lane only starts sample 0)
@@ -139,6 +141,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_INLINE_WAVES) render_inline
                         axis = mk(get(3), get(4), get(5)); hk = get(6);
                         over = false; pending = s < n_spp;
                     }
+                    phase.shade(pending);
                     if (pending) {
                         V3 next; float brdf;
                         next_about_axis(mb, axis, hk, seed, next, brdf);

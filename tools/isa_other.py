@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
-"""isa_other.py [KERNEL_SUBSTRING] [PROFILE.json] -- where the non-arithmetic quarter of a kernel's VALU instructions sits.
+"""isa_other.py [--json] [PHASE_STATS.json] -- where the non-arithmetic quarter of render_inline_kernel's VALU instructions sits.
 
 rocprofv3 counts a launch's VALU wave-instructions by class (SQ_INSTS_VALU_ADD_F32, ..._MUL_F32, ...); what is in none of them -- moves,
-compares, selects, lane reads, bit-field ops -- is the class OTHER (profiles/rNN_valu_roofline.json: mix_wave_instr_per_launch), 24.5 % of
-render_inline_kernel's instructions on C2.  This tool
-  1. cuts the kernel's assembly (build/isa/ptmi_inline.s, written by tools/kernel_resources.py) into basic blocks and counts every block's
-     VALU instructions by the same classes, OTHER by opcode;
-  2. estimates how often a wave executes each block per launch from the MEASURED class totals: non-negative least squares of
-     (class count of block b) x (executions of b) = (class total of the launch) over the blocks of the main loop -- twelve equations, the
-     blocks have distinct signatures (the sphere test holds the sqrt, the plane test the division, the shade the f64 sin/cos ...);
-  3. prints OTHER per block: static opcodes, estimated executions, share of the launch's OTHER instructions.
-The estimate is a fit, not a trace: it says which blocks to look at, and how well the fit reproduces the class totals is printed with it."""
+compares, selects, lane reads, the division helpers -- is the class OTHER (profiles/rNN_valu_roofline.json: mix_wave_instr_per_launch),
+24.5 % of the kernel's instructions on C2 in round 5.  This tool
+  1. cuts the kernel's assembly (build/isa/ptmi_inline.s, written by tools/kernel_resources.py) into basic blocks, keeps the blocks of the
+     main loop (the compiler's own loop comments), and counts every block's VALU instructions by the counters' classes, OTHER by opcode;
+  2. gives every block a ROLE by its signature (the sphere test holds v_min_f32 and a ds_read_b128, its candidate path the v_sqrt_f32, the
+     plane test the division, the sin/cos blocks the f64 arithmetic ...) and every role its executions per launch from the WAVE-level
+     counters of a -DPTMI_PHASE_STATS / -DPTMI_SPHERE_STATS build (tools/phase_stats.py: `wave_block_executions` -- exact counts of how often
+     a wave runs the block on C2, 64 spp);
+  3. prints OTHER per role: static opcodes, executions, wave-instructions per launch, share -- and how the sum compares with the measured
+     OTHER total of the committed PMC profile.
+Blocks without a signature of their own are booked under the loop's control flow at one execution per trip: an estimate, labelled so."""
 import json
 import os
 import re
@@ -38,7 +40,7 @@ def classify(op):
         return "MUL_F32"
     if re.match(r"v_(rcp|rsq|sqrt|sin|cos|exp|log|rcp_iflag)_(f32|legacy_f32)", o):
         return "TRANS_F32"
-    if re.match(r"v_(fma|mad)_f64", o):
+    if re.match(r"v_(fma|mad|fmac)_f64", o):
         return "FMA_F64"
     if re.match(r"v_(add|min|max)_f64", o):
         return "ADD_F64"
@@ -67,41 +69,93 @@ def kernel_body(sub):
     raise SystemExit("no kernel matching %r in build/isa/*.s (run tools/kernel_resources.py first)" % sub)
 
 
+LOOPS = {}       # label -> the headers of the loops the block is in, outermost first (from the compiler's own comments)
+
+
 def blocks_of(body):
     """[(label, [instruction lines])] in layout order; the entry block is labelled 'entry'."""
     out, label, cur = [], "entry", []
-    for line in body.split("\n"):
+    lines = body.split("\n")
+    for k, line in enumerate(lines):
         code = line.split(";")[0].rstrip()
-        if not code.strip():
-            continue
         m = re.match(r"^(\.LBB\d+_\d+):", code)
         if m:
             out.append((label, cur))
             label, cur = m.group(1), []
+            note = " ".join(l for l in lines[k:k + 4] if l.lstrip().startswith(";") or l is line)
+            heads = re.findall(r"(?:Parent Loop|Header=|Loop Header:)\s*(BB\d+_\d+)?", note)
+            own = ["BB" + label[4:]] if "Loop Header" in note else []
+            LOOPS[label] = [h for h in re.findall(r"Parent Loop (BB\d+_\d+)", note)] + re.findall(r"Header=(BB\d+_\d+)", note) + own
+            continue
+        if not code.strip():
             continue
         if code.startswith("\t.") or code.startswith("."):
             continue
         cur.append(code.strip())
     out.append((label, cur))
+    for lab, loops in LOOPS.items():                 # a block inside an inner loop names that loop's header only: the parents are the header's
+        if loops:
+            head = LOOPS.get(".L" + loops[0], [])
+            if head and head[0] != loops[0]:
+                LOOPS[lab] = head[:head.index(loops[0])] + loops if loops[0] in head else head + loops
     return out
 
 
+def role_of(b, inner):
+    ops = [i.split()[0] for i in b["code"]]
+    has = lambda *names: any(any(o.startswith(n) for n in names) for o in ops)      # noqa: E731
+    if has("v_cmp_class_f32") and has("v_sqrt_f32"):
+        return "sqrt_slow"                         # the compiler's denormal-scaled square root: only when a lane holds 0 < x < 2^-96
+    if has("v_min_f32") and has("v_cmp_ngt_f32") and has("v_cmp_gt_u32") and b["valu"] <= 26:
+        return "sphere_test"
+    if has("v_sqrt_f32"):
+        return "sphere_candidate"
+    if inner and has("v_cndmask_b32") and has("v_cmp_nle_f32") and b["valu"] <= 8 and not has("v_div_scale_f32"):
+        return "sphere_candidate"                  # the fold update behind the square root
+    if has("v_div_scale_f32") and inner:
+        return "plane_test"
+    if has("v_cvt_f64_f32") or has("v_cvt_i32_f64"):
+        return "sincos_reduce"
+    if has("v_fma_f64", "v_fmac_f64", "v_mul_f64"):
+        return "sincos_polynomial"
+    if has("v_div_scale_f32"):
+        return "division_fallback"                 # compiler divisions behind __all() range checks (normal of a hit, sincos of inf / NaN): rare
+    if has("v_rcp_f32"):
+        return "hit_normal"
+    return None
+
+
 def main():
-    sub = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].endswith(".json") else "render_inline_kernelILb1ELi8EE"
-    profile = next((a for a in sys.argv[1:] if a.endswith(".json")), None)
-    if profile is None:
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    stats_path = next((a for a in args if a.endswith(".json")), None)
+    if stats_path is None:
         for tag in ("r06", "r05"):
-            cand = os.path.join(ROOT, "profiles", "%s_valu_roofline.json" % tag)
-            if os.path.exists(cand):
-                profile = cand
+            cand = os.path.join(ROOT, "profiles", "%s_phase_stats.json" % tag)
+            if os.path.exists(cand) and "wave_block_executions" in open(cand).read():
+                stats_path = cand
                 break
-    name, body = kernel_body(sub)
+    execs = None
+    if stats_path:
+        for line in open(stats_path):
+            if "wave_block_executions" in line:
+                execs = json.loads(line)["wave_block_executions"]
+    measured = None
+    for tag in ("r06", "r05"):
+        cand = os.path.join(ROOT, "profiles", "%s_valu_roofline.json" % tag)
+        if os.path.exists(cand):
+            d = json.load(open(cand))
+            measured = (tag, d["mix_wave_instr_per_launch"], d.get("build_id", d.get("source_hash")))
+            break
+    name, body = kernel_body("render_inline_kernelILb1ELi8EE")
     blocks = blocks_of(body)
+    main_header = max(set(h[0] for h in LOOPS.values() if h), key=lambda hd: sum(1 for h in LOOPS.values() if h and h[0] == hd))
     table = []
     for label, code in blocks:
+        loops = LOOPS.get(label, [])
+        if not loops or loops[0] != main_header:
+            continue
         counts = dict.fromkeys(CLASSES, 0)
         other_ops = {}
-        marks = set()
         for ins in code:
             op = ins.split()[0]
             if op.startswith("v_"):
@@ -110,38 +164,67 @@ def main():
                 if cls == "OTHER":
                     key = re.sub(r"_(e32|e64)$", "", op)
                     other_ops[key] = other_ops.get(key, 0) + 1
-            if op.startswith("ds_"):
-                marks.add("lds")
-            if op.startswith("global_") or op.startswith("buffer_"):
-                marks.add("global")
-            if op.startswith("scratch_"):
-                marks.add("scratch")
-        table.append({"label": label, "n": len(code), "valu": sum(counts.values()), "counts": counts, "other_ops": other_ops, "marks": sorted(marks),
-                      "branches": [i.split()[-1] for i in code if i.startswith("s_cbranch") or i.startswith("s_branch")]})
-    mix = json.load(open(profile))["mix_wave_instr_per_launch"] if profile else None
-    est = None
-    if mix:
-        from scipy.optimize import nnls
-        hot = [i for i, b in enumerate(table) if b["valu"] > 0]
-        A = np.array([[table[i]["counts"][c] for i in hot] for c in CLASSES], float)
-        y = np.array([mix.get(c, 0.0) for c in CLASSES], float)
-        scale = 1.0 / np.maximum(y, y.max() * 1e-3)               # relative residuals: the small classes (sqrt, f64) carry the signatures
-        x, _ = nnls(A * scale[:, None], y * scale)
-        est = dict(zip(hot, x))
-        fit = A @ x
-        print("fit of the class totals (launch, wave-instructions; fitted / measured):")
-        print("  " + "  ".join("%s %.3f" % (c, (f / m) if m else float("nan")) for c, f, m in zip(CLASSES, fit, y)))
-    total_other = sum((est or {}).get(i, 0.0) * b["counts"]["OTHER"] for i, b in enumerate(table)) or 1.0
-    print("kernel %s: %d blocks, %d VALU instructions static, %d of them OTHER" % (name[-60:], len(table), sum(b["valu"] for b in table), sum(b["counts"]["OTHER"] for b in table)))
-    print("%-12s %5s %5s %6s %14s %7s  %s" % ("block", "instr", "VALU", "OTHER", "est. execs", "% OTHER", "OTHER opcodes | marks"))
-    rows = sorted(range(len(table)), key=lambda i: -((est or {}).get(i, 0.0) * table[i]["counts"]["OTHER"]))
-    for i in rows[:24]:
-        b = table[i]
-        e = (est or {}).get(i, 0.0)
-        print("%-12s %5d %5d %6d %14.0f %6.1f%%  %s | %s" % (b["label"], b["n"], b["valu"], b["counts"]["OTHER"], e, 100.0 * e * b["counts"]["OTHER"] / total_other,
-                                                          " ".join("%s:%d" % kv for kv in sorted(b["other_ops"].items(), key=lambda kv: -kv[1])), ",".join(b["marks"])))
+        table.append({"label": label, "code": code, "valu": sum(counts.values()), "counts": counts, "other_ops": other_ops, "inner": len(loops) > 1})
+    roles = {}
+    order = ["sphere_test", "sphere_candidate", "plane_test", "sincos_reduce", "sincos_polynomial", "hit_normal", "rest_of_loop", "sqrt_slow", "division_fallback"]
+    for b in table:
+        r = role_of(b, b["inner"]) or "rest_of_loop"
+        roles.setdefault(r, []).append(b)
+    # executions of ONE copy of a role's code per launch.  A role with k copies in the kernel (unrolled sites, the three sin/cos evaluations) runs
+    # each copy (role executions / k) times; all copies hold the same instructions, so instructions per launch = mean static count x role executions
+    e = execs or {}
+    role_execs = {"sphere_test": e.get("sphere_tests"), "sphere_candidate": e.get("sphere_sqrt_path"), "plane_test": e.get("plane_division_path"),
+                  "sincos_reduce": 3 * e["shade"] if e else None, "sincos_polynomial": 3 * e["shade"] if e else None, "hit_normal": None,
+                  "rest_of_loop": e.get("trips"), "sqrt_slow": 0, "division_fallback": 0}
+    what = {"sphere_test": "distanceTo @Sphere, the part every lane runs (16 f32 operations, the candidate test)", "sphere_candidate": "... its square root, t and the fold update, when a lane of the wave can be hit",
+            "plane_test": "distanceTo @Plane with its IEEE division and fold update", "sincos_reduce": "sin/cos: argument reduction (f64), three per shade",
+            "sincos_polynomial": "sin/cos: the two f64 polynomials, sign and swap by bit operations", "hit_normal": "hit: the sphere normal's three divisions by one length",
+            "rest_of_loop": "everything else in the loop, booked at ONE execution per trip: flags and masks, frozen check and finish, restart, draws, rotation, apply_bounce",
+            "sqrt_slow": "compiler's scaled square root (a lane with 0 < x < 2^-96): practically never", "division_fallback": "compiler divisions behind range checks (huge or zero operands, inf / NaN): practically never"}
+    # copies per role: sphere and plane tests are counted per TEST, a test runs one copy; sin/cos roles per evaluation
+    out_rows, total = [], 0.0
+    for r in order:
+        bs = roles.get(r, [])
+        if not bs:
+            continue
+        valu = sum(b["valu"] for b in bs)
+        other = sum(b["counts"]["OTHER"] for b in bs)
+        ops = {}
+        for b in bs:
+            for k, v in b["other_ops"].items():
+                ops[k] = ops.get(k, 0) + v
+        if r == "sphere_test":
+            copies = len(bs)
+        elif r == "sphere_candidate":
+            copies = max(1, len(roles.get("sphere_test", [])))
+        elif r == "plane_test":
+            copies = max(1, sum(1 for b in bs if any(i.startswith("v_div_fixup") for i in b["code"])))
+        elif r in ("sincos_reduce", "sincos_polynomial"):
+            copies = 3
+        else:
+            copies = 1
+        if r == "hit_normal":
+            n_exec = e.get("trace") if e else None               # at most once per trace (a sphere hit with a normal to normalise)
+        else:
+            n_exec = role_execs.get(r)
+        dyn = None if n_exec is None else other / copies * n_exec
+        dyn_valu = None if n_exec is None else valu / copies * n_exec
+        if dyn:
+            total += dyn
+        out_rows.append({"role": r, "what": what[r], "blocks": len(bs), "copies": copies, "static_valu": valu, "static_other": other, "other_opcodes": ops,
+                         "executions_per_launch": n_exec, "other_wave_instr_per_launch": dyn, "valu_wave_instr_per_launch": dyn_valu})
+    print("kernel ...%s: main loop %s, %d blocks; wave-level executions from %s" % (name[-48:], main_header, len(table), stats_path))
+    print("%-18s %4s %6s %6s %14s %14s %7s  %s" % ("role", "blk", "VALU", "OTHER", "executions", "OTHER / launch", "share", "OTHER opcodes (static, all copies)"))
+    for row in out_rows:
+        dyn = row["other_wave_instr_per_launch"]
+        print("%-18s %4d %6d %6d %14s %14s %6s  %s" % (row["role"], row["blocks"], row["static_valu"], row["static_other"],
+              "%.0f" % row["executions_per_launch"] if row["executions_per_launch"] is not None else "-", "%.0f" % dyn if dyn is not None else "-",
+              "%.1f%%" % (100.0 * dyn / total) if dyn else "-", " ".join("%s:%d" % kv for kv in sorted(row["other_opcodes"].items(), key=lambda kv: -kv[1]))))
+    if measured:
+        print("sum %.0f M OTHER wave-instructions per launch; the PMC profile profiles/%s_valu_roofline.json (binary %s) measured %.0f M" % (total / 1e6, measured[0], measured[2], measured[1]["OTHER"] / 1e6))
     if "--json" in sys.argv:
-        print(json.dumps({"kernel": name, "blocks": [{k: b[k] for k in ("label", "n", "valu", "counts", "other_ops", "marks")} | {"est_execs": (est or {}).get(i)} for i, b in enumerate(table)]}))
+        print(json.dumps({"kernel": name, "main_loop": main_header, "wave_block_executions": execs, "roles": out_rows, "sum_other": total,
+                          "measured_other": measured[1]["OTHER"] if measured else None, "measured_in": measured[0] if measured else None}))
 
 
 if __name__ == "__main__":

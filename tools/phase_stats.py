@@ -49,11 +49,16 @@ def main():
         ctx.set_variant(int(os.environ.get("PTMI_PHASE_VARIANT", "13")))
         ctx.init_output(0x5EED1234)
         ctx.reset_stats()
-        ctx.render(pkg.world.initial_camera(), 8, 8)
+        ctx.render(pkg.world.initial_camera(), 8, spp)
         raw = ctx.debug_counters().astype("uint32")
     print(json.dumps({"sphere_tests": {"per_wave_tests": float(raw[16]), "fraction_taking_sqrt_path": float(raw[17]) / max(float(raw[16]), 1),
                                        "candidate_lanes_per_test": float(raw[18]) / max(float(raw[16]), 1),
-                                       "active_lanes_per_test": float(raw[19]) / max(float(raw[16]), 1)}}))
+                                       "active_lanes_per_test": float(raw[19]) / max(float(raw[16]), 1), "spp": spp},
+                      "plane_tests": {"per_wave_tests": float(raw[20]), "fraction_taking_division_path": float(raw[21]) / max(float(raw[20]), 1)}}))
+    # how often a WAVE runs each block of the loop in one C2 launch (64 spp): what tools/isa_other.py multiplies static instruction counts with
+    print(json.dumps({"wave_block_executions": {"trips": c[24], "frozen_check": c[25], "frozen_finish": c[26], "restart": c[27], "shade": c[28], "trace": c[29],
+                                                "sphere_tests": float(raw[16]), "sphere_sqrt_path": float(raw[17]), "plane_tests": float(raw[20]), "plane_division_path": float(raw[21]),
+                                                "waves": w * h / 64.0}}))
     lane_iter, a, b, cc, paid = c[1], c[2], c[3], c[4], c[5]
     print(json.dumps({
         "lane_iterations_needed": lane_iter, "lane_iterations_paid_by_waves": paid,
