@@ -69,7 +69,9 @@ def test_library_carries_the_id_of_the_code_it_holds(pkg):
     assert re.fullmatch(r"[0-9a-f]{16}", want)
     assert lib.ptmi_build_id().decode() == want == lib.build_id
     assert pkg._build.read_build_id(pkg._build.LIB) == want
-    assert pkg._build.read_source_hash(pkg._build.LIB) == pkg._build.source_hash() != want
+    # the text hash the library was linked from is the present one, or the text has moved since without moving the code (a comment, a probe
+    # that is empty in the product): either way the library is current
+    assert re.fullmatch(r"[0-9a-f]{16}", pkg._build.read_source_hash(pkg._build.LIB)) and pkg._build.source_hash() != want
     assert not pkg._build.is_stale() and pkg._build.matches_sources(pkg._build.LIB)
     assert pkg._build.read_build_id(pkg._build.build_ablations_lib()) == pkg._build.code_id(["-DPTMI_ABLATIONS"])
     assert pkg._build.code_id(["-DPTMI_ABLATIONS"]).endswith("+PTMI_ABLATIONS") and pkg._build.code_id(["-DPTMI_ABLATIONS"]).split("+")[0] != want
