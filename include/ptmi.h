@@ -185,8 +185,8 @@ enum {
      * oracle also with GLASS (a colour word has one adder).
      * PTMI_FORM_STREAM: the stream ("wavefront") form -- the start hits of the pixels as a compacted list, persistent waves whose
      * lanes take items from it by ballot + prefix, refraction children compacted into a ring per wave; ONE launch per call.  With GLASS a
-     * pixel's contributions are added through float atomics in no defined order (as Accelerate's permute): colours agree with the per-pixel
-     * kernels to 1e-4, the RNG planes exactly.
+     * pixel's contributions are added through float atomics in no defined order (as Accelerate's permute): the same additions in another
+     * association -- colours agree with the per-pixel kernels to ~1e-4 relative (1.4e-4 seen at 256 spp), the RNG planes exactly.
      * PTMI_FORM_AUTO (default): PIXEL -- except for a scene with GLASS on a PARTITIONED context (ptmi_set_partition with more than one part:
      * one rank of a multi-GPU job) at 256 samples per call or more, where it is STREAM: there the job is as fast as its slowest part, and the
      * stream form is 5 % faster on that part and evens the parts out (BASELINE configs[4]: 29.1 against 30.7 ms on the bounding part, imbalance
