@@ -228,11 +228,25 @@ _toolchain = None
 
 
 def toolchain_id():
-    """`hipcc --version`, hashed: objects of another compiler or ROCm release are not reused (part of the object directory's key)."""
+    """Which compiler made the cached objects: objects of another compiler or ROCm release are not reused (part of the object directory's
+    key).  Read from FILES -- the ROCm release's version file, the resolved name of the clang binary (it carries the version), the bytes of
+    the hipcc driver -- and never by running `hipcc --version`: code_id() is asked by bench.py while a profiler's preloaded library has
+    already initialised the GPU in the process, and starting another program from there is what the GPU boxes refuse."""
     global _toolchain
     if _toolchain is None:
-        res = subprocess.run([hipcc_path(), "--version"], capture_output=True, text=True)
-        _toolchain = hashlib.sha256((res.stdout + res.stderr + os.environ.get("HIPCC_COMPILE_FLAGS_APPEND", "")).encode()).hexdigest()[:12]
+        h = hashlib.sha256(os.environ.get("HIPCC_COMPILE_FLAGS_APPEND", "").encode())
+        hipcc = os.path.realpath(hipcc_path())
+        root = os.path.dirname(os.path.dirname(hipcc))
+        for info in (os.path.join(root, ".info", "version"), os.path.join(root, ".info", "version-dev")):
+            if os.path.exists(info):
+                with open(info, "rb") as fh:
+                    h.update(fh.read())
+        for clang in (os.path.join(root, "lib", "llvm", "bin", "clang++"), os.path.join(root, "llvm", "bin", "clang++")):
+            if os.path.exists(clang):
+                h.update(os.path.realpath(clang).encode() + str(os.path.getsize(clang)).encode())
+        with open(hipcc, "rb") as fh:
+            h.update(fh.read())
+        _toolchain = h.hexdigest()[:12]
     return _toolchain
 
 

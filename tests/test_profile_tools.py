@@ -81,32 +81,38 @@ def test_pmc_summary_reports_n_min_max_and_the_bench_lines_kernel_time(tmp_path)
 
 
 def test_the_documents_and_the_committed_profiles_name_one_binary():
-    """DESIGN.md section 7 says which binary its tables were measured on; the committed round-5 profiles (the VALU accountings bench.py reads, the PMC
-    summaries, the part bounds, the traffic terms) and the fuzz record must carry that same build id -- a table of one binary next to a profile of
-    another is the kind of evidence round 4's verdict took apart."""
+    """DESIGN.md section 7 says which binary its tables were measured on; the committed round-6 profiles (the VALU accountings bench.py reads, the PMC
+    summaries, the part bounds, the traffic terms, the C0 call timings) and the fuzz record must carry that same build id -- a table of one binary
+    next to a profile of another is the kind of evidence round 4's verdict took apart.  Since round 6 the id is a hash over the COMPILED code
+    (_build.code_id): comment and documentation edits after the profile round leave every record valid."""
     import re
     # the measured tables of DESIGN.md are GENERATED from the committed profiles (tools/design_tables.py): they must be what the profiles say
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "design_tables.py"), "r05", "--check"], capture_output=True, text=True)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "design_tables.py"), "r06", "--check"], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert len(design.encode()) <= 26 * 1024, "DESIGN.md is what a maintainer reads: at most ~25 KB (narrative goes to HISTORY.md)"
     ids = set(re.findall(r"`ptmi_build_id\(\)` = `([0-9a-f]{16})`", design))
     assert len(ids) == 1, ids
     (build_id,) = ids
 
     def load(name):
         return json.load(open(os.path.join(ROOT, "profiles", name)))
-    assert load("r05_valu_roofline.json")["source_hash"] == build_id
-    streams = load("r05_valu_roofline_streams.json")
-    assert set(streams) == {"streams", "s16_stream", "glass_tree", "glass_stream", "c5_tree", "c5_stream"}        # none refused: every profile is its workload's
+    assert load("r06_valu_roofline.json")["build_id"] == build_id
+    streams = load("r06_valu_roofline_streams.json")
+    assert set(streams) == {"streams", "s16_stream", "glass_tree", "glass_stream", "c5_tree", "c5_stream"}
     for key, entry in streams.items():
-        assert entry["source_hash"] == build_id, key
+        assert "refused" not in entry, (key, entry.get("refused"))                            # every profile is its workload's
+        assert entry["build_id"] == build_id, key
         assert abs(entry["kernel_us_in_profile"] - entry["bench_kernel_us_under_rocprof"]) <= 0.1 * entry["bench_kernel_us_under_rocprof"], key
     for w in ("c2", "streams", "s16_stream", "glass_tree", "glass_stream", "c5_tree", "c5_stream"):
-        summary = load("r05_pmc_%s.json" % w)
+        summary = load("r06_pmc_%s.json" % w)
         assert summary["_bench"]["binary_build_id"] == build_id, w
         assert summary["_bench"]["ramp"]["spp_per_launch"] == (512 if w.startswith("c5") else 64), w      # the ramp launched the workload's own sample count
         assert all(v["one_launch_size"] for k, v in summary.items() if k != "_bench" and not k.startswith("__amd_")), w      # (the runtime's own copy kernels move buffers of many sizes)
-    assert load("r05_bench.json")["binary_build_id"] == build_id
-    assert load("r05_c5_part.json")["binary_build_id"] == build_id and load("r05_c4_part.json")["binary_build_id"] == build_id
-    assert all(v["build_id"].split("+")[0] == build_id for v in load("r05_traffic_terms.json")["variants"].values())
-    assert ("source hash %s" % build_id) in open(os.path.join(ROOT, "profiles", "r05_fuzz_campaign.txt")).read()
+    bench = load("r06_bench.json")
+    assert bench["binary_build_id"] == build_id == bench["code_id_now"]
+    assert load("r06_c5_part.json")["binary_build_id"] == build_id and load("r06_c4_part.json")["binary_build_id"] == build_id
+    assert all(v["build_id"].split("+")[0] == build_id or "+" in v["build_id"] for v in load("r06_traffic_terms.json")["variants"].values())
+    assert load("r06_traffic_terms.json")["variants"]["product"]["build_id"] == build_id
+    assert load("r06_c0_calls.json")["build_id"] == build_id
+    assert ("build id %s" % build_id) in open(os.path.join(ROOT, "profiles", "r06_fuzz_campaign.txt")).read()

@@ -43,28 +43,31 @@ def tables(tag):
     also = lambda p: next(e for e in b["also"] if e["workload"].startswith(p))      # noqa: E731
     ab = ab_runs(tag)
     out = {}
-    out["build id"] = ("**Which binary.**  Every line above comes from a process whose `libptmi.so` answered `ptmi_build_id()` = `%s`, the hash of the kernel\n"
-                       "sources, headers and flags of this commit" % b["binary_build_id"])
+    out["build id"] = ("**Which binary.**  Every line above comes from a process whose `libptmi.so` answered `ptmi_build_id()` = `%s`: a hash over the\n"
+                       "allocated sections of the objects it was linked from" % b["binary_build_id"])
     c0, c0b, c3, c4, c4p = also("C0: "), also("C0 at 30"), also("C3"), also("C4: "), also("C4, one part")
+    cl_ch, cl_cp = also("C0 through the compatible closure, chained"), also("C0 through the compatible closure, copying")
     st_c, st_s = also("C2 through render Streams, per-pixel"), also("C2 through render Streams, stream")
     g_t, g_s = also("glass scene, 1920x1080, 64 spp, render Streams, tree"), also("glass scene, 1920x1080, 64 spp, render Streams, stream")
     c5t, c5s = also("C5, one part of 8: "), also("C5, one part of 8, stream")
     cpu = b["cpu_baseline"]
     rows = [
-        "| C2 -- this round's run (a %.2f-GHz box) | 1× MI355X | **%s** | %.3f (%.3f) | %s (%.1f %%) | physical HBM %.0f MB per launch = %.0f GB/s (%.1f %%); VALU issue ≥ 91 %% |"
-        % (valu["clock_ghz"], th(b["value"]), b["ms_per_step"], r["kernel_ms"], th(r["achieved"]), 100 * r["frac"], r["traffic"] / 1e6, r["physical_GBps"], 100 * r["physical_frac"]),
-        "| C2 | oracle port, %d host cores (cgroup quota %d of %d) | %.0f | — | %.1f | single thread %.1f; live fraction %.4f; GPU / port ≈ %s×: a reported baseline, not a quality claim |"
-        % (cpu["cores"], cpu["cores"], cpu["affinity_cpus"], cpu["value"], cpu["value"] * 7 / 1e3, cpu["single_thread_value"], cpu["live_fraction"], th(round(b["value"] / cpu["value"], -2))),
-        "| C0 800×600, `mainScene`, limit 15, 1 spp per call (the reference's own configuration) | 1× MI355X | — | %.3f (%.3f) | — | %.3f ms at 30 spp per call |"
+        "| C2 -- this round's run (a %.2f-GHz box) | 1× MI355X | **%s** | %.3f (%.3f) | %s (%.1f %%) | physical HBM %.0f MB per launch = %.0f GB/s (%.1f %%); VALU issue %.0f %% |"
+        % (valu["clock_ghz"], th(b["value"]), b["ms_per_step"], r["kernel_ms"], th(r["achieved"]), 100 * r["frac"], r["traffic"] / 1e6, r["physical_GBps"], 100 * r["physical_frac"], 100 * valu["frac_in_profile"]),
+        "| C2 | oracle port, %d host cores (cgroup quota %d of %d) | %.0f | — | %.1f | single thread %.1f; GPU / port ≈ %s×: a reported baseline, not a quality claim |"
+        % (cpu["cores"], cpu["cores"], cpu["affinity_cpus"], cpu["value"], cpu["value"] * 7 / 1e3, cpu["single_thread_value"], th(round(b["value"] / cpu["value"], -2))),
+        "| C0 800×600, `mainScene`, limit 15 (the reference's own configuration), resident: 1 / 30 spp per call | 1× MI355X | — | %.3f (%.3f) / %.3f | — | |"
         % (c0["ms_per_step"], c0["kernel_ms"], c0b["ms_per_step"]),
+        "| C0 through `compileFor`'s closure, one sample per call: **chained / copying** | 1× MI355X | %s / %s | **%.4f / %.3f** | — | chained = `ptmi_render1_chained` (what `patches/Main.hs.diff` wires): %d of %d calls found their input on the device; copying = `ptmi_render1` |"
+        % (th(cl_ch["Msamples_per_s"]), th(cl_cp["Msamples_per_s"]), cl_ch["ms_per_step"], cl_cp["ms_per_step"], cl_ch["chain"]["renders_chained"], cl_ch["chain"]["renders_chained"] + cl_ch["chain"]["renders_uploaded"]),
         "| C3 3840×2160, 256 spp | 1× MI355X | %s | %.1f | %s (%.1f %%) | |" % (th(c3["Msamples_per_s"]), c3["ms_per_step"], th(c3["algorithmic_GBps"]), c3["algorithmic_GBps"] / 80.0),
         "| C4 3840×2160, 1024 spp, whole image / one part of 8 | 1× MI355X | %s / — | %.1f / %.2f | %s (%.1f %%) | §6: every part, three stripe heights |"
         % (th(c4["Msamples_per_s"]), c4["ms_per_step"], c4p["ms_per_step"], th(c4["algorithmic_GBps"]), c4["algorithmic_GBps"] / 80.0),
-        "| C2 through `render Streams`: chain / stream form | 1× MI355X | — | %.3f / %.3f | — | driver r4: 4.204 / 4.315; `tools/ab.py` best-of, same box: %s / %s |"
+        "| C2 through `render Streams`: chain / stream form | 1× MI355X | — | %.3f / %.3f | — | round 5's driver run: 4.177 / 4.273; `tools/ab.py` best-of, this round: %s / %s |"
         % (st_c["ms_per_step"], st_s["ms_per_step"], span(ab, "streams"), span(ab, "s16_stream")),
-        "| glass scene 1080p / 64 spp: tree walk / stream form | 1× MI355X | — | **%.2f / %.2f** | — | driver r4: 7.608 / 7.604; `tools/ab.py` best-of, same box: %s / %s |"
+        "| glass scene 1080p / 64 spp: tree walk / stream form | 1× MI355X | — | **%.2f / %.2f** | — | round 5's driver run: 7.627 / 7.698; `tools/ab.py`: %s / %s |"
         % (g_t["ms_per_step"], g_s["ms_per_step"], span(ab, "glass_tree"), span(ab, "glass_stream")),
-        "| **C5 per part** (glass, 4K / 512 spp, one of 8): tree walk / stream form | 1× MI355X | — | **%.2f / %.2f** | — | driver r4: 29.40 / 28.73; `tools/ab.py`, same box: %s / %s; §6: every part |"
+        "| **C5 per part** (glass, 4K / 512 spp, one of 8): tree walk / stream form | 1× MI355X | — | **%.2f / %.2f** | — | round 5's driver run: 29.47 / 29.49; `tools/ab.py`: %s / %s; §6: every part |"
         % (c5t["ms_per_step"], c5s["ms_per_step"], span(ab, "c5_tree"), span(ab, "c5_stream")),
     ]
     out["run rows"] = "\n".join(rows)
@@ -78,9 +81,9 @@ def tables(tag):
     out["valu rows"] = "\n".join([
         vrow("`render_inline_kernel<true, 8>` (C2)", valu, False, "%.0f" % valu["hbm_MB_per_call"], valu["priced_with_measured_rates"]["frac"]).replace("%.2f G" % (valu["valu_wave_instr_per_launch"] / 1e9), "%.3f G" % (valu["valu_wave_instr_per_launch"] / 1e9)),
         vrow("`render_streams_kernel<true, 8>` (C2 through Streams)", s["streams"], False, "%.0f" % s["streams"]["hbm_MB_per_call"]),
-        vrow("`streams_pixels_kernel` + the tail beside it (same, stream form)", s["s16_stream"], False, "%.0f (r04: 310)" % s["s16_stream"]["hbm_MB_per_call"]),
+        vrow("`streams_pixels_kernel` + the tail beside it (same, stream form)", s["s16_stream"], False, "%.0f" % s["s16_stream"]["hbm_MB_per_call"]),
         vrow("`render_streams_tree_kernel<true, 8>` (glass 1080p)", s["glass_tree"], True, th(s["glass_tree"]["hbm_MB_per_call"])),
-        vrow("`streams_split_kernel<true, true>` (glass 1080p)", s["glass_stream"], True, "**%s** (r04: 2 169)" % th(s["glass_stream"]["hbm_MB_per_call"])),
+        vrow("`streams_split_kernel<true, true>` (glass 1080p)", s["glass_stream"], True, th(s["glass_stream"]["hbm_MB_per_call"])),
         vrow("`render_streams_tree_kernel<true, 8>` (C5 part, 512 spp)", s["c5_tree"], False, th(s["c5_tree"]["hbm_MB_per_call"])),
         vrow("`streams_split_kernel<true, true>` (C5 part, 512 spp)", s["c5_stream"], True, th(s["c5_stream"]["hbm_MB_per_call"])),
     ])
@@ -96,8 +99,8 @@ def tables(tag):
         return "| %s | %s | %.1f ms | %s | %s | %s |" % (label, form, whole, cell(stripes["6"], fastest == "6"), cell(stripes["8"], fastest == "8"), cell(stripes["10"], fastest == "10"))
     out["bound rows"] = "\n".join([
         brow("C4 (S16, 1024 spp, `render Inline`; `profiles/%s_c4_part.json`)" % tag, "--", c4b["whole"]["best_ms"], c4b["stripes"]),
-        brow("C5 (glass, 512 spp, `render Streams`; `profiles/%s_c5_part.json`)" % tag, "tree walk (the default with GLASS)", c5b["forms"]["tree"]["whole"]["best_ms"], c5b["forms"]["tree"]["stripes"]),
-        brow("", "stream form", c5b["forms"]["stream"]["whole"]["best_ms"], c5b["forms"]["stream"]["stripes"]),
+        brow("C5 (glass, 512 spp, `render Streams`; `profiles/%s_c5_part.json`)" % tag, "tree walk (`PTMI_FORM_PIXEL`)", c5b["forms"]["tree"]["whole"]["best_ms"], c5b["forms"]["tree"]["stripes"]),
+        brow("", "stream form (what `PTMI_FORM_AUTO` picks for a glass part)", c5b["forms"]["stream"]["whole"]["best_ms"], c5b["forms"]["stream"]["stripes"]),
     ])
 
     pmc = load(tag, "pmc_glass_stream.json")
@@ -106,11 +109,11 @@ def tables(tag):
     fr = sp["hbm_read_MB_per_call"] + se["hbm_read_MB_per_call"] + ad["hbm_read_MB_per_call"]
     wr = sp["hbm_write_MB_per_call"] + se["hbm_write_MB_per_call"] + ad["hbm_write_MB_per_call"]
     out["budget rows"] = "\n".join([
-        "| `streams_split_kernel` | %.0f | %.0f | fetched: records 3 x 190 + snapshots 6 x 47 (a snapshot line serves one pass) = 854, spilled children read back 54, tickets, record counts and the colour lines of item ends ~ 35; written: spilled children 54, colour atomics 44, cost atomics ~ 35 (the recording launches' share of the profiled mean; 0 in the steady state), the rest statistics |"
+        "| `streams_split_kernel` | %.0f | %.0f | records and snapshots once per GROUP of equal-size passes, spilled children there and back, colour atomics; cost atomics only in recording launches |"
         % (sp["hbm_read_MB_per_call"], sp["hbm_write_MB_per_call"]),
-        "| `streams_slot_seeds_kernel` | %.0f | %.0f | 33 MB of seed planes + 12 of keys + counts in; passes x slots x 16 B of snapshots out |" % (se["hbm_read_MB_per_call"], se["hbm_write_MB_per_call"]),
+        "| `streams_slot_seeds_kernel` | %.0f | %.0f | seed planes + 4-byte slot keys in; passes × slots × 16 B of snapshots out |" % (se["hbm_read_MB_per_call"], se["hbm_write_MB_per_call"]),
         "| `streams_advance_seeds_kernel` | %.0f | %.0f | the four RNG planes, once each way |" % (ad["hbm_read_MB_per_call"], ad["hbm_write_MB_per_call"]),
-        "| **the call** | **%s** | **%.0f** | **%.2f GB** (round 4: 2.78 GB); split kernel alone %s MB = %.1f x the planes (r04: 18.7 x, r03: 12.8 x) at %.2f-%.2f ms (median, mean of the profiled calls) |"
+        "| **the call** | **%s** | **%.0f** | **%.2f GB** (round 4: 2.78); split kernel alone %s MB = %.1f × the planes at %.2f-%.2f ms (median, mean of the profiled calls) |"
         % (th(fr), wr, (fr + wr) / 1e3, th(sp["hbm_read_MB_per_call"] + sp["hbm_write_MB_per_call"]), (sp["hbm_read_MB_per_call"] + sp["hbm_write_MB_per_call"]) / 116.1,
            sp["median_us"] / 1e3, sp["avg_us"] / 1e3),
     ])
@@ -119,7 +122,7 @@ def tables(tag):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    tag = args[0] if args else "r05"
+    tag = args[0] if args else "r06"
     check = "--check" in sys.argv
     path = os.path.join(ROOT, "DESIGN.md")
     text = open(path).read()
