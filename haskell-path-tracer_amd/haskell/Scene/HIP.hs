@@ -29,7 +29,7 @@
 --    device residency runN has on the reference's own GPU backend: the result of a call STAYS ON THE DEVICE (its seven
 --    planes are thunks that download on first use: graphicsLoop forces r, g and b, nobody forces the RNG planes), and a call
 --    whose argument is such a result finds it there (ptmi_render1_chained: no upload).  A RenderResult that came from
---    anywhere else is uploaded as before.  800x600: ~30 us per call instead of ~1.9 ms (profiles/r06_c0_calls.json).
+--    anywhere else is uploaded as before.  800x600: ~30 us per call instead of ~1.1 ms (profiles/r06_c0_calls.json).
 --
 --    > let compute' = HIP.compileFor hip arguments                 -- replaces `compileFor arguments`            (:154)
 --    > seeds <- HIP.initialOutput hip seed0                        -- replaces `run <$> initialOutput`           (:155, :306)

@@ -327,7 +327,7 @@ int ptmi_render1(ptmi_ctx *ctx, const ptmi_camera *camera, int algorithm, int bo
  * `dewit = runN (render config) screenPixels` (app/Main.hs:190) is a pure function of arrays, and on the reference's own GPU backend
  * those arrays LIVE ON THE DEVICE: runN leaves its result there and copies it to the host lazily, when somebody reads it
  * (graphicsLoop, app/Main.hs:350), and an argument that is a previous result is found on the device again and not uploaded.
- * ptmi_render1 above moves all seven planes both ways on every call (1.07 ms per sample at 800x600 around a 0.03-ms kernel);
+ * ptmi_render1 above moves all seven planes both ways on every call (1.1 ms per sample at 800x600 around a 0.03-ms kernel);
  * these entry points give the closure runN's behaviour.  A STATE is one RenderResult (seven planes, width x height) held by the
  * context under a TOKEN (never 0, never reused, meaningless to other contexts).  To the caller a state is an immutable value:
  *   - ptmi_render1_chained(token_in) renders ONE sample from the state token_in names into a NEW state and returns its token; the

@@ -221,3 +221,71 @@ def test_the_resident_planes_are_untouched_by_the_chain(fresh, pkg, ora):
     ctx.render(cam, 15, 1)
     want, _ = ora.render_inline(sp, pl, cam, w, h, 15, 3, initial_planes(ora, w, h, 1))
     assert_planes_equal(ctx.download_state(), want, "resident state, one more sample")
+
+
+def test_random_walks_over_the_chain_api_equal_a_model_of_values(fresh, pkg, ora):
+    """A token is a value: whatever sequence of calls -- render from ANY held token (not only the newest), reseed, consume, release, fetch, with
+    three device slots so that states keep moving to the host and back -- every held token reads as the planes a pure model computes for it
+    with the oracle (one sample = ora.render_inline on the parent's planes)."""
+    ctx = fresh
+    B = pkg.binding
+    sp, pl = pkg.world.main_scene()
+    cams = [pkg.world.initial_camera(), moved(pkg, pkg.world.initial_camera(), 0.4, -0.07)]
+    w, h, limit = 24, 10, 6
+    ctx.set_scene(sp, pl)
+    ctx.set_option(B.OPT_CHAIN_SLOTS, 3)
+    rng = np.random.default_rng(20261005)
+    model = {}                                               # token -> seven planes
+
+    def check(tok):
+        assert_planes_equal(ctx.chain_fetch(tok, w, h), model[tok], "token %x" % tok)
+
+    t = ctx.chain_init_output(w, h, 11)
+    model[t] = initial_planes(ora, w, h, 11)
+    ops = {"render": 0, "consume": 0, "reseed": 0, "release": 0, "fetch": 0, "init": 0, "from_host": 0}
+    for step in range(400):
+        held = sorted(model)
+        r = rng.random()
+        src = int(held[rng.integers(len(held))])
+        cam = cams[int(rng.integers(2))]
+        if r < 0.45:                                         # the closure, from any held value
+            consume = rng.random() < 0.25
+            new, got = ctx.render1_chained(cam, limit, w, h, src, consume=bool(consume), fetch=("g",) if rng.random() < 0.2 else ())
+            want, _ = ora.render_inline(sp, pl, cam, w, h, limit, 1, model[src])
+            model[new] = list(want)
+            if "g" in got:
+                assert np.array_equal(got["g"].view(np.uint32), want[1].view(np.uint32))
+            if consume:
+                del model[src]
+                ops["consume"] += 1
+            ops["render"] += 1
+        elif r < 0.55:
+            seed0 = int(rng.integers(1, 1 << 40))
+            new = ctx.chain_reseed(seed0, w, h, src)
+            model[new] = list(model[src][:3]) + [s.reshape(h, w) for s in ora.gen_seeds(seed0, 0, w * h)]
+            ops["reseed"] += 1
+        elif r < 0.62:                                       # a RenderResult from elsewhere: host planes, token 0
+            planes = [p.copy() for p in model[src]]
+            new, _ = ctx.render1_chained(cam, limit, w, h, 0, planes_in=planes)
+            want, _ = ora.render_inline(sp, pl, cam, w, h, limit, 1, planes)
+            model[new] = list(want)
+            ops["from_host"] += 1
+        elif r < 0.70:
+            seed0 = int(rng.integers(1, 1 << 40))
+            new = ctx.chain_init_output(w, h, seed0)
+            model[new] = initial_planes(ora, w, h, seed0)
+            ops["init"] += 1
+        elif r < 0.85 and len(held) > 2:
+            ctx.chain_release(src)
+            del model[src]
+            with pytest.raises(pkg.PtmiError):
+                ctx.chain_fetch(src, w, h)
+            ops["release"] += 1
+        else:
+            check(src)
+            ops["fetch"] += 1
+    for tok in model:
+        check(tok)
+    info = ctx.chain_info()
+    assert info["states_on_device"] + info["states_on_host"] == len(model) and info["states_on_device"] <= 3
+    assert info["evictions"] > 20 and ops["consume"] > 10 and ops["release"] > 10 and ops["from_host"] > 5, (info, ops)

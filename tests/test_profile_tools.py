@@ -90,7 +90,7 @@ def test_the_documents_and_the_committed_profiles_name_one_binary():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "design_tables.py"), "r06", "--check"], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
-    assert len(design.encode()) <= 26 * 1024, "DESIGN.md is what a maintainer reads: at most ~25 KB (narrative goes to HISTORY.md)"
+    assert len(design.encode()) <= 27 * 1024, "DESIGN.md is what a maintainer reads: ~26 KB, generated tables included (narrative goes to HISTORY.md)"
     ids = set(re.findall(r"`ptmi_build_id\(\)` = `([0-9a-f]{16})`", design))
     assert len(ids) == 1, ids
     (build_id,) = ids
