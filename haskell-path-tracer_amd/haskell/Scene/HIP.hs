@@ -22,7 +22,8 @@
 --    > (r, g, b) <- HIP.downloadColor hip          -- the three planes, or
 --    > rgb       <- HIP.presentRGB32F hip iterations   -- interleaved and already divided by the iteration count (fs.glsl:12)
 --
---    The 'Result' record then carries the iteration count only; 'Handle' is the accumulator.
+--    The 'Result' record then carries the iteration count only; 'Handle' is the accumulator.  patches/Main.resident.diff is this wiring
+--    as a patch against app/Main.hs.
 --
 -- 2. COMPATIBLE.  'compileFor' builds the very closure of app/Main.hs:188-191,
 --    @Camera -> (Int, RenderResult) -> (Int, RenderResult)@, one sample per call, pure -- and, since libptmi 0.6, with the
@@ -112,8 +113,8 @@ data Handle = Handle
 handleSize :: Handle -> (Int, Int)
 handleSize h = (handleWidth h, handleHeight h)
 
--- | What the loaded libptmi was built from (ptmi_build_id: the hash of its kernel sources, headers and flags): print it next to
--- any timing, so that a number can be tied to a binary.
+-- | Which code the loaded libptmi holds (ptmi_build_id: a hash over its compiled host and gfx950 code): print it next to any timing,
+-- so that a number can be tied to a binary.
 libraryBuildId :: IO String
 libraryBuildId = c_build_id >>= peekCString
 

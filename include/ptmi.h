@@ -108,10 +108,11 @@ typedef struct ptmi_ctx ptmi_ctx;
 
 /* ---- lifetime ---------------------------------------------------------------- */
 int         ptmi_version(void);
-/* What this binary was built from: the first 16 hex digits of the sha256 over the kernel sources, headers and build flags
- * (haskell-path-tracer_amd/_build.py: source_hash), followed by "+<flags>" for a non-default build (ablations, diagnostic builds).
+/* Which code this binary holds: 16 hex digits of a sha256 over the allocated sections of the objects it was linked from -- host code and
+ * the gfx950 code objects (haskell-path-tracer_amd/_build.py: code_id) -- followed by "+<flags>" for a non-default build (ablations,
+ * diagnostic builds).  A comment or documentation edit leaves it unchanged; an instruction, a constant or a kernel's name changes it.
  * Every measurement names it (bench.py: binary_build_id; profiles/): a number belongs to the binary that carries the id, and the
- * Python binding refuses a library whose id is not that of the sources beside it.  Never NULL; static storage. */
+ * Python binding refuses a library that does not hold the code the sources beside it compile to.  Never NULL; static storage. */
 const char *ptmi_build_id(void);
 const char *ptmi_strerror(int code);
 /* Create a context on HIP device `device` (>= 0).  Fails with PTMI_ENODEVICE when the
@@ -339,7 +340,8 @@ int ptmi_render1(ptmi_ctx *ctx, const ptmi_camera *camera, int algorithm, int bo
  *     passes none and calls ptmi_chain_fetch when somebody reads a plane: colour for graphicsLoop, all seven on demand.
  *   - a state is held until ptmi_chain_release(token) (a Haskell finalizer, a C++ destructor), or until a call CONSUMES it
  *     (PTMI_CHAIN_CONSUME: the caller gives up token_in with the call; the sample is then rendered in place, without the
- *     device-to-device copy that otherwise keeps the input intact -- the cost of a resident ptmi_render).  At most
+ *     device-to-device copy that otherwise keeps the input intact -- the cost of a resident ptmi_render; should the call then fail, the
+ *     input is gone with it).  At most
  *     PTMI_OPT_CHAIN_SLOTS states stay on the device; older ones move to host memory the library owns and are served from there.
  * Any thread; calls are serialised by the context's mutex like all others.  The resident planes of ptmi_resize / ptmi_render and
  * their partition are a separate matter and untouched. */
