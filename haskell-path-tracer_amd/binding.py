@@ -14,8 +14,9 @@ from . import _build
 from .world import CAMERA_DTYPE, PLANE_DTYPE, SPHERE_DTYPE, INLINE, STREAMS
 
 OPT_STREAMS_SEED_RULE, OPT_STREAM_STEP_CAP, OPT_STREAM_CAPACITY, OPT_STREAMS_FORM, OPT_STREAM_BATCH, OPT_SPP_CHUNKS, OPT_ARITHMETIC = 1, 2, 3, 4, 5, 6, 7
-OPT_STREAM_TAIL, OPT_ORDERED_PASSES, OPT_GLASS_BATCH, OPT_STREAM_GRADED, OPT_SNAPSHOT_BUDGET_MB, OPT_STREAM_PASS_GROUPS, OPT_CHAIN_SLOTS = 8, 9, 10, 11, 12, 13, 14
+OPT_STREAM_TAIL, OPT_ORDERED_PASSES, OPT_GLASS_BATCH, OPT_STREAM_GRADED, OPT_SNAPSHOT_BUDGET_MB, OPT_STREAM_PASS_GROUPS, OPT_CHAIN_SLOTS, OPT_PASS_HANDOFF = 8, 9, 10, 11, 12, 13, 14, 15
 CHAIN_CONSUME = 1
+HANDOFF_FENCED, HANDOFF_FENCE_FREE = 0, 1
 ARITH_EXACT, ARITH_CONTRACTED = 0, 1
 SEED_KEEP_ACCUMULATOR, SEED_FROM_RESULT, SEED_AUTO = 0, 1, 2
 FORM_AUTO, FORM_STREAM, FORM_PIXEL = 0, 1, 2

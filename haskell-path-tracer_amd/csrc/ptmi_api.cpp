@@ -100,6 +100,7 @@ struct ptmi_ctx {
     unsigned int *d_region_done = nullptr;   // stream form, ordered passes: items published per region
     unsigned int region_done_words = 0;
     int opt_ordered_passes = 0;      // PTMI_OPT_ORDERED_PASSES: 0 = automatic, 1 = off, k = k passes
+    int opt_pass_handoff = 0;        // PTMI_OPT_PASS_HANDOFF: 0 = release / acquire once per (region, pass); 1 = the fence-free write-through hand-off
     int *d_pass_first = nullptr;     // stream form, split kernel: the samples of every pass (ItemArgs.pass_first), kMaxStreamPasses + 1 entries
     std::vector<int> pass_first_host;   // ... what the device block holds
     unsigned int *d_qcount = nullptr;
@@ -484,9 +485,10 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
         int passes = 1;
         if (c->opt_ordered_passes > 0) passes = c->opt_ordered_passes;    // (1 = off: one pass, no hand-off between waves inside the launch)
         else if (c->opt_batch > 0) passes = (n_spp + c->opt_batch - 1) / c->opt_batch;     // PTMI_OPT_STREAM_BATCH: samples per item
-        // NEVER by itself (since 0.6): the hand-off between passes is fence-free -- measured valid on gfx950, not promised by the memory model
-        // (include/ptmi.h, PTMI_OPT_ORDERED_PASSES) -- and a default must not rest on a soak test.  Until 0.5 `n < 3 lanes && n_spp >= 256`
-        // chose min(n_spp / 64, 8) passes here; the measurements behind that rule, for a caller who sets the option:
+        else if (c->opt_pass_handoff == 0 && n < 3ull * lanes && n_spp >= 256) passes = n_spp / 64 < 8 ? n_spp / 64 : 8;
+        // (automatic only with the FENCED hand-off -- release / acquire at agent scope once per region and pass, what the memory model
+        // promises; the fence-free hand-off of rounds 3-5, PTMI_OPT_PASS_HANDOFF = 1, is measured valid, not promised, and never chosen
+        // without the caller's explicit PTMI_OPT_ORDERED_PASSES)
         // (few, LONG items per lane: items of >= 64 samples, at most 8 passes.  The kernel of the ordered passes is 3 % slower per trip
         // than the one-pass kernel, and an item costs its refill and its seven stores.  1080p, S16, ms with 1 / 2 / 4 / 8 / 16 / 32 passes:
         // 64 spp 4.46 / 4.62 / 4.63 / 4.84 / 4.83 / 4.86; 256 spp 17.49 / 17.24 / 16.99 / 17.11 / 17.70 / 18.96; 1024 spp 69.7 / 68.1 / 66.0 /
@@ -498,6 +500,8 @@ int render_streams_wavefront(ptmi_ctx *c, RenderArgs &a, int n_spp, const ptmi_c
         if (passes > most) passes = most;
         if (passes < 1) passes = 1;
         it.passes = passes;                                // (ordered passes wait for each other: every pass on its own, no group table)
+        it.fenced = c->opt_pass_handoff == 0 ? 1 : 0;
+        if (passes > 1 && n_regions >= (1u << 26)) return fail(c, PTMI_ELIMIT, "image too large for ordered passes (2^26 regions)");
         it.chunk_cursor = tickets_of(0);
         // THE TAIL.  A lane renders a pixel's whole sample chain, so the persistent launch ends as its last items do: its waves end between
         // 70 and 100 % of it.  The cheapest quads of the dispatch order -- the order kernel marks where they begin, on the device -- are
@@ -1356,6 +1360,9 @@ int ptmi_set_option(ptmi_ctx *c, int option, int64_t value)
     case PTMI_OPT_CHAIN_SLOTS:
         if (value != 0 && (value < 2 || value > 4096)) return fail(c, PTMI_EINVAL, "chain slots must be 0 (automatic) or in [2, 4096]");
         c->opt_chain_slots = (int)value; return PTMI_OK;
+    case PTMI_OPT_PASS_HANDOFF:
+        if (value != PTMI_HANDOFF_FENCED && value != PTMI_HANDOFF_FENCE_FREE) return fail(c, PTMI_EINVAL, "unknown pass hand-off");
+        c->opt_pass_handoff = (int)value; return PTMI_OK;
     default: return fail(c, PTMI_EINVAL, "unknown option");
     }
 }
@@ -1380,6 +1387,7 @@ int ptmi_get_option(ptmi_ctx *c, int option, int64_t *value)
     case PTMI_OPT_STREAM_PASS_GROUPS: *value = c->opt_pass_groups; return PTMI_OK;
     case PTMI_OPT_SNAPSHOT_BUDGET_MB: *value = c->opt_snapshot_mb; return PTMI_OK;
     case PTMI_OPT_CHAIN_SLOTS: *value = c->opt_chain_slots; return PTMI_OK;
+    case PTMI_OPT_PASS_HANDOFF: *value = c->opt_pass_handoff; return PTMI_OK;
     default: return fail(c, PTMI_EINVAL, "unknown option");
     }
 }

@@ -142,6 +142,7 @@ struct ItemArgs {
                                     // region's items of one group follow each other through one ticket queue, and all but the first find its records and
                                     // colour lines in that XCD's L2 (decode_ticket).  A group of one pass is that pass, pass by pass as ever
     unsigned int *region_done;      // streams_pixels_kernel, passes > 1: per region, the items published so far (zero at launch)
+    int fenced;                     // ... 1: release / acquire at agent scope, once per (region, pass); 0: the fence-free write-through hand-off (PTMI_OPT_PASS_HANDOFF)
     unsigned int *chunk_cursor;     // device: the launch's eight ticket counters, kCounterStride words apart, zero at launch
     // streams_split_kernel only
     const int *pass_first;          // device, passes + 1 entries: pass p renders samples [pass_first[p], pass_first[p + 1]) of its pixels -- long items first, short ones

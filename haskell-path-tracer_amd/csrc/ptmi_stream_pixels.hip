@@ -1,5 +1,5 @@
 // ptmi_stream_pixels.hip -- the stream form of render Streams for scenes whose rays never split: persistent waves, items by
-// ticket, lanes that refill by ballot + prefix, optional ordered passes handed from lane to lane without a fence.
+// ticket, lanes that refill by ballot + prefix, optional ordered passes handed from lane to lane (one release per region and pass).
 #include "ptmi_stream_form.h"
 
 namespace ptmi {
@@ -15,12 +15,14 @@ namespace {
 #define PTMI_PIXELS_WAVES 7
 #endif
 constexpr int kMinPassSamples = 1;                           // the fewest samples an ordered pass may hold (a lane publishes an item before it takes the next)
+constexpr unsigned int kChunkSlots = 64;                     // ordered passes, fenced hand-off: chunks a wave may have in flight (one counter each in LDS)
 template <bool LDS_SCENE, bool PASSES>
 __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixels_kernel(const RenderArgs a, const ItemArgs it)
 {
     // the lane's item: 0-2 position of the start hit, 3-5 axis and 6 half-angle scale of its bounce, 7 primitive, 8 quad,
     // 9 the lane's count of shaded hits when the item began, 10 the samples the item renders, 11 its region
     __shared__ float item_const[12][kRenderBlock];
+    __shared__ unsigned int chunk_left[kChunkSlots], chunk_total[kChunkSlots];      // (PASSES only: the other instantiations never touch them)
     extern __shared__ float4 lds_scene[];
     const int ns = a.scene.n_spheres, np = a.scene.n_planes;
     if (LDS_SCENE) {
@@ -36,18 +38,26 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
     // long as the last items.  The samples are therefore cut into passes: an item renders one pass's samples of its pixel, and the
     // pixel's seven words travel through the planes to whichever lane -- of any wave, on any XCD -- takes its next pass.  What orders
     // them: an item of pass p is handed out only when region_done[its region] says that every item of the region's pass p - 1 has
-    // been PUBLISHED.  The L2s of the eight XCDs are not coherent with each other and a CU's L1 is never refreshed, so the seven
-    // words are stored WRITE-THROUGH (sc1: agent-scope relaxed atomic stores), the storing wave waits for its stores (vmcnt(0))
-    // before its lanes add to the region's counter (agent-scope atomics), and the taking lanes read counter and words with sc1
-    // loads, which pass the L1 by and are served coherently (MI355X_MICROARCH.md, "Valid forms": every store of the handed-off bytes
-    // sc1 and drained before the counter moves, every load of them sc1; the loads come after the poll of the same wave).  No fence:
-    // an agent-scope release is a write-back of the XCD's whole L2, and the L2 serves them one after the other -- 7 168 waves
-    // releasing every 16 trips (112 write-backs per microsecond on the chip) DOUBLED the launch (1080p / 64 spp as four passes:
-    // 4.5 -> 9.4 ms), and releasing in batches of up to 256 trips still cost more than short passes gained.
+    // been PUBLISHED.  The L2s of the eight XCDs are not coherent with each other and a CU's L1 is never refreshed.  Two hand-offs:
+    //   * FENCED (it.fenced, the default since round 6): the architecturally promised form -- stores, the storing wave's vmcnt(0), an
+    //     agent-scope RELEASE, the counter; on the taking side the poll, then an agent-scope ACQUIRE, then the loads.  A release is a
+    //     chip resource (a write-back of the XCD's L2: 7 168 waves releasing every 16 trips DOUBLED a launch in round 3), so it is paid
+    //     once per (region, pass), not per item: every item of a chunk is taken by the ONE wave that drew its ticket, so that wave
+    //     knows when the chunk's last item ends -- a counter per chunk in flight in LDS, decremented by the lane that ends an item -- and
+    //     that lane alone releases and adds the chunk's whole count.  130 000 releases per launch of one of 8 parts of a 4K image at
+    //     1024 spp instead of 8.3 million: 3.6 per microsecond on the chip.  (The words are still stored write-through, so the release
+    //     finds the L2 clean of them.)
+    //   * FENCE-FREE (PTMI_OPT_PASS_HANDOFF = 1, rounds 3-5's form): the seven words are stored WRITE-THROUGH (sc1), the storing wave
+    //     waits for its stores (vmcnt(0)) before its lanes add to the region's counter, and the taking lanes read counter and words with
+    //     sc1 loads (MI355X_MICROARCH.md, "Valid forms").  Measured valid on gfx950 over 5 billion hand-offs, not promised by the
+    //     memory model: the caller's explicit choice only.
     // Nothing here depends on which XCD or CU a wave runs on.
     // (PASSES is a template parameter: carried as run-time branches the blocks below cost the one-pass kernel 3.8 % -- 4.57 -> 4.75 ms on
     // S16 -- in scalar registers spilled and instructions per trip)
     const int passes = PASSES ? it.passes : 1;
+    const bool fenced = PASSES && it.fenced != 0;            // wave-uniform (a kernel argument)
+    if (PASSES) { if (threadIdx.x < (int)kChunkSlots) chunk_left[threadIdx.x] = 0u; }      // (one wave per workgroup: LDS operations of a wave are in order)
+    unsigned int chunk_serial = 0, cur_slot = 0;
     float *mine = &item_const[0][threadIdx.x];
     auto put = [&](int k, float v) { mine[k * kRenderBlock] = v; };
     auto get = [&](int k) { return mine[k * kRenderBlock]; };
@@ -61,7 +71,25 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
     // waves leave as they end: ptmi_api.cpp)
     cur.n_positions = it.n_positions;
     if (it.tail_start) { const unsigned int t = *it.tail_start; cur.n_positions = t < it.n_positions ? t : it.n_positions; }
-    next_chunk<false>(cur, it);
+    // The wave's next chunk.  Fenced hand-off: the chunk gets a slot for its count of unfinished items; if the slot's previous tenant -- the
+    // chunk drawn kChunkSlots chunks ago -- still has an item running in some lane (one very long item), no ticket is drawn now and the
+    // refill tries again next trip: the busy lanes go on, their items end, the slot frees (no lane busy = no slot taken: the loop's exit
+    // condition is never starved).
+    auto take_chunk = [&]() {
+        if (fenced) {
+            const unsigned int slot = (chunk_serial + 1u) & (kChunkSlots - 1u);
+            const unsigned int tenant = (unsigned int)__builtin_amdgcn_readfirstlane((int)chunk_left[slot]);
+            if (tenant != 0u) { cur.taken = 0; cur.len = 0; return; }
+            next_chunk<false>(cur, it);
+            if (cur.len) {
+                ++chunk_serial; cur_slot = slot;
+                if (lane == 0) { chunk_left[slot] = cur.len; chunk_total[slot] = cur.len; }
+            }
+        } else {
+            next_chunk<false>(cur, it);
+        }
+    };
+    take_chunk();
     diag::TailProbe probe; probe.begin();                     // (diagnostic builds: ptmi_diag.h)
 
     bool busy = false, pending = false, has_ray = false, over = false, unpublished = false;
@@ -74,8 +102,12 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
     for (;;) {
         // ---- publish (ordered passes): the items whose words this wave stored in its last trip (a trip ago: the wait is free)
         if (PASSES && __any(unpublished)) {                   // wave-uniform
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the write-through stores have completed before the counters move
-            if (unpublished) { atomicAdd(it.region_done + f2u(get(11)), 1u); unpublished = false; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stores have completed before the counters move
+            if (fenced) {                                     // a chunk of this wave is complete: ONE release for all its items' words
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the compiler may drop the wait behind buffer_wbl2 when it believes the scoreboard empty)
+                if (unpublished) { const unsigned int at = f2u(get(11)); atomicAdd(it.region_done + (at & 0x3ffffffu), chunk_total[at >> 26]); unpublished = false; }
+            } else if (unpublished) { atomicAdd(it.region_done + (f2u(get(11)) & 0x3ffffffu), 1u); unpublished = false; }
         }
         // ---- refill: idle lanes take the next start hits of the wave's chunk (at once: an item is a pixel's whole sample chain)
         const unsigned long long idle = __ballot(!busy);
@@ -88,8 +120,10 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
             // but this keeps a future compiler from hoisting them above the poll they depend on -- the mirror of the storing side's asm memory
             // clobber.  The hardware orders them: same wave, loads issued after the poll's value has returned.)
             asm volatile("" ::: "memory");
-            if (done >= cur.pass * cur.len) cur.ready = true;
-            else { open = false; if (!__any(busy)) __builtin_amdgcn_s_sleep(8); }
+            if (done >= cur.pass * cur.len) {
+                cur.ready = true;
+                if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // ONE poll, ONE acquire, then this wave's loads of the region's words
+            } else { open = false; if (!__any(busy)) __builtin_amdgcn_s_sleep(8); }
         }
         if (open) {                                           // wave-uniform
             probe.refill_begin();
@@ -104,7 +138,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
                 put(3, r0.w); put(4, r1.x); put(5, r1.y); put(6, r1.z);
                 put(7, r3.x); put(8, r3.w); put(9, u2f(live));
                 // the samples of this pass: n_spp over the passes, the first (n_spp mod passes) passes one more
-                put(10, u2f((uint32_t)(a.n_spp / passes + ((int)cur.pass < a.n_spp % passes ? 1 : 0)))); put(11, u2f(cur.region));
+                put(10, u2f((uint32_t)(a.n_spp / passes + ((int)cur.pass < a.n_spp % passes ? 1 : 0)))); put(11, u2f(cur.region | (cur_slot << 26)));   // (regions: < 2^26, checked by the host)
                 if (PASSES) {                                  // another wave's stores of a moment ago: sc1 loads
                     acc = mk(load_agent(&plane_at(a.planes.r, pixel4)), load_agent(&plane_at(a.planes.g, pixel4)), load_agent(&plane_at(a.planes.b, pixel4)));
                     pixel_seed.a = load_agent(&plane_at(a.planes.sa, pixel4)); pixel_seed.b = load_agent(&plane_at(a.planes.sb, pixel4));
@@ -117,7 +151,7 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
                 s = -1; busy = true; over = true; pending = false; has_ray = false;
             }
             cur.taken += take;
-            if (cur.taken >= cur.len) next_chunk<false>(cur, it);
+            if (cur.taken >= cur.len) take_chunk();
             probe.refill_end(take);
         }
         if (!__any(busy) && !chunks_left(cur)) break;      // (no lane busy, chunks left: nothing below has a lane to run for; the next trip refills)
@@ -160,7 +194,8 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
                     store_agent(&plane_at(a.planes.r, pixel4), acc.x); store_agent(&plane_at(a.planes.g, pixel4), acc.y); store_agent(&plane_at(a.planes.b, pixel4), acc.z);
                     store_agent(&plane_at(a.planes.sa, pixel4), pixel_seed.a); store_agent(&plane_at(a.planes.sb, pixel4), pixel_seed.b);
                     store_agent(&plane_at(a.planes.sc, pixel4), pixel_seed.c); store_agent(&plane_at(a.planes.sctr, pixel4), pixel_seed.counter);
-                    unpublished = true;                        // published at the top of the next trip
+                    // published at the top of the next trip: every item (fence-free), or the chunk by the lane that ends its LAST item (fenced)
+                    unpublished = fenced ? atomicSub(&chunk_left[f2u(get(11)) >> 26], 1u) == 1u : true;
                 } else {
                     plane_at(a.planes.r, pixel4) = acc.x; plane_at(a.planes.g, pixel4) = acc.y; plane_at(a.planes.b, pixel4) = acc.z;
                     plane_at(a.planes.sa, pixel4) = pixel_seed.a; plane_at(a.planes.sb, pixel4) = pixel_seed.b;
@@ -201,7 +236,8 @@ __global__ void __launch_bounds__(kRenderBlock, PTMI_PIXELS_WAVES) streams_pixel
     }
     if (PASSES && __any(unpublished)) {                      // (nobody waits for the last pass; a wave that ends earlier owes its items)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (unpublished) atomicAdd(it.region_done + f2u(get(11)), 1u);
+        if (fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        if (unpublished) { const unsigned int at = f2u(get(11)); atomicAdd(it.region_done + (at & 0x3ffffffu), fenced ? chunk_total[at >> 26] : 1u); }
     }
     probe.flush(a.work_counter);
     // statistics: the per-pixel kernels' sharded counters

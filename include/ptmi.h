@@ -36,7 +36,8 @@ extern "C" {
 #endif
 
 #define PTMI_VERSION 600   /* 0.6.0: the chained closure (ptmi_render1_chained, ptmi_chain_*: device residency behind compileFor's pure type), PTMI_ESTALE,
-                            * option 14; ptmi_build_id names the compiled code, not the source text.  0.5.0: ptmi_build_id; ptmi_debug_counters writes 64 words again (as in 0.3) and ptmi_debug_counters_n takes a
+                            * options 14 and 15, PTMI_FORM_PIXEL; ordered passes hand off with release / acquire per region; ptmi_build_id names the
+                            * compiled code, not the source text.  0.5.0: ptmi_build_id; ptmi_debug_counters writes 64 words again (as in 0.3) and ptmi_debug_counters_n takes a
                             * capacity; option 13 and ptmi_stream_tickets; the stream form's overflow streams grow instead of dropping children;
                             * no option is read from the environment any more.  (0.4.0: options 8-12, ptmi_stream_schedule.) */
 
@@ -222,14 +223,11 @@ enum {
      * where a lane sees fewer than four pixels), 0 = no tail. */
     PTMI_OPT_STREAM_TAIL = 8,
     /* PTMI_OPT_ORDERED_PASSES: scenes without GLASS: a pixel's samples cut into this many ORDERED passes inside the one launch; the pixel's
-     * seven words are handed from the lane that rendered pass p to whichever lane -- of any wave, on any XCD -- takes pass p + 1, through
-     * write-through (sc1) stores, a counter that moves after the storing wave's vmcnt(0), and sc1 loads after the poll.  That hand-off
-     * uses NO FENCE: it is the "valid form" of MI355X_MICROARCH.md, MEASURED valid on gfx950 (5 billion hand-offs compared bit for bit,
-     * profiles/r05_soak_ordered_passes.json) -- not a promise of the HSA memory model.  Since 0.6 it is therefore NEVER chosen automatically:
-     * 0 (default) and 1 = one pass per launch, no hand-off between waves at all -- only architecturally guaranteed synchronisation;
-     * k in [2, 64] = k passes, the caller's explicit choice (worth 5-8 % for one of 8 parts of a 4K image at >= 256 spp, where a lane sees
-     * fewer than three pixels).  1 also overrides PTMI_OPT_STREAM_BATCH for scenes without GLASS.  (Until 0.4 the environment variables
-     * PTMI_ORDERED_PASSES / PTMI_STREAM_TAIL overrode these two options at creation; nothing is read from the environment any more.) */
+     * seven words are handed from the lane that rendered pass p to whichever lane -- of any wave, on any XCD -- takes pass p + 1
+     * (PTMI_OPT_PASS_HANDOFF says how).  0 (default) = automatic: passes only for parts of an image at >= 256 spp, where a lane sees fewer
+     * than three pixels and they are worth 5-8 % -- and only with the FENCED hand-off; 1 = OFF: one pass per launch, no hand-off between
+     * waves at all; k in [2, 64] = k passes.  1 also overrides PTMI_OPT_STREAM_BATCH for scenes without GLASS.  (Until 0.4 the environment
+     * variables PTMI_ORDERED_PASSES / PTMI_STREAM_TAIL overrode these two options at creation; nothing is read from the environment any more.) */
     PTMI_OPT_ORDERED_PASSES = 9,
     /* PTMI_OPT_GLASS_BATCH: scenes with GLASS: a GLASS hit waits in its lane until this many lanes of its wave hold one (or the wave has
      * nothing else to shade or trace), so that the refraction block runs for that many lanes at a time.  0 (default) = automatic,
@@ -257,8 +255,18 @@ enum {
     /* PTMI_OPT_CHAIN_SLOTS: how many states of the chained closure (ptmi_render1_chained below) may stay on the DEVICE at a time; the oldest one
      * beyond that moves to host memory the library owns (nothing is lost; ptmi_chain_fetch serves it from there).  0 (default) = automatic: what
      * a sixteenth of the device's memory holds, at least 3, at most 64; otherwise k in [2, 4096]. */
-    PTMI_OPT_CHAIN_SLOTS = 14
+    PTMI_OPT_CHAIN_SLOTS = 14,
+    /* PTMI_OPT_PASS_HANDOFF: how ordered passes (PTMI_OPT_ORDERED_PASSES) hand a pixel's words from wave to wave.
+     * PTMI_HANDOFF_FENCED (default): what the HSA memory model promises -- the storing wave's vmcnt(0), an agent-scope RELEASE, the region's
+     * counter; the taking wave's poll, an agent-scope ACQUIRE, its loads -- paid once per (region, pass), not per item: all items of a region's
+     * pass run in the one wave that drew its ticket, and the lane that ends the last of them releases for all.
+     * PTMI_HANDOFF_FENCE_FREE: rounds 3-5's form -- write-through (sc1) stores, a counter that moves after the storing wave's vmcnt(0), sc1
+     * loads after the poll, NO fence: the "valid form" of MI355X_MICROARCH.md, MEASURED valid on gfx950 (5 billion hand-offs compared bit for
+     * bit, profiles/r05_soak_ordered_passes.json) -- not a promise of the memory model.  Never chosen automatically: with this value
+     * PTMI_OPT_ORDERED_PASSES = 0 means one pass. */
+    PTMI_OPT_PASS_HANDOFF = 15
 };
+enum { PTMI_HANDOFF_FENCED = 0, PTMI_HANDOFF_FENCE_FREE = 1 };
 enum { PTMI_ARITH_EXACT = 0, PTMI_ARITH_CONTRACTED = 1 };
 enum { PTMI_SEED_KEEP_ACCUMULATOR = 0, PTMI_SEED_FROM_RESULT = 1, PTMI_SEED_AUTO = 2 };
 enum { PTMI_FORM_AUTO = 0, PTMI_FORM_STREAM = 1, PTMI_FORM_PIXEL = 2 };

@@ -194,13 +194,15 @@ def test_a_call_that_would_drop_children_is_redone_with_longer_streams(pkg, ora,
         assert c.get_option(B.OPT_STREAM_CAPACITY) == 2
 
 
+@pytest.mark.parametrize("handoff", ["fenced", "fence_free"])
 @pytest.mark.parametrize("rule", ["auto", "keep"])
-def test_ordered_passes_inside_one_launch_are_bit_exact(ctx, pkg, ora, rule):
+def test_ordered_passes_inside_one_launch_are_bit_exact(ctx, pkg, ora, rule, handoff):
     """Without a ray-splitting material the stream form cuts a pixel's samples into ORDERED passes inside its one launch (a
     pixel's seven words travel through the planes from the lane that rendered one pass to whichever lane takes the next; a pass
-    is handed out once the previous one has been published: write-through stores, then the region's counter): here 64 samples as
-    4 items of 16 and as 2 of 32 (PTMI_OPT_STREAM_BATCH under the result's-seed rule, where a pixel's samples are one serial chain) -- bit-identical
-    to the oracle, both seed rules, image with and without whole tiles."""
+    is handed out once the previous one has been published): here 64 samples as 4 items of 16, as 2 of 32 and as 32 of 2
+    (PTMI_OPT_STREAM_BATCH under the result's-seed rule, where a pixel's samples are one serial chain) -- bit-identical to the oracle, both seed
+    rules, image with and without whole tiles, through BOTH hand-offs (PTMI_OPT_PASS_HANDOFF): release / acquire once per region and pass
+    (the default since 0.6; 32 passes of 2 samples put many chunks of a wave in flight at once), and the fence-free write-through form."""
     B = pkg.binding
     scene = pkg.world.scene16()
     cam = pkg.world.initial_camera()
@@ -209,11 +211,12 @@ def test_ordered_passes_inside_one_launch_are_bit_exact(ctx, pkg, ora, rule):
         start = initial_planes(ora, w, h)
         seed_rule = ora.SEED_KEEP_ACCUMULATOR if rule == "keep" else None
         want, live = ora.render_streams(scene[0], scene[1], cam, w, h, CAP, spp, start, seed_rule=seed_rule)
-        for batch in (16, 32):
+        for batch in (16, 32, 2):
             with pkg.Context(0) as c:
                 c.set_scene(*scene)
                 c.resize(w, h)
                 c.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+                c.set_option(B.OPT_PASS_HANDOFF, B.HANDOFF_FENCED if handoff == "fenced" else B.HANDOFF_FENCE_FREE)
                 if rule == "keep":                               # (under the keep rule a batch selects the unordered split kernel instead)
                     c.set_option(B.OPT_STREAMS_SEED_RULE, B.SEED_KEEP_ACCUMULATOR)
                     c.set_option(B.OPT_ORDERED_PASSES, spp // batch)
@@ -347,12 +350,13 @@ def test_options_of_the_stream_form_are_range_checked_and_visible(pkg):
     B = pkg.binding
     with pkg.Context(0) as c:
         defaults = {B.OPT_STREAM_TAIL: -1, B.OPT_ORDERED_PASSES: 0, B.OPT_GLASS_BATCH: 0, B.OPT_STREAM_GRADED: 1, B.OPT_SNAPSHOT_BUDGET_MB: 0,
-                    B.OPT_STREAM_PASS_GROUPS: 0}
+                    B.OPT_STREAM_PASS_GROUPS: 0, B.OPT_PASS_HANDOFF: B.HANDOFF_FENCED, B.OPT_CHAIN_SLOTS: 0}
         for opt, value in defaults.items():
             assert c.get_option(opt) == value
         for opt, bad in ((B.OPT_STREAM_TAIL, -2), (B.OPT_STREAM_TAIL, 1001), (B.OPT_ORDERED_PASSES, -1), (B.OPT_ORDERED_PASSES, 65),
                          (B.OPT_GLASS_BATCH, 65), (B.OPT_STREAM_GRADED, 2), (B.OPT_SNAPSHOT_BUDGET_MB, -1), (B.OPT_SNAPSHOT_BUDGET_MB, (1 << 20) + 1),
-                         (B.OPT_STREAM_PASS_GROUPS, -1), (B.OPT_STREAM_PASS_GROUPS, 65), (B.OPT_STREAM_PASS_GROUPS, 101), (B.OPT_STREAM_PASS_GROUPS, 165)):
+                         (B.OPT_STREAM_PASS_GROUPS, -1), (B.OPT_STREAM_PASS_GROUPS, 65), (B.OPT_STREAM_PASS_GROUPS, 101), (B.OPT_STREAM_PASS_GROUPS, 165),
+                         (B.OPT_PASS_HANDOFF, 2), (B.OPT_PASS_HANDOFF, -1), (B.OPT_CHAIN_SLOTS, 1), (B.OPT_CHAIN_SLOTS, 4097)):
             with pytest.raises(pkg.PtmiError) as e:
                 c.set_option(opt, bad)
             assert e.value.code == B.PTMI_EINVAL

@@ -39,6 +39,13 @@ for _k in (0, 50, 100, 150, 200, 250, 300, 400, 500):      # PTMI_OPT_STREAM_TAI
 WORKLOADS["c2_v17"] = ("s16", "inline", "auto", {"VARIANT": 17}, None)     # render Inline with the scene through scalar loads instead of LDS (ptmi_set_variant 17)
 WORKLOADS["c2_main"] = ("main", "inline", "auto", {}, None)                # ... on mainScene (7 primitives)
 C4_PART = (3840, 2160, 1024, 8)     # one of 8 parts of BASELINE configs[3]
+C4_PART_256 = (3840, 2160, 256, 8)
+for _tag, _shape in (("c4p", C4_PART), ("c4p256", C4_PART_256)):           # the stream form on one part, S16: ordered passes and their hand-off
+    WORKLOADS[_tag + "_stream_1pass"] = ("s16", "streams", "stream", {"ORDERED_PASSES": 1}, _shape)
+    WORKLOADS[_tag + "_stream_auto"] = ("s16", "streams", "stream", {}, _shape)
+    for _k in (4, 8):
+        WORKLOADS[_tag + "_stream_%dfenced" % _k] = ("s16", "streams", "stream", {"ORDERED_PASSES": _k, "PASS_HANDOFF": 0}, _shape)
+        WORKLOADS[_tag + "_stream_%dfree" % _k] = ("s16", "streams", "stream", {"ORDERED_PASSES": _k, "PASS_HANDOFF": 1}, _shape)
 WORKLOADS["c4_part"] = ("s16", "inline", "auto", {}, C4_PART)
 WORKLOADS["c4_part_streams"] = ("s16", "streams", "auto", {}, C4_PART)
 for _k in (1, 2, 4, 5, 6, 8, 12, 16):

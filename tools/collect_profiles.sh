@@ -37,6 +37,7 @@ for w in streams s16_stream; do [ -d "$ROOT/gpurun_out/pmcx_$w" ] && python3 "$R
 for f in split_stats tail_stats tail_phases; do [ -s "$SRC/$f.json" ] && cp "$SRC/$f.json" "$ROOT/profiles/${TAG}_$f.json"; done
 [ -s "$SRC/contracted.json" ] && cp "$SRC/contracted.json" "$ROOT/profiles/${TAG}_contracted_arithmetic.json"
 [ -s "$SRC/traffic_terms.json" ] && cp "$SRC/traffic_terms.json" "$ROOT/profiles/${TAG}_traffic_terms.json"
+[ -s "$SRC/soak_passes.json" ] && cp "$SRC/soak_passes.json" "$ROOT/profiles/${TAG}_soak_ordered_passes.json"
 [ -s "$SRC/c0_calls.json" ] && cp "$SRC/c0_calls.json" "$ROOT/profiles/${TAG}_c0_calls.json"
 for f in tree_stats; do [ -s "$SRC/$f.json" ] && cp "$SRC/$f.json" "$ROOT/profiles/${TAG}_$f.json"; done
 true

@@ -54,6 +54,8 @@ bash tools/pmc_extra.sh streams --algorithm streams > "$OUT/pmcx_streams.log" 2>
 bash tools/pmc_extra.sh s16_stream --algorithm streams --streams-form stream > "$OUT/pmcx_s16_stream.log" 2>&1; echo "pmcx s16 stream rc=$?"
 timeout -k 10 300 python3 tools/contracted_report.py > "$OUT/contracted.json" 2> "$OUT/contracted.log"; echo "contracted rc=$?"
 # 7. where the split kernel's HBM bytes go, term by term (product, ticket orders, measurement builds that leave one source out)
+# 8a. the ordered passes of the stream form under load, default (fenced) hand-off: every launch bit for bit against the chain kernel
+timeout -k 10 400 python3 tools/soak_passes.py 120 fenced > "$OUT/soak_passes.json" 2> "$OUT/soak_passes.log"; echo "soak rc=$?"
 # 8. the reference's own configuration through the three forms of the boundary (resident, compatible closure, chained closure)
 timeout -k 10 300 python3 tools/c0_calls.py > "$OUT/c0_calls.json" 2> "$OUT/c0_calls.log"; echo "c0 calls rc=$?"
 timeout -k 10 900 python3 tools/traffic_terms.py --out "$ROOT/gpurun_out/traffic_terms_$TAG" --variants product,pass_by_pass,one_group,uniform_4x16,skip_item_atomics,skip_ring_atomics,skip_item_costs > "$OUT/traffic_terms.json" 2> "$OUT/traffic_terms.log"; echo "traffic terms rc=$?"

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""soak_passes.py [launches] -- the ordered passes of the stream form under load: C2's image (1920x1080, 64 spp, S16) rendered by
+"""soak_passes.py [launches] [fenced|fence_free] -- the ordered passes of the stream form under load: C2's image (1920x1080, 64 spp, S16) rendered by
 the per-pixel chain kernel and, with the same seeds, by the stream form: in turn as whole sample chains (one pass, the cheap end of
 the dispatch order rendered by the chain kernel beside the persistent launch) and with the chains cut into 64, 32, 16, 8 and 4 ordered
-passes (items of 1, 2, 4, 8, 16 samples: up to 130 million hand-offs per launch, lane to lane through the planes, write-through stores
-+ counter + sc1 loads), while a third context renders render Inline on a stream of its own beside them.
+passes (items of 1, 2, 4, 8, 16 samples: up to 130 million hand-offs per launch, lane to lane through the planes -- by default with the
+library's default hand-off, release / acquire once per region and pass; `fence_free`: write-through stores + counter + sc1 loads), while a
+third context renders render Inline on a stream of its own beside them.
 Every launch: all seven planes of the two forms compared bit for bit.  Prints one JSON line."""
 import json
 import os
@@ -18,6 +19,7 @@ import __graft_entry__ as graft  # noqa: E402
 
 def main():
     launches = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    handoff = sys.argv[2] if len(sys.argv) > 2 else "fenced"
     pkg = graft.load_package()
     pkg._build.build_lib()
     B = pkg.binding
@@ -30,6 +32,7 @@ def main():
             c.resize(1920, 1080)
             c.init_output(0x5EED1234)
         stream.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+        stream.set_option(B.OPT_PASS_HANDOFF, B.HANDOFF_FENCE_FREE if handoff == "fence_free" else B.HANDOFF_FENCED)
         hits = None
         for k in range(launches):
             batch = (0, 1, 2, 4, 8, 16)[k % 6]              # 0: whole sample chains, with the per-pixel tail beside the persistent launch
@@ -50,7 +53,8 @@ def main():
                 print("launch %d ok" % (k + 1), file=sys.stderr, flush=True)
     print(json.dumps({"ok": True, "launches": launches, "image": "1920x1080, 64 spp, S16", "samples_per_item_cycle": ["all (one pass, per-pixel tail)", 1, 2, 4, 8, 16],
                       "handoffs_between_lanes_at_least": handoffs, "compared": "all seven planes, bit for bit, against the per-pixel chain kernel, every launch",
-                      "beside": "a third context rendering render Inline on its own stream"}))
+                      "beside": "a third context rendering render Inline on its own stream", "handoff": handoff,
+                      "binary_build_id": pkg.load_library().build_id}))
 
 
 if __name__ == "__main__":
