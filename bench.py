@@ -236,21 +236,32 @@ def also_measurements(pkg, torch):
             for _ in range(40 if chained else 5):
                 one()
             c.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(calls):
-                one()
-            c.synchronize()
-            ms = (time.perf_counter() - t0) * 1e3 / calls
+            # three timed blocks, the median reported, Python's cyclic collector off: in this process -- torch's heap beside it -- a full
+            # collection takes ~40 ms, the loop allocates a few containers per call, and one collection inside a block of calls that
+            # cost 30 us each multiplied the block's figure by ten (tools/chain_variance.py: always at the same call, gone with gc off)
+            import gc
+            blocks = []
+            gc.collect(); gc.disable()
+            try:
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    for _ in range(calls):
+                        one()
+                    c.synchronize()
+                    blocks.append((time.perf_counter() - t0) * 1e3 / calls)
+            finally:
+                gc.enable()
+            ms = sorted(blocks)[1]
             info = c.chain_info() if chained else None
-        rec = {"workload": name, "ms_per_step": round(ms, 4), "kernel_ms": None, "steps": calls, "note": note,
+        rec = {"workload": name, "ms_per_step": round(ms, 4), "kernel_ms": None, "steps": calls, "blocks_ms_per_call": [round(b, 4) for b in blocks], "note": note,
                "Msamples_per_s": round(800 * 600 * 15 / (ms * 1e-3) / 1e6, 1)}
         if info:
             rec["chain"] = {k: info[k] for k in ("renders_chained", "renders_uploaded", "evictions", "states_on_device", "states_on_host")}
         out.append(rec)
     closure("C0 through the compatible closure, chained (ptmi_render1_chained: compileFor's pure type, results left on the device; what haskell/patches/Main.hs.diff wires)",
-            True, 400, "wall clock per closure call; nothing is fetched (graphicsLoop's read of three colour planes costs ~0.27 ms when it happens)")
+            True, 150, "wall clock per closure call (median of three blocks); nothing is fetched (graphicsLoop's read of three colour planes costs ~0.27 ms when it happens)")
     closure("C0 through the compatible closure, copying (ptmi_render1: seven host planes in and out per call; the closure until 0.5)",
-            False, 30, "wall clock per closure call, PCIe both ways inside")
+            False, 12, "wall clock per closure call (median of three blocks), PCIe both ways inside")
     run("C3: 3840x2160, 256 spp, limit 8, S16, render Inline", "s16", 3840, 2160, 256, BOUNCE_LIMIT, pkg.INLINE)
     run("C4: 3840x2160, 1024 spp, limit 8, S16, render Inline, the whole image on one GPU", "s16", 3840, 2160, 1024, BOUNCE_LIMIT, pkg.INLINE, warm=2)
     run("C4, one part of 8 (10-row stripes): what one rank of the 8-GPU job renders", "s16", 3840, 2160, 1024, BOUNCE_LIMIT, pkg.INLINE, part_of=8)

@@ -58,7 +58,7 @@ def tables(tag):
         % (cpu["cores"], cpu["cores"], cpu["affinity_cpus"], cpu["value"], cpu["value"] * 7 / 1e3, cpu["single_thread_value"], th(round(b["value"] / cpu["value"], -2))),
         "| C0 800×600, `mainScene`, limit 15 (the reference's own configuration), resident: 1 / 30 spp per call | 1× MI355X | — | %.3f (%.3f) / %.3f | — | |"
         % (c0["ms_per_step"], c0["kernel_ms"], c0b["ms_per_step"]),
-        "| C0 through `compileFor`'s closure, one sample per call: **chained / copying** | 1× MI355X | %s / %s | **%.4f / %.3f** | — | `ptmi_render1_chained` (%d of %d inputs found on the device) / `ptmi_render1` |"
+        "| C0 through `compileFor`'s closure, one sample per call: **chained / copying** | 1× MI355X | %s / %s | **%.4f / %.3f** | — | `ptmi_render1_chained` (%d of %d inputs found on the device) / `ptmi_render1`; medians of three blocks |"
         % (th(cl_ch["Msamples_per_s"]), th(cl_cp["Msamples_per_s"]), cl_ch["ms_per_step"], cl_cp["ms_per_step"], cl_ch["chain"]["renders_chained"], cl_ch["chain"]["renders_chained"] + cl_ch["chain"]["renders_uploaded"]),
         "| C3 3840×2160, 256 spp | 1× MI355X | %s | %.1f | %s (%.1f %%) | |" % (th(c3["Msamples_per_s"]), c3["ms_per_step"], th(c3["algorithmic_GBps"]), c3["algorithmic_GBps"] / 80.0),
         "| C4 3840×2160, 1024 spp, whole image / one part of 8 | 1× MI355X | %s / — | %.1f / %.2f | %s (%.1f %%) | §6: every part, three stripe heights |"
