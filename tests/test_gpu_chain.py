@@ -289,3 +289,76 @@ def test_random_walks_over_the_chain_api_equal_a_model_of_values(fresh, pkg, ora
     info = ctx.chain_info()
     assert info["states_on_device"] + info["states_on_host"] == len(model) and info["states_on_device"] <= 3
     assert info["evictions"] > 20 and ops["consume"] > 10 and ops["release"] > 10 and ops["from_host"] > 5, (info, ops)
+
+
+def test_three_threads_share_the_closure_like_the_application(fresh, pkg, ora):
+    """app/Main.hs:178-180: a computation thread applies the closure in a loop, the graphics thread reads the colour planes of whatever value
+    the MVar holds, a third thread lets old values go -- all on ONE context, entered from three OS threads at once (ctypes drops the GIL
+    inside the calls).  Every colour snapshot the reader took must be the oracle's planes after exactly that many samples."""
+    import threading
+    import time
+    ctx = fresh
+    sp, pl = pkg.world.main_scene()
+    cam = pkg.world.initial_camera()
+    w, h, limit, total = 64, 40, 15, 240
+    ctx.set_scene(sp, pl)
+    start = initial_planes(ora, w, h, 5)
+    lock = threading.Lock()
+    state = {"value": (0, ctx.chain_init_output(w, h, 5)), "old": [], "done": False, "error": None}
+    snapshots = []
+
+    def compute():
+        try:
+            for _ in range(total):
+                k, tok = state["value"]
+                new, _ = ctx.render1_chained(cam, limit, w, h, tok)
+                with lock:
+                    state["value"] = (k + 1, new)
+                    state["old"].append(tok)
+        except Exception as e:                               # noqa: BLE001
+            state["error"] = e
+        finally:
+            state["done"] = True
+
+    def graphics():
+        try:
+            while not state["done"]:
+                with lock:
+                    k, tok = state["value"]
+                    # (the value in hand cannot be released under the reader: the releaser only takes what left `value` before)
+                    r, g, b = ctx.chain_fetch(tok, w, h, "r g b")
+                if not snapshots or snapshots[-1][0] != k:
+                    snapshots.append((k, r, g, b))
+                time.sleep(0.001)                            # (graphicsLoop does not spin either; a spinning reader starves the lock)
+        except Exception as e:                               # noqa: BLE001
+            state["error"] = e
+
+    def releaser():
+        try:
+            while True:
+                finished = state["done"]
+                with lock:                                   # (all but the newest: nobody holds those any more; after the end, all of them)
+                    olds, state["old"] = (state["old"], []) if finished else (state["old"][:-1], state["old"][-1:])
+                for t in olds:
+                    ctx.chain_release(t)
+                if finished:
+                    break
+                time.sleep(0.001)
+        except Exception as e:                               # noqa: BLE001
+            state["error"] = e
+
+    threads = [threading.Thread(target=f, daemon=True) for f in (compute, graphics, releaser)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not any(t.is_alive() for t in threads), "a thread did not finish"
+    assert state["error"] is None, state["error"]
+    assert state["value"][0] == total and len(snapshots) >= 3
+    picks = snapshots[:: max(1, len(snapshots) // 6)][:6] + [snapshots[-1]]
+    for k, r, g, b in picks:
+        want, _ = ora.render_inline(sp, pl, cam, w, h, limit, k, start)
+        assert_planes_equal([r, g, b], want[:3], "the reader's snapshot after %d samples" % k)
+    want, _ = ora.render_inline(sp, pl, cam, w, h, limit, total, start)
+    assert_planes_equal(ctx.chain_fetch(state["value"][1], w, h), want, "the final value")
+    assert ctx.chain_info()["renders_uploaded"] == 0
