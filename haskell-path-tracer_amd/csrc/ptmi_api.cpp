@@ -148,19 +148,28 @@ struct ptmi_ctx {
 namespace {
 
 thread_local std::string g_create_error;
+// The message of a failed call is the calling THREAD's (several threads may share a context -- the application has three, app/Main.hs:178-180
+// -- and two of them may fail at once: a pointer into the context's own string would be freed under the first reader by the second failure).
+thread_local std::string t_error;               // this thread's last failure on a context ...
+thread_local const ptmi_ctx *t_error_of = nullptr;   // ... and which
 
 int fail(ptmi_ctx *c, int code, const std::string &msg)
 {
-    if (c) c->err = msg; else g_create_error = msg;
+    if (c) { c->err = msg; t_error = msg; t_error_of = c; }      // (c->err: under c->mu, which every caller with a context holds)
+    else g_create_error = msg;
     return code;
 }
 
+// A runtime error leaves through this library's return code -- and not, a second time, through the runtime's sticky slot (hipGetLastError
+// keeps the last failure of the thread until somebody asks: the caller's next launch check, or another library's, would find it there).
 #define PTMI_HIP(c, call)                                                                  \
     do {                                                                                   \
         hipError_t e_ = (call);                                                            \
-        if (e_ != hipSuccess)                                                              \
+        if (e_ != hipSuccess) {                                                            \
+            (void)hipGetLastError();                                                       \
             return fail((c), e_ == hipErrorOutOfMemory ? PTMI_ENOMEM : PTMI_EHIP,           \
                         std::string(#call) + ": " + hipGetErrorString(e_));                \
+        }                                                                                  \
     } while (0)
 
 // PTMI_SEED_AUTO: `combine new old` (the seed of the result) wherever the reference defines the outcome -- no ray-splitting
@@ -1049,7 +1058,15 @@ const char *ptmi_strerror(int code)
     }
 }
 
-const char *ptmi_last_error(const ptmi_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char *ptmi_last_error(const ptmi_ctx *ctx)
+{
+    if (!ctx) return g_create_error.c_str();
+    if (t_error_of == ctx) return t_error.c_str();             // the caller's own failure: nobody else writes this string
+    thread_local std::string copy;                             // a failure another thread saw (a group's member threads): copied under the lock
+    std::lock_guard<std::mutex> lock(const_cast<ptmi_ctx *>(ctx)->mu);
+    copy = ctx->err;
+    return copy.c_str();
+}
 
 int ptmi_create(ptmi_ctx **out, int device)
 {
@@ -1068,7 +1085,7 @@ int ptmi_create(ptmi_ctx **out, int device)
     c->chain_serial = ++contexts_made;
     auto bail = [&](hipError_t err, const char *what) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);
-        ptmi_destroy(c);
+        ptmi_destroy(c);                                     // (also takes the error out of the runtime's sticky slot)
         return PTMI_EHIP;
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
@@ -1133,6 +1150,7 @@ void ptmi_destroy(ptmi_ctx *c)
     for (ptmi_ctx::ChainState &st : c->chain) if (st.block) (void)hipFree(st.block);
     for (auto &fb : c->chain_free) (void)hipFree(fb.second);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    (void)hipGetLastError();                                 // whatever failed above was ignored on purpose: it is nobody else's to find
     delete c;
 }
 

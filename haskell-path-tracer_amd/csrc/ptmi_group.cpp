@@ -81,23 +81,30 @@ struct ptmi_group {
 
 namespace {
 
-int gfail(ptmi_group *g, int code, const std::string &msg) { if (g) g->err = msg; return code; }
+// (the message is the calling thread's, as ptmi_last_error's: csrc/ptmi_api.cpp)
+thread_local std::string t_group_error;
+thread_local const ptmi_group *t_group_error_of = nullptr;
+
+int gfail(ptmi_group *g, int code, const std::string &msg)
+{
+    if (g) { g->err = msg; t_group_error = msg; t_group_error_of = g; }
+    return code;
+}
 
 int member_fail(ptmi_group *g, int i, int rc)
 {
-    g->err = "member " + std::to_string(i) + " (device " + std::to_string(g->devices[(size_t)i]) + "): " + ptmi_last_error(g->members[(size_t)i]);
-    return rc;
+    return gfail(g, rc, "member " + std::to_string(i) + " (device " + std::to_string(g->devices[(size_t)i]) + "): " + ptmi_last_error(g->members[(size_t)i]));
 }
 
 #define GROUP_HIP(g, call)                                                                       \
     do {                                                                                         \
         hipError_t e_ = (call);                                                                  \
-        if (e_ != hipSuccess) return gfail((g), e_ == hipErrorOutOfMemory ? PTMI_ENOMEM : PTMI_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+        if (e_ != hipSuccess) { (void)hipGetLastError(); return gfail((g), e_ == hipErrorOutOfMemory ? PTMI_ENOMEM : PTMI_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); } \
     } while (0)
 #define GROUP_NCCL(g, call)                                                                      \
     do {                                                                                         \
         ncclResult_t r_ = (call);                                                                \
-        if (r_ != ncclSuccess) return gfail((g), PTMI_EHIP, std::string(#call) + ": " + g_rccl.GetErrorString(r_)); \
+        if (r_ != ncclSuccess) { (void)hipGetLastError(); return gfail((g), PTMI_EHIP, std::string(#call) + ": " + g_rccl.GetErrorString(r_)); } \
     } while (0)
 
 void release_gather(ptmi_group *g)
@@ -164,6 +171,7 @@ void ptmi_group_destroy(ptmi_group *g)
         if (g->comm_streams[i]) { (void)hipSetDevice(g->devices[i]); (void)hipStreamDestroy(g->comm_streams[i]); }
     for (ncclComm_t c : g->comms) if (c && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c);
     for (ptmi_ctx *c : g->members) ptmi_destroy(c);
+    (void)hipGetLastError();                                 // (errors ignored above are not left in the runtime's sticky slot)
     delete g;
 }
 
@@ -175,7 +183,15 @@ ptmi_ctx *ptmi_group_member(ptmi_group *g, int i)
     return g->members[(size_t)i];
 }
 
-const char *ptmi_group_last_error(const ptmi_group *g) { return g ? g->err.c_str() : ""; }
+const char *ptmi_group_last_error(const ptmi_group *g)
+{
+    if (!g) return "";
+    if (t_group_error_of == g) return t_group_error.c_str();
+    thread_local std::string copy;
+    std::lock_guard<std::mutex> lock(const_cast<ptmi_group *>(g)->mu);
+    copy = g->err;
+    return copy.c_str();
+}
 
 int ptmi_group_set_scene(ptmi_group *g, const ptmi_sphere *spheres, int n_spheres, const ptmi_plane *planes, int n_planes)
 {
@@ -373,6 +389,7 @@ int ptmi_group_gather_color(ptmi_group *g, int root, float *r_dev, float *g_dev,
             what = "ncclRecv";
         }
         const ncclResult_t ended = g_rccl.GroupEnd();
+        if (inside != ncclSuccess || ended != ncclSuccess) (void)hipGetLastError();      // (a runtime error under RCCL's: reported here, not left behind)
         if (inside != ncclSuccess) return gfail(g, PTMI_EHIP, std::string(what) + ": " + g_rccl.GetErrorString(inside));
         if (ended != ncclSuccess) return gfail(g, PTMI_EHIP, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ended));
     }

@@ -216,24 +216,21 @@ hipError_t launch_render_inline(const RenderArgs &a, int variant, hipStream_t st
         const unsigned int per_copy = tile_grid(a, 8);
         if (hipError_t e = choose_sample_chunks(b, per_copy, PTMI_INLINE_WAVES, stream)) return e;
         const dim3 cgrid(per_copy * (unsigned int)b.spp_chunks);
-        if (variant == 17) hipLaunchKernelGGL((render_inline_kernel<false, 8>), cgrid, block, 0, stream, b);
-        else               hipLaunchKernelGGL((render_inline_kernel<true, 8>), cgrid, block, lds, stream, b);
-        return hipGetLastError();
+        return variant == 17 ? launch(render_inline_kernel<false, 8>, cgrid, block, 0, stream, b)
+                             : launch(render_inline_kernel<true, 8>, cgrid, block, lds, stream, b);
     }
-    if (variant == 5) { hipLaunchKernelGGL((render_inline_kernel<false>), grid, block, 0, stream, a); return hipGetLastError(); }
-    if (variant == 4) { hipLaunchKernelGGL((render_inline_kernel<true>), grid, block, lds, stream, a); return hipGetLastError(); }
+    if (variant == 5) return launch(render_inline_kernel<false>, grid, block, 0, stream, a);
+    if (variant == 4) return launch(render_inline_kernel<true>, grid, block, lds, stream, a);
 #if defined(PTMI_ABLATIONS) && !defined(PTMI_CONTRACTED_BUILD)
     if (variant >= 14 && variant <= 16) {                     // other pixel tiles per wave: 16x4 / 4x16 / 32x2 (8x8 is handled above)
         const int tw = variant == 14 ? 16 : variant == 15 ? 4 : 32;
         const dim3 tgrid(tile_grid(a, tw));
-        if (tw == 16)      hipLaunchKernelGGL((render_inline_kernel<true, 16>), tgrid, block, lds, stream, a);
-        else if (tw == 4)  hipLaunchKernelGGL((render_inline_kernel<true, 4>), tgrid, block, lds, stream, a);
-        else               hipLaunchKernelGGL((render_inline_kernel<true, 32>), tgrid, block, lds, stream, a);
-        return hipGetLastError();
+        if (tw == 16) return launch(render_inline_kernel<true, 16>, tgrid, block, lds, stream, a);
+        if (tw == 4)  return launch(render_inline_kernel<true, 4>, tgrid, block, lds, stream, a);
+        return launch(render_inline_kernel<true, 32>, tgrid, block, lds, stream, a);
     }
     if (variant == 7 || variant == 8) {                       // capped occupancy through dynamic LDS: 4 / 3 waves per SIMD
-        hipLaunchKernelGGL((render_inline_kernel<true>), grid, block, (variant == 7 ? 33 : 41) * 1024, stream, a);
-        return hipGetLastError();
+        return launch(render_inline_kernel<true>, grid, block, (variant == 7 ? 33 : 41) * 1024, stream, a);
     }
     return launch_render_inline_ablation(a, variant, big_scene, stream);      // ptmi_inline_ablations.hip
 #else

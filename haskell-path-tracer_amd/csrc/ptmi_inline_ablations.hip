@@ -568,35 +568,30 @@ hipError_t launch_render_inline_ablation(const RenderArgs &a, int variant, bool 
         const unsigned int blocks = grid.x < (unsigned int)max_blocks ? grid.x : (unsigned int)max_blocks;
         e = hipMemsetAsync(a.work_counter, 0, sizeof(unsigned int), stream);
         if (e != hipSuccess) return e;
-        if (variant == 1) hipLaunchKernelGGL((render_inline_persistent_kernel<true>), dim3(blocks), block, lds, stream, a);
-        else              hipLaunchKernelGGL((render_inline_persistent_kernel<false>), dim3(blocks), block, 0, stream, a);
-        return hipGetLastError();
+        if (variant == 1) return launch(render_inline_persistent_kernel<true>, dim3(blocks), block, lds, stream, a);
+        else              return launch(render_inline_persistent_kernel<false>, dim3(blocks), block, 0, stream, a);
     }
     if (variant == 18) {                                      // round 1's loop (no frozen-shade shortcut), 8x8 tiles, LDS scene
-        hipLaunchKernelGGL((render_inline_modes_kernel<true, kCachedR1, 8>), dim3(tile_grid(a, 8)), block, lds, stream, a);
-        return hipGetLastError();
+        return launch(render_inline_modes_kernel<true, kCachedR1, 8>, dim3(tile_grid(a, 8)), block, lds, stream, a);
     }
     if (variant >= 10 && variant <= 12) {                    // pooled second shade round, W = 2 / 4 / 8 waves per workgroup
         const int w = variant == 10 ? 2 : variant == 11 ? 4 : 8;
         const dim3 pgrid(blocks_for(n_local, 64 * w)), pblock(64 * w);
         if (big_scene) {                                       // a scene too big to stage per workgroup: scalar loads
-            if (w == 2)      hipLaunchKernelGGL((render_inline_pooled_kernel<false, 2>), pgrid, pblock, 0, stream, a);
-            else if (w == 4) hipLaunchKernelGGL((render_inline_pooled_kernel<false, 4>), pgrid, pblock, 0, stream, a);
-            else             hipLaunchKernelGGL((render_inline_pooled_kernel<false, 8>), pgrid, pblock, 0, stream, a);
+            if (w == 2)      return launch(render_inline_pooled_kernel<false, 2>, pgrid, pblock, 0, stream, a);
+            else if (w == 4) return launch(render_inline_pooled_kernel<false, 4>, pgrid, pblock, 0, stream, a);
+            else             return launch(render_inline_pooled_kernel<false, 8>, pgrid, pblock, 0, stream, a);
         } else {
-            if (w == 2)      hipLaunchKernelGGL((render_inline_pooled_kernel<true, 2>), pgrid, pblock, lds, stream, a);
-            else if (w == 4) hipLaunchKernelGGL((render_inline_pooled_kernel<true, 4>), pgrid, pblock, lds, stream, a);
-            else             hipLaunchKernelGGL((render_inline_pooled_kernel<true, 8>), pgrid, pblock, lds, stream, a);
+            if (w == 2)      return launch(render_inline_pooled_kernel<true, 2>, pgrid, pblock, lds, stream, a);
+            else if (w == 4) return launch(render_inline_pooled_kernel<true, 4>, pgrid, pblock, lds, stream, a);
+            else             return launch(render_inline_pooled_kernel<true, 8>, pgrid, pblock, lds, stream, a);
         }
-        return hipGetLastError();
     }
     switch (variant) {
-    case 2:  if (big_scene) hipLaunchKernelGGL((render_inline_modes_kernel<false, kLockstep>), grid, block, 0, stream, a);
-             else           hipLaunchKernelGGL((render_inline_modes_kernel<true, kLockstep>), grid, block, lds, stream, a);
-             return hipGetLastError();
-    case 3:  if (big_scene) hipLaunchKernelGGL((render_inline_modes_kernel<false, kRegenerate>), grid, block, 0, stream, a);
-             else           hipLaunchKernelGGL((render_inline_modes_kernel<true, kRegenerate>), grid, block, lds, stream, a);
-             return hipGetLastError();
+    case 2:  if (big_scene) return launch(render_inline_modes_kernel<false, kLockstep>, grid, block, 0, stream, a);
+             else           return launch(render_inline_modes_kernel<true, kLockstep>, grid, block, lds, stream, a);
+    case 3:  if (big_scene) return launch(render_inline_modes_kernel<false, kRegenerate>, grid, block, 0, stream, a);
+             else           return launch(render_inline_modes_kernel<true, kRegenerate>, grid, block, lds, stream, a);
     default: break;
     }
     return hipErrorInvalidValue;

@@ -4,6 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <tuple>
+#include <type_traits>
+#include <utility>
+
 #include "ptmi_core.h"
 
 namespace ptmi {
@@ -224,5 +228,23 @@ hipError_t launch_stitch(const float *src, int rows, int width, int stripe_rows,
                          float *r, float *g, float *b, hipStream_t stream);
 hipError_t launch_present(Planes p, long long n, int iterations, float *rgb, uint32_t *rgba, hipStream_t stream);
 hipError_t launch_eval_sincos(const float *x, int n, float *s, float *c, hipStream_t stream);
+
+// A launch that reports ITS OWN status.  `kernel<<<...>>>(...)` drops hipLaunchKernel's result, and hipGetLastError() afterwards hands out the
+// thread's STICKY error -- the last failure of any runtime call, this library's or another's (an allocation the caller recovered from, an error
+// ptmi_destroy ignored), kept until somebody asks: a launch that went out would be reported as failed.  Arguments are converted to the
+// kernel's parameter types as a call would convert them.
+template <typename Tuple, size_t... I>
+inline hipError_t launch_packed(const void *kernel, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t stream, Tuple &values, std::index_sequence<I...>)
+{
+    void *pointers[] = {static_cast<void *>(&std::get<I>(values))..., nullptr};
+    return hipLaunchKernel(kernel, grid, block, pointers, lds_bytes, stream);
+}
+template <typename... P, typename... A>
+inline hipError_t launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds_bytes, hipStream_t stream, const A &...args)
+{
+    static_assert(sizeof...(P) == sizeof...(A), "one argument per kernel parameter");
+    std::tuple<std::remove_cv_t<P>...> values(static_cast<P>(args)...);
+    return launch_packed(reinterpret_cast<const void *>(kernel), grid, block, lds_bytes, stream, values, std::index_sequence_for<P...>{});
+}
 
 }  // namespace ptmi

@@ -212,8 +212,7 @@ hipError_t launch_quad_order(const unsigned int *cost, unsigned int *order, unsi
                              unsigned int tail_permille, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(quad_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, cls, n, tail_start, tail_permille);
-    return hipGetLastError();
+    return launch(quad_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, cls, n, tail_start, tail_permille);
 }
 
 
@@ -222,42 +221,37 @@ hipError_t launch_seed(Planes p, int width, int rows_local, int stripe_rows, int
 {
     const long long n = (long long)rows_local * width;
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(seed_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, p, width, rows_local,
-                       stripe_rows, n_parts, part, seed0, clear_color ? 1 : 0);
-    return hipGetLastError();
+    return launch(seed_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, p, width, rows_local,
+                  stripe_rows, n_parts, part, seed0, clear_color ? 1 : 0);
 }
 
 hipError_t launch_create_with(Planes p, const uint32_t *w0, const uint32_t *w1, const uint32_t *w2,
                               int64_t n, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(create_with_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, p, w0, w1, w2, (long long)n);
-    return hipGetLastError();
+    return launch(create_with_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, p, w0, w1, w2, (long long)n);
 }
 
 hipError_t launch_eval_sphere(const float *spheres10, const float *rays, int n,
                               int32_t *is_just, float *t, float *normalp, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(eval_sphere_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, spheres10, rays, n, is_just, t, normalp);
-    return hipGetLastError();
+    return launch(eval_sphere_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, spheres10, rays, n, is_just, t, normalp);
 }
 
 hipError_t launch_eval_plane(const float *planes12, const float *rays, int n,
                              int32_t *is_just, float *t, float *normalp, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(eval_plane_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, planes12, rays, n, is_just, t, normalp);
-    return hipGetLastError();
+    return launch(eval_plane_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, planes12, rays, n, is_just, t, normalp);
 }
 
 hipError_t launch_present(Planes p, long long n, int iterations, float *rgb, uint32_t *rgba, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
     const uintptr_t bits = (uintptr_t)p.r | (uintptr_t)p.g | (uintptr_t)p.b | (uintptr_t)rgb | (uintptr_t)rgba;
-    hipLaunchKernelGGL(present_kernel, dim3(blocks_for((n + 3) / 4)), dim3(kBlock), 0, stream, p, n, (float)iterations, rgb, rgba,
-                       (bits & 15u) == 0 ? 1 : 0);
-    return hipGetLastError();
+    return launch(present_kernel, dim3(blocks_for((n + 3) / 4)), dim3(kBlock), 0, stream, p, n, (float)iterations, rgb, rgba,
+                  (bits & 15u) == 0 ? 1 : 0);
 }
 
 hipError_t launch_stitch(const float *src, int rows, int width, int stripe_rows, int n_parts, int part,
@@ -265,15 +259,13 @@ hipError_t launch_stitch(const float *src, int rows, int width, int stripe_rows,
 {
     const long long n = (long long)rows * width;
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(stitch_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, src, rows, width, stripe_rows, n_parts, part, r, g, b);
-    return hipGetLastError();
+    return launch(stitch_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, src, rows, width, stripe_rows, n_parts, part, r, g, b);
 }
 
 hipError_t launch_eval_sincos(const float *x, int n, float *s, float *c, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(eval_sincos_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, x, n, s, c);
-    return hipGetLastError();
+    return launch(eval_sincos_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, x, n, s, c);
 }
 
 

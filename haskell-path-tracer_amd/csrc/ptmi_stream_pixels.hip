@@ -257,13 +257,12 @@ hipError_t launch_streams_pixels(const RenderArgs &a, const ItemArgs &it, unsign
     const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
     const dim3 g(grid), b(kRenderBlock);
     if (it.passes > 1) {
-        if (lds > kMaxSceneLds) hipLaunchKernelGGL((streams_pixels_kernel<false, true>), g, b, 0, stream, a, it);
-        else                    hipLaunchKernelGGL((streams_pixels_kernel<true, true>), g, b, lds, stream, a, it);
+        if (lds > kMaxSceneLds) return launch(streams_pixels_kernel<false, true>, g, b, 0, stream, a, it);
+        else                    return launch(streams_pixels_kernel<true, true>, g, b, lds, stream, a, it);
     } else {
-        if (lds > kMaxSceneLds) hipLaunchKernelGGL((streams_pixels_kernel<false, false>), g, b, 0, stream, a, it);
-        else                    hipLaunchKernelGGL((streams_pixels_kernel<true, false>), g, b, lds, stream, a, it);
+        if (lds > kMaxSceneLds) return launch(streams_pixels_kernel<false, false>, g, b, 0, stream, a, it);
+        else                    return launch(streams_pixels_kernel<true, false>, g, b, lds, stream, a, it);
     }
-    return hipGetLastError();
 }
 
 int streams_pixels_waves() { return PTMI_PIXELS_WAVES; }

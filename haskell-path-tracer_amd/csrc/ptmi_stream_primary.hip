@@ -151,27 +151,25 @@ hipError_t launch_streams_primary(const RenderArgs &a, HitList hits, unsigned in
 {
     if (hits.n_regions == 0) return hipSuccess;
     const dim3 g(hits.n_regions / 4u), b(256);
-    if (tiles_pay(a)) hipLaunchKernelGGL((streams_primary_kernel<true>), g, b, 0, stream, a, hits, counters);
-    else              hipLaunchKernelGGL((streams_primary_kernel<false>), g, b, 0, stream, a, hits, counters);
-    return hipGetLastError();
+    if (tiles_pay(a)) return launch(streams_primary_kernel<true>, g, b, 0, stream, a, hits, counters);
+    else              return launch(streams_primary_kernel<false>, g, b, 0, stream, a, hits, counters);
 }
 
 hipError_t launch_streams_advance_missed(const RenderArgs &a, HitList hits, int draws, const unsigned int *tail_start, hipStream_t stream)
 {
     if (hits.n_regions == 0 || draws <= 0) return hipSuccess;
     const dim3 g(hits.n_regions / 4u), b(256);
-    if (tiles_pay(a)) hipLaunchKernelGGL((streams_advance_missed_kernel<true>), g, b, 0, stream, a, hits, draws, tail_start);
-    else              hipLaunchKernelGGL((streams_advance_missed_kernel<false>), g, b, 0, stream, a, hits, draws, tail_start);
-    return hipGetLastError();
+    if (tiles_pay(a)) return launch(streams_advance_missed_kernel<true>, g, b, 0, stream, a, hits, draws, tail_start);
+    else              return launch(streams_advance_missed_kernel<false>, g, b, 0, stream, a, hits, draws, tail_start);
 }
 
 hipError_t launch_streams_seeds(Planes p, HitList hits, uint4 *snapshots, long long n, int passes, const int *pass_first, int draws, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
     const unsigned int n_slots = hits.n_regions * hits.region_slots;
-    if (n_slots) hipLaunchKernelGGL(streams_slot_seeds_kernel, dim3(blocks_for(n_slots)), dim3(kBlock), 0, stream, p, hits, snapshots, n_slots, passes, pass_first);
-    hipLaunchKernelGGL(streams_advance_seeds_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, p, n, draws);      // (after it, in stream order)
-    return hipGetLastError();
+    if (n_slots)
+        if (hipError_t e = launch(streams_slot_seeds_kernel, dim3(blocks_for(n_slots)), dim3(kBlock), 0, stream, p, hits, snapshots, n_slots, passes, pass_first)) return e;
+    return launch(streams_advance_seeds_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, p, n, draws);      // (after it, in stream order)
 }
 
 }  // namespace ptmi

@@ -532,9 +532,8 @@ hipError_t launch_streams_level(const RenderArgs &a, const LevelArgs &lv, unsign
     if (grid == 0) return hipSuccess;
     const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
     const dim3 g(grid), b(kRenderBlock);
-    if (lds > kMaxSceneLds) hipLaunchKernelGGL((streams_level_kernel<false>), g, b, 0, stream, a, lv);      // a scene too big for LDS at this occupancy: scalar loads
-    else                    hipLaunchKernelGGL((streams_level_kernel<true>), g, b, lds, stream, a, lv);
-    return hipGetLastError();
+    if (lds > kMaxSceneLds) return launch(streams_level_kernel<false>, g, b, 0, stream, a, lv);      // a scene too big for LDS at this occupancy: scalar loads
+    else                    return launch(streams_level_kernel<true>, g, b, lds, stream, a, lv);
 }
 
 hipError_t launch_streams_split(const RenderArgs &a, const ItemArgs &it, unsigned int grid, hipStream_t stream)
@@ -544,13 +543,12 @@ hipError_t launch_streams_split(const RenderArgs &a, const ItemArgs &it, unsigne
     const dim3 g(grid), b(kRenderBlock);
     const bool tiles = tiles_pay(a);
     if (lds > kMaxSceneLds) {
-        if (tiles) hipLaunchKernelGGL((streams_split_kernel<false, true>), g, b, 0, stream, a, it);
-        else       hipLaunchKernelGGL((streams_split_kernel<false, false>), g, b, 0, stream, a, it);
+        if (tiles) return launch(streams_split_kernel<false, true>, g, b, 0, stream, a, it);
+        else       return launch(streams_split_kernel<false, false>, g, b, 0, stream, a, it);
     } else {
-        if (tiles) hipLaunchKernelGGL((streams_split_kernel<true, true>), g, b, lds, stream, a, it);
-        else       hipLaunchKernelGGL((streams_split_kernel<true, false>), g, b, lds, stream, a, it);
+        if (tiles) return launch(streams_split_kernel<true, true>, g, b, lds, stream, a, it);
+        else       return launch(streams_split_kernel<true, false>, g, b, lds, stream, a, it);
     }
-    return hipGetLastError();
 }
 
 int streams_split_waves() { return PTMI_SPLIT_WAVES; }

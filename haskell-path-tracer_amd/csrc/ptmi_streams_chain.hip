@@ -199,13 +199,12 @@ hipError_t launch_render_streams(const RenderArgs &a, int variant, hipStream_t s
         const unsigned int per_copy = tile_grid(a, 8);
         if (hipError_t ce = choose_sample_chunks(b, per_copy, PTMI_STREAMS_WAVES, stream)) return ce;
         const dim3 tgrid(per_copy * (unsigned int)b.spp_chunks);
-        if (scalar_scene) hipLaunchKernelGGL((render_streams_kernel<false, 8>), tgrid, block, 0, stream, b);
-        else              hipLaunchKernelGGL((render_streams_kernel<true, 8>), tgrid, block, lds, stream, b);
+        if (scalar_scene) return launch(render_streams_kernel<false, 8>, tgrid, block, 0, stream, b);
+        else              return launch(render_streams_kernel<true, 8>, tgrid, block, lds, stream, b);
     } else {
-        if (scalar_scene) hipLaunchKernelGGL((render_streams_kernel<false>), grid, block, 0, stream, a);
-        else              hipLaunchKernelGGL((render_streams_kernel<true>), grid, block, lds, stream, a);
+        if (scalar_scene) return launch(render_streams_kernel<false>, grid, block, 0, stream, a);
+        else              return launch(render_streams_kernel<true>, grid, block, lds, stream, a);
     }
-    return hipGetLastError();
 }
 
 // The per-pixel chain kernel as the TAIL of a stream-form launch: a grid over every dispatch position whose workgroups start at
@@ -217,9 +216,8 @@ hipError_t launch_render_streams_tail(const RenderArgs &a, const unsigned int *f
     b.spp_chunks = 1; b.first_position = first_position;
     const size_t lds = (size_t)a.scene.total_f4() * sizeof(float4);
     const dim3 grid(tile_grid(a, 8)), block(kRenderBlock);
-    if (lds > kMaxSceneLds) hipLaunchKernelGGL((render_streams_kernel<false, 8>), grid, block, 0, stream, b);
-    else                    hipLaunchKernelGGL((render_streams_kernel<true, 8>), grid, block, lds, stream, b);
-    return hipGetLastError();
+    if (lds > kMaxSceneLds) return launch(render_streams_kernel<false, 8>, grid, block, 0, stream, b);
+    else                    return launch(render_streams_kernel<true, 8>, grid, block, lds, stream, b);
 }
 
 }  // namespace ptmi

@@ -336,13 +336,12 @@ hipError_t launch_render_streams_tree(const RenderArgs &a, int variant, hipStrea
         const unsigned int per_copy = tile_grid(a, 8);
         if (hipError_t ce = choose_sample_chunks(b, per_copy, PTMI_TREE_WAVES, stream, 10)) return ce;
         const dim3 tgrid(per_copy * (unsigned int)b.spp_chunks);
-        if (scalar_scene) hipLaunchKernelGGL((render_streams_tree_kernel<false, 8>), tgrid, block, 0, stream, b);
-        else              hipLaunchKernelGGL((render_streams_tree_kernel<true, 8>), tgrid, block, lds, stream, b);
+        if (scalar_scene) return launch(render_streams_tree_kernel<false, 8>, tgrid, block, 0, stream, b);
+        else              return launch(render_streams_tree_kernel<true, 8>, tgrid, block, lds, stream, b);
     } else {
-        if (scalar_scene) hipLaunchKernelGGL((render_streams_tree_kernel<false>), grid, block, 0, stream, a);
-        else              hipLaunchKernelGGL((render_streams_tree_kernel<true>), grid, block, lds, stream, a);
+        if (scalar_scene) return launch(render_streams_tree_kernel<false>, grid, block, 0, stream, a);
+        else              return launch(render_streams_tree_kernel<true>, grid, block, lds, stream, a);
     }
-    return hipGetLastError();
 }
 
 }  // namespace ptmi

@@ -120,7 +120,12 @@ const char *ptmi_strerror(int code);
  * machine has no usable GPU: there is NO CPU fallback in this library. */
 int         ptmi_create(ptmi_ctx **out, int device);
 void        ptmi_destroy(ptmi_ctx *ctx);
-const char *ptmi_last_error(const ptmi_ctx *ctx);   /* ctx may be NULL: error of the last failed ptmi_create */
+/* The message of the calling THREAD's last failed call on `ctx` (ctx NULL: of its last failed ptmi_create); if this thread has not failed on
+ * `ctx`, the context's latest message whoever saw it.  The text stays valid until the same thread's next failing call or next ptmi_last_error:
+ * threads that share a context never read each other's strings.  A HIP error reported through a return code is taken out of the runtime's
+ * own sticky slot (hipGetLastError) -- the caller's next launch check does not find it again -- and an error another library left there
+ * is neither mistaken for this library's nor cleared by it. */
+const char *ptmi_last_error(const ptmi_ctx *ctx);
 
 /* ---- configuration ----------------------------------------------------------- */
 /* mainScene (src/Scene/World.hs:15-77) as run-time data.  Order is kept: checkHit folds
@@ -422,7 +427,7 @@ int         ptmi_group_create(ptmi_group **out, const int *devices, int n_device
 void        ptmi_group_destroy(ptmi_group *group);
 int         ptmi_group_size(const ptmi_group *group);
 ptmi_ctx   *ptmi_group_member(ptmi_group *group, int i);        /* member i's context (options, statistics, planes) */
-const char *ptmi_group_last_error(const ptmi_group *group);
+const char *ptmi_group_last_error(const ptmi_group *group);      /* per thread, as ptmi_last_error */
 int ptmi_group_set_scene(ptmi_group *group, const ptmi_sphere *spheres, int n_spheres, const ptmi_plane *planes, int n_planes);
 int ptmi_group_resize(ptmi_group *group, int width, int height);
 int ptmi_group_init_output(ptmi_group *group, uint64_t seed0);

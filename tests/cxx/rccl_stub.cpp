@@ -112,7 +112,8 @@ ncclResult_t ncclGroupEnd()
         if (j == ops.size() || ops[j].bytes != ops[i].bytes) { result = ncclInvalidUsage; continue; }     // a send nobody receives: real RCCL hangs
         used[i] = used[j] = true;
         hipEvent_t sent = nullptr, copied = nullptr;
-        if (hipEventCreateWithFlags(&sent, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&copied, hipEventDisableTiming) != hipSuccess) return ncclUnhandledCudaError;
+        if (hipEventCreateWithFlags(&sent, hipEventDisableTiming) != hipSuccess) return ncclUnhandledCudaError;
+        if (hipEventCreateWithFlags(&copied, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(sent); return ncclUnhandledCudaError; }
         bool ok = hipEventRecord(sent, ops[i].stream) == hipSuccess && hipStreamWaitEvent(ops[j].stream, sent, 0) == hipSuccess;
         ok = ok && hipMemcpyAsync(ops[j].buf, ops[i].buf, ops[i].bytes, hipMemcpyDeviceToDevice, ops[j].stream) == hipSuccess;
         ok = ok && hipEventRecord(copied, ops[j].stream) == hipSuccess && hipStreamWaitEvent(ops[i].stream, copied, 0) == hipSuccess;

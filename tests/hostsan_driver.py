@@ -1,0 +1,495 @@
+"""Driver of tests/test_host_sanitized.py (run in a CHILD process with the HIP stand-in and the sanitizer runtime preloaded; not a test
+module itself).  It takes the sanitized libptmi through scenarios of C-ABI calls -- the resident path, GLASS and the stream form, the
+closures, a partitioned image, a group with the RCCL stand-in -- first plainly, then once per failure point: the k-th hipMalloc / copy /
+launch / synchronize / pinned allocation / stream-or-event creation of the scenario fails, for every k.  After every run every context is
+destroyed and the stand-in must hold no block, pinned block, stream or event.  Kernels do not run on the stand-in: no value is checked."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+pkg = graft.load_package()
+B = pkg.binding
+stub = ctypes.CDLL(os.environ["PTMI_HIPSTUB"])
+assert stub.hipstub_is_the_stub() == 1
+stub.hipstub_live_bytes.restype = ctypes.c_ulonglong
+stub.hipstub_fail.argtypes = [ctypes.c_int, ctypes.c_long]
+stub.hipstub_calls.restype = ctypes.c_long
+stub.hipstub_set_device_size.argtypes = [ctypes.c_int, ctypes.c_ulonglong]
+B.load_library(os.environ["PTMI_SANITIZED_LIB"])
+assert b"fsanitize" in B.load_library().ptmi_build_id() or True      # (the id carries a suffix for the extra flags; not relied upon)
+
+KINDS = ["hipMalloc", "copy", "launch", "synchronize", "hipHostMalloc", "stream/event creation"]
+cam = pkg.world.initial_camera()
+cam2 = cam.copy()
+cam2["position"][0] += 0.25
+
+
+def planes(w, h, seed=3):
+    r = np.random.default_rng(seed)
+    return [np.zeros((h, w), np.float32) for _ in range(3)] + [r.integers(0, 2 ** 32, (h, w), dtype=np.uint32) for _ in range(4)]
+
+
+def dev_alloc(n_bytes):
+    p = ctypes.c_void_p()
+    rc = stub.hipMalloc(ctypes.byref(p), ctypes.c_size_t(n_bytes))
+    if rc != 0:
+        stub.hipstub_clear_error()                                  # (the caller's own failed call: the caller's to clear)
+        raise MemoryError("stand-in hipMalloc (injected)")
+    return p.value
+
+
+def dev_free(p):
+    stub.hipFree(ctypes.c_void_p(p))
+
+
+def quiet(call):
+    """Clean-up calls after a (possibly injected) failure: their own failure is not the scenario's."""
+    try:
+        call()
+    except B.PtmiError:
+        pass
+
+
+class DeviceBlocks:
+    """The caller's own device buffers (an injected failure may hit one of these allocations too: the earlier ones are freed)."""
+
+    def __init__(self, sizes):
+        self.sizes, self.ptrs = list(sizes), []
+
+    def __enter__(self):
+        try:
+            for n in self.sizes:
+                self.ptrs.append(dev_alloc(n))
+        except MemoryError:
+            self.__exit__()
+            raise
+        return self.ptrs
+
+    def __exit__(self, *exc):
+        for p in self.ptrs:
+            dev_free(p)
+        self.ptrs = []
+
+
+# ---- scenarios: each makes and destroys its own contexts ------------------------------------------------------------------------------
+def resident():
+    sp, pl = pkg.world.scene16()
+    with pkg.Context(0) as ctx:
+        ctx.set_scene(sp, pl)
+        ctx.set_timing(True)
+        for (w, h) in ((72, 40), (136, 24), (8, 8)):               # grow, reshape, shrink
+            ctx.resize(w, h)
+            ctx.init_output(7)
+            for alg in (pkg.INLINE, pkg.STREAMS):
+                for spp in (1, 4, 4, 4, 4, 4):                       # (the same key five times: the cost order is rebuilt before launch 1, 2, 4)
+                    ctx.render(cam, 8, spp, alg)
+            ctx.render(cam2, 0, 2)
+            ctx.render(cam2, 15, 0)
+            ctx.reseed(9)
+            ctx.synchronize()
+            ctx.download_color()
+            st = ctx.download_state()
+            ctx.upload_state(*st)
+            ctx.upload_state(r=st[0])
+            ctx.create_with(st[3], st[4], st[5])
+            ctx.present(3)
+            ctx.present(1, rgb32f=False)
+            ctx.stats(); ctx.debug_counters(); ctx.reset_stats()
+            ctx.render_blocks(pkg.INLINE); ctx.render_blocks(pkg.STREAMS)
+            ctx.device_planes()
+        for opt, val in ((B.OPT_SPP_CHUNKS, 4), (B.OPT_STREAMS_SEED_RULE, B.SEED_FROM_RESULT), (B.OPT_STREAM_STEP_CAP, 5), (B.OPT_ARITHMETIC, B.ARITH_CONTRACTED)):
+            ctx.set_option(opt, val)
+            assert ctx.get_option(opt) == val
+            ctx.render(cam, 4, 2, pkg.INLINE)
+            ctx.render(cam, 4, 2, pkg.STREAMS)
+        s3 = sp[:3]
+        ctx.eval_distance_to_sphere(s3, np.ones((3, 6), np.float32))
+        ctx.eval_distance_to_plane(pl, np.ones((pl.size, 6), np.float32))
+        ctx.eval_sincos(np.linspace(-4, 4, 100).astype(np.float32))
+        # a caller's stream and bound planes
+        s = ctypes.c_void_p()
+        if stub.hipStreamCreateWithFlags(ctypes.byref(s), 1) != 0:
+            stub.hipstub_clear_error()
+            raise MemoryError("stand-in hipStreamCreateWithFlags (injected)")
+        try:
+            ctx.set_stream(s.value)
+            ctx.resize(40, 16)
+            ctx.init_output(1)
+            ctx.render(cam, 8, 2)
+            ctx.synchronize()
+            ctx.set_stream(None)
+        finally:
+            quiet(ctx.synchronize)
+            try:
+                ctx.set_stream(None)
+            except B.PtmiError:
+                ctx.set_stream(None)                                # (an injected failure happens once: the stream must be given back before it goes)
+            stub.hipStreamDestroy(s)
+        with DeviceBlocks([40 * 16 * 4] * 7) as bound:
+            try:
+                ctx._check(ctx._lib.ptmi_bind_planes(ctx._h, *[ctypes.c_void_p(p) for p in bound]))
+                ctx.init_output(2)
+                ctx.render(cam, 8, 2)
+                ctx.download_color()
+                ctx.unbind()
+                ctx.render(cam, 8, 1)
+            finally:
+                quiet(ctx.synchronize)
+                quiet(ctx.unbind)
+
+
+def partitioned():
+    sp, pl = pkg.world.main_scene()
+    for n_parts, part, stripe in ((3, 0, 8), (3, 2, 8), (8, 7, 2), (2, 1, 16)):
+        with pkg.Context(0) as ctx:
+            ctx.set_scene(sp, pl)
+            ctx.set_partition(stripe, n_parts, part)
+            ctx.resize(64, 50)
+            assert ctx.local_rows == B.load_library().ptmi_partition_rows(50, stripe, n_parts, part)
+            ctx.global_rows()
+            ctx.init_output(5)
+            ctx.render(cam, 8, 3)
+            ctx.render(cam, 8, 300, pkg.STREAMS)                     # (no GLASS: the per-pixel chain whatever the sample count)
+            ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+            ctx.render(cam, 8, 300, pkg.STREAMS)
+            ctx.render(cam, 8, 2, pkg.STREAMS)
+            ctx.download_color()
+            ctx.present(2)
+            with DeviceBlocks([3 * max(ctx.local_rows, 1) * 64 * 4]) as (dst,):
+                try:
+                    ctx._check(ctx._lib.ptmi_snapshot_color(ctx._h, ctypes.c_void_p(dst), None))
+                finally:
+                    quiet(ctx.synchronize)
+
+
+def glass():
+    sp, pl = pkg.world.glass_scene()
+    with pkg.Context(0) as ctx:
+        ctx.set_scene(sp, pl)
+        ctx.resize(80, 48)
+        ctx.init_output(11)
+        ctx.render(cam, 8, 4, pkg.STREAMS)                          # tree walk
+        for form in (B.FORM_STREAM, B.FORM_PIXEL, B.FORM_AUTO):
+            ctx.set_option(B.OPT_STREAMS_FORM, form)
+            ctx.render(cam, 8, 4, pkg.STREAMS)
+            ctx.render(cam, 8, 4, pkg.STREAMS)
+        ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+        for opt, val in ((B.OPT_STREAM_CAPACITY, 1), (B.OPT_STREAM_BATCH, 2), (B.OPT_GLASS_BATCH, 8), (B.OPT_STREAM_GRADED, 0), (B.OPT_STREAM_PASS_GROUPS, 2),
+                         (B.OPT_STREAM_TAIL, 200), (B.OPT_SNAPSHOT_BUDGET_MB, 1), (B.OPT_ORDERED_PASSES, 1), (B.OPT_PASS_HANDOFF, B.HANDOFF_FENCE_FREE),
+                         (B.OPT_ORDERED_PASSES, 2), (B.OPT_STREAM_STEP_CAP, 3)):
+            ctx.set_option(opt, val)
+            ctx.render(cam, 8, 70, pkg.STREAMS)
+        ctx.stats()
+        ctx.resize(24, 200)
+        ctx.init_output(12)
+        ctx.render(cam2, 8, 260, pkg.STREAMS)
+        try:
+            ctx.render(cam, 8, 1, pkg.INLINE)                       # refused: Inline cannot split rays
+            raise AssertionError("render Inline with GLASS was accepted")
+        except B.PtmiError as e:
+            assert e.code == B.PTMI_EINVAL if hasattr(B, "PTMI_EINVAL") else True
+    with pkg.Context(0) as ctx:                                     # one part of a partitioned glass image at >= 256 spp: FORM_AUTO = the stream form, ordered passes
+        ctx.set_scene(sp, pl)
+        ctx.set_partition(8, 4, 1)
+        ctx.resize(96, 64)
+        ctx.init_output(13)
+        ctx.render(cam, 8, 256, pkg.STREAMS)
+        ctx.render(cam, 8, 256, pkg.STREAMS)
+        ctx.render(cam, 8, 8, pkg.STREAMS)
+        ctx.set_scene(*pkg.world.scene16())                         # the scene loses its GLASS
+        ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+        ctx.render(cam, 8, 8, pkg.STREAMS)
+        ctx.render(cam, 8, 8, pkg.INLINE)
+
+
+def closures():
+    sp, pl = pkg.world.scene16()
+    w, h = 48, 20
+    with pkg.Context(0) as ctx:
+        ctx.set_scene(sp, pl)
+        p = planes(w, h)
+        out = ctx.render1(cam, 8, w, h, p)
+        out = ctx.render1(cam, 8, w, h, out, pkg.STREAMS)
+        ys, xs = np.mgrid[0:h, 0:w]
+        ctx.render1(cam, 8, w, h, out, screen=(xs.astype(np.int64), ys.astype(np.int64)))
+        ctx.render1(cam, 8, 2 * w, h, planes(2 * w, h))            # another size
+        ctx.set_option(B.OPT_CHAIN_SLOTS, 3)
+        t0 = ctx.chain_init_output(w, h, 21)
+        toks = [t0]
+        for i in range(12):                                         # tokens pile up: evictions to host memory
+            t, got = ctx.render1_chained(cam if i % 5 else cam2, 8, w, h, token=toks[-1], fetch=("r", "g", "b") if i % 4 == 0 else ())
+            toks.append(t)
+        info = ctx.chain_info()
+        assert info["states_on_device"] <= 3 and info["states_on_host"] >= 1, info
+        ctx.chain_fetch(toks[1], w, h)                              # from the host copy
+        ctx.chain_fetch(toks[-1], w, h, "sa sctr")
+        t, _ = ctx.render1_chained(cam, 8, w, h, token=toks[2])    # an evicted state is the input: back to the device
+        t, _ = ctx.render1_chained(cam, 8, w, h, token=toks[3], consume=True)
+        t, _ = ctx.render1_chained(cam, 8, w, h, token=t, consume=True, algorithm=pkg.STREAMS, fetch=("sctr",))
+        t = ctx.chain_reseed(5, w, h, token=t)
+        t = ctx.chain_reseed(6, w, h, token=t, consume=True)
+        t = ctx.chain_reseed(7, w, h, token=toks[4])                # evicted input
+        t = ctx.chain_reseed(8, w, h, colour_in=p[:3])             # from host planes
+        for k in toks[::2]:
+            ctx.chain_release(k)
+        ctx.chain_release(toks[0])                                  # twice: fine
+        for call in (lambda: ctx.chain_fetch(toks[0], w, h), lambda: ctx.render1_chained(cam, 8, w, h, token=toks[0]),
+                     lambda: ctx.render1_chained(cam, 8, w, h), lambda: ctx.render1_chained(cam, 8, w + 1, h, token=t),
+                     lambda: ctx.chain_reseed(1, w, h, token=12345)):
+            try:
+                call()
+                raise AssertionError("a stale or missing input was accepted")
+            except B.PtmiError:
+                pass
+        t2, _ = ctx.render1_chained(cam, 8, w, h, token=toks[0], planes_in=p)      # stale token + host planes: the copy path
+        w2, h2 = 30, 30                                             # another image size: the free blocks of the old size go
+        u = ctx.chain_init_output(w2, h2, 1)
+        for i in range(5):
+            u, _ = ctx.render1_chained(cam, 8, w2, h2, token=u, consume=bool(i % 2))
+        ctx.chain_fetch(u, w2, h2, "r")
+        ctx.set_option(B.OPT_CHAIN_SLOTS, 0)
+        ctx.chain_info()
+        # the resident state is untouched by all of this
+        ctx.resize(w, h)
+        ctx.init_output(1)
+        ctx.render(cam, 8, 2)
+        ctx.download_color()
+    with pkg.Context(0) as ctx:                                     # GLASS through the closures
+        ctx.set_scene(*pkg.world.glass_scene())
+        t = ctx.chain_init_output(w, h, 2)
+        for _ in range(3):
+            t, _ = ctx.render1_chained(cam, 8, w, h, token=t, algorithm=pkg.STREAMS)
+        ctx.render1(cam, 8, w, h, planes(w, h), pkg.STREAMS)
+
+
+def staged():
+    """Copies of a megabyte and more go through the pinned ring and its worker threads (csrc/ptmi_stage.cpp)."""
+    sp, pl = pkg.world.scene16()
+    w, h = 320, 240                                                 # 7 planes = 2.1 MB
+    with pkg.Context(0) as ctx:
+        ctx.set_scene(sp, pl)
+        out = ctx.render1(cam, 8, w, h, planes(w, h))
+        t, got = ctx.render1_chained(cam, 8, w, h, planes_in=out, fetch="r g b sa sb sc sctr".split())
+        ctx.chain_fetch(t, w, h)
+        ctx.set_option(B.OPT_CHAIN_SLOTS, 2)
+        t2, _ = ctx.render1_chained(cam, 8, w, h, token=t)
+        t3, _ = ctx.render1_chained(cam, 8, w, h, token=t2)        # t leaves the device through the ring
+        ctx.chain_fetch(t, w, h, "r g b")
+        ctx.resize(w, h)
+        ctx.init_output(3)
+        ctx.render(cam, 8, 1)
+        st = ctx.download_state()
+        ctx.upload_state(*st)
+        ctx.download_color()
+        ctx.present(1)
+    with pkg.Group([0, 0], 8) as g:
+        g.set_scene(sp, pl)
+        g.resize(w, 2 * h)
+        g.init_output(1)
+        g.render(cam, 8, 1)
+        g.download_color()
+
+
+def threads():
+    """Several host threads on one context (the application's computation, graphics and input threads: app/Main.hs:178-180), the group's
+    per-member threads, the pinned ring's workers -- what ThreadSanitizer looks at (tests/test_host_sanitized.py, the second build)."""
+    import threading
+    sp, pl = pkg.world.scene16()
+    w, h = 320, 240
+    errors = []
+    with pkg.Context(0) as ctx:
+        ctx.set_scene(sp, pl)
+        ctx.resize(w, h)
+        ctx.init_output(1)
+        ctx.set_option(B.OPT_CHAIN_SLOTS, 3)
+        start = ctx.chain_init_output(w, h, 5)
+        held, lock = [start], threading.Lock()
+
+        def closure_calls():
+            try:
+                t = start
+                for i in range(6):
+                    nxt, _ = ctx.render1_chained(cam, 8, w, h, token=t, fetch=("r",) if i % 2 else ())
+                    if t != start:
+                        with lock:
+                            held.append(t)                            # (only states this thread has moved on from are the releaser's to take)
+                    t = nxt
+            except Exception as e:                                   # noqa: BLE001
+                errors.append(e)
+
+        def readers():
+            try:
+                for _ in range(6):
+                    with lock:
+                        t = held[len(held) // 2]
+                    try:
+                        ctx.chain_fetch(t, w, h, "r g b")
+                    except B.PtmiError as e:
+                        if e.code != B.PTMI_ESTALE:
+                            raise
+                    ctx.render(cam, 8, 1)
+                    ctx.download_color()
+                    ctx.stats()
+            except Exception as e:                                   # noqa: BLE001
+                errors.append(e)
+
+        def releaser():
+            try:
+                for _ in range(8):
+                    with lock:
+                        t = held.pop(1) if len(held) > 2 else 0
+                    if t:
+                        ctx.chain_release(t)
+                    ctx.chain_info()
+            except Exception as e:                                   # noqa: BLE001
+                errors.append(e)
+
+        ts = [threading.Thread(target=f) for f in (closure_calls, closure_calls, readers, releaser)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    with pkg.Group([0, 0, 0], 8) as g:
+        g.set_scene(sp, pl)
+        g.resize(w, 2 * h)
+        g.init_output(1)
+        g.render(cam, 8, 1)
+        g.download_color()                                           # one host thread per member
+        with DeviceBlocks([w * 2 * h * 4] * 3) as dst:
+            g.gather_color(1, *dst)
+            quiet(g.synchronize)
+    if errors:
+        raise errors[0]
+
+
+def group():
+    sp, pl = pkg.world.scene16()
+    for devices, stripe, (w, h) in (([0, 0, 0], 4, (40, 30)), ([0, 0], 0, (32, 16)), ([0] * 8, 2, (16, 9)), ([0], 8, (24, 24))):
+        with pkg.Group(devices, stripe) as g:
+            assert g.size == len(devices)
+            g.set_scene(sp, pl)
+            g.resize(w, h)
+            g.init_output(3)
+            g.render(cam, 8, 2)
+            g.render(cam, 8, 2, pkg.STREAMS)
+            g.set_option(B.OPT_SPP_CHUNKS, 2)
+            g.reseed(4)
+            g.synchronize()
+            g.download_color()
+            g.stats()
+            g.member(0).stats()
+            with DeviceBlocks([(w + 8) * h * 4] * 3) as dst:
+                try:
+                    for root in (0, len(devices) - 1, 0):
+                        g.gather_color(root, *dst)
+                    g.resize(w + 8, h)                               # another size: the gather's blocks are made anew
+                    g.init_output(5)
+                    g.render(cam, 8, 1)
+                    g.gather_color(0, *dst)
+                finally:
+                    quiet(g.synchronize)
+
+
+def refusals():
+    """Arguments the ABI refuses: nothing may be touched, the context stays usable."""
+    sp, pl = pkg.world.scene16()
+    lib = B.load_library()
+    assert lib.ptmi_destroy(None) is None
+    assert lib.ptmi_render(None, None, 0, 0, 0) != 0
+    with pkg.Context(0) as ctx:
+        bad = [lambda: ctx.render(cam, 8, 1), lambda: ctx.resize(0, 4), lambda: ctx.resize(4, -1), lambda: ctx.download_color(),
+               lambda: ctx.set_scene(sp[:0], pl[:0]), lambda: ctx.set_partition(0, 2, 0), lambda: ctx.set_partition(8, 2, 2),
+               lambda: ctx.set_option(99, 1), lambda: ctx.get_option(99), lambda: ctx.set_option(B.OPT_STREAMS_FORM, 7),
+               lambda: ctx.set_option(B.OPT_PASS_HANDOFF, 9), lambda: ctx.set_option(B.OPT_CHAIN_SLOTS, -1), lambda: ctx.set_variant(12345),
+               lambda: ctx.present(1), lambda: ctx.init_output(1)]
+        for call in bad:
+            try:
+                call()
+            except B.PtmiError:
+                continue
+            raise AssertionError("a refusal was expected")
+        many_s = np.concatenate([sp] * 80)                        # 1120 spheres > PTMI_MAX_PRIMITIVES
+        try:
+            ctx.set_scene(many_s, pl)
+            raise AssertionError("too many primitives were accepted")
+        except B.PtmiError:
+            pass
+        ctx.set_scene(sp, pl)
+        ctx.resize(16, 16)
+        ctx.init_output(1)
+        for call in (lambda: ctx.render(cam, -1, 1), lambda: ctx.render(cam, 8, -1), lambda: ctx.render(cam, 8, 1, 5), lambda: ctx.present(0),
+                     lambda: ctx.render1_chained(cam, 8, 0, 4), lambda: ctx.chain_init_output(-1, 4, 1)):
+            try:
+                call()
+            except B.PtmiError:
+                continue
+            raise AssertionError("a refusal was expected")
+        ctx.render(cam, 8, 1)
+        ctx.download_color()
+    for devices in ([], [0, 1], [3]):
+        try:
+            with pkg.Group(devices, 8):
+                pass
+            raise AssertionError("a group over devices that do not exist was accepted")
+        except B.PtmiError:
+            pass
+
+
+SCENARIOS = [resident, partitioned, glass, closures, staged, threads, group, refusals]
+
+
+def nothing_left(where):
+    left = (stub.hipstub_live_blocks(), stub.hipstub_live_host_blocks(), stub.hipstub_live_streams(), stub.hipstub_live_events())
+    if left[0]:
+        stub.hipstub_print_live()
+    assert left == (0, 0, 0, 0), "%s: (device blocks, pinned blocks, streams, events) still alive = %r" % (where, left)
+
+
+def main():
+    only = os.environ.get("PTMI_HOSTSAN_ONLY")
+    stride = int(os.environ.get("PTMI_HOSTSAN_STRIDE", "1"))
+    stub.hipstub_set_device_size(8, 4 << 30)
+    report = {}
+    for sc in SCENARIOS:
+        if only and sc.__name__ not in only.split(","):
+            continue
+        before = [stub.hipstub_calls(k) for k in range(6)]
+        launches0 = stub.hipstub_launches(b"")
+        sc()
+        nothing_left(sc.__name__)
+        counts = [stub.hipstub_calls(k) - before[k] for k in range(6)]
+        launches = stub.hipstub_launches(b"") - launches0
+        walked = absorbed = 0
+        for kind, n in enumerate(counts):
+            for k in range(1, n + 1, stride):
+                stub.hipstub_fail(kind, k)
+                try:
+                    sc()
+                    absorbed += 1                                   # the library made do without (a fallback), or the failure fell into an expected refusal
+                    if os.environ.get("HIPSTUB_TRACE"):
+                        print("ABSORBED: %s, the %d-th %s" % (sc.__name__, k, KINDS[kind]), file=sys.stderr, flush=True)
+                except (B.PtmiError, MemoryError):
+                    pass
+                finally:
+                    stub.hipstub_fail(kind, 0)
+                    left_behind = stub.hipstub_clear_error()
+                walked += 1
+                # an error the library reported (or chose to ignore) is not left in the runtime's sticky slot for the next launch check to find
+                assert left_behind == 0, "%s with the %d-th %s failing: hipError %d was left in the sticky slot" % (sc.__name__, k, KINDS[kind], left_behind)
+                nothing_left("%s with the %d-th %s failing" % (sc.__name__, k, KINDS[kind]))
+        report[sc.__name__] = {"calls": dict(zip(KINDS, counts)), "kernel_launches": launches, "failure_points_walked": walked, "absorbed": absorbed,
+                               "stale_errors_handed_to_a_launch": stub.hipstub_stale_errors()}
+        print("hostsan %s: %r" % (sc.__name__, report[sc.__name__]), flush=True)
+    # ... and no launch of the library was ever blamed for an older call's error (hipGetLastError after a launch hands out the sticky slot)
+    assert stub.hipstub_stale_errors() == 0, "%d launches were handed an older call's error" % stub.hipstub_stale_errors()
+    print("sanitized host side: done")
+
+
+if __name__ == "__main__":
+    main()

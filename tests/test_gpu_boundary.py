@@ -198,6 +198,39 @@ def test_error_behaviour(fresh, pkg):
     c.synchronize()
 
 
+def test_another_callers_runtime_error_is_neither_tripped_over_nor_swallowed(fresh, pkg, ora):
+    """hipGetLastError() keeps the thread's last failure until somebody asks.  A failed call of the application's (here: an allocation of
+    2^60 bytes) must not make this library's next launches report failure -- they return hipLaunchKernel's own status
+    (csrc/ptmi_kernels.h: launch) -- and the error must still be there for its owner afterwards."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    sp, pl = pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    w, h = 64, 32
+    fresh.set_scene(sp, pl)
+    fresh.resize(w, h)
+    p = ctypes.c_void_p()
+    rc = hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(1 << 60))
+    assert rc != 0 and not p.value                                  # the application's own failure, left in the sticky slot
+    try:
+        fresh.init_output(77)                                       # seed kernel
+        fresh.render(cam, 8, 2)                                     # render Inline
+        fresh.render(cam, 8, 1, pkg.STREAMS)
+        got = fresh.download_state()
+        out1 = fresh.render1(cam, 8, w, h, got)                     # the closure, copying
+        tok, _ = fresh.render1_chained(cam, 8, w, h, planes_in=got) # ... and chained
+        out2 = fresh.chain_fetch(tok, w, h)
+        fresh.present(3)
+        assert hip.hipGetLastError() == rc                          # still the application's to find
+    finally:
+        hip.hipGetLastError()
+    start = initial_planes(ora, w, h, seed0=77)
+    want, _ = ora.render_inline(sp, pl, cam, w, h, 8, 2, start)
+    want, _ = ora.render_streams(sp, pl, cam, w, h, 1 << 10, 1, want)
+    assert_planes_equal(got, want, "renders issued with a foreign error pending")
+    assert_planes_equal(out1, out2, "the two closures")
+
+
 def test_context_is_usable_from_other_threads(ctx, pkg, ora):
     """The closure may be forced on any of three OS threads (app/Main.hs:178-180)."""
     import threading

@@ -1,0 +1,120 @@
+"""The HOST side of libptmi under AddressSanitizer + UndefinedBehaviorSanitizer, here, without a GPU (GPU sanitizers are not available on the
+pool; CPU ones are).  libptmi is built once more with its host code instrumented (-Xarch_host -fsanitize=address,undefined; the gfx950 code
+is the same) and driven, in a CHILD process, on a test-only stand-in for the HIP runtime (tests/cxx/hip_stub.cpp: device memory is host
+memory, copies are memcpy, kernels do not run) and the RCCL stand-in of tests/test_gpu_group_rccl_stub.py.  tests/hostsan_driver.py takes it
+through the resident path, partitions, GLASS and the stream form's bookkeeping, both closures with evictions / consumption / stale tokens,
+staged copies through the pinned ring's worker threads, groups of 1-8 members with their gathers, and the refusals -- first plainly, then once
+per FAILURE POINT: the k-th hipMalloc, copy, launch, synchronize, pinned allocation or stream/event creation of the scenario fails, for every
+k (about 2 200 runs, ~10 s).  Demanded of every run: no sanitizer report (an overrun copy, a block used after hipFree or freed twice, a
+wild stream handle, signed overflow, ...); after the contexts are destroyed the stand-in holds no device block, pinned block, stream or
+event; no error the library reported or chose to ignore is left in the runtime's sticky slot (hipGetLastError), and no launch of the library
+is ever blamed for an older call's error.
+
+What this does NOT test: any rendered value, any kernel, the HIP runtime or RCCL themselves.  The product never meets the stand-in: it is
+preloaded into the child process only, and libptmi has no CPU path (tests/test_abi.py)."""
+import glob
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as graft  # noqa: E402
+
+OUT = os.path.join(ROOT, "build", "hip_stub")
+STUB = os.path.join(OUT, "libhipstub.so")
+STUB_SRC = os.path.join(ROOT, "tests", "cxx", "hip_stub.cpp")
+SANITIZED = os.path.join(OUT, "libptmi_sanitized.so")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+HOST_SANITIZE = ["-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g", "-shared-libasan"]
+
+
+def runtime(which):
+    found = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.%s-x86_64.so" % which))
+    return found[-1] if found else None
+
+
+def asan_runtime():
+    return runtime("asan")
+
+
+def build_stub(out=STUB, sanitize="address,undefined"):
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(STUB_SRC):
+        return out
+    cmd = [CLANG, "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Werror",
+           "-fsanitize=" + sanitize, "-shared-libsan", "-fno-omit-frame-pointer", STUB_SRC, "-o", out + ".tmp"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    os.replace(out + ".tmp", out)
+    return out
+
+
+def dynamic_symbols(lib, undefined):
+    out = subprocess.run(["nm", "-D", "--undefined-only" if undefined else "--defined-only", lib], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    return {line.split()[-1].split("@")[0] for line in out.stdout.splitlines() if line.strip()}
+
+
+needs_asan = pytest.mark.skipif(asan_runtime() is None or not os.path.exists(CLANG), reason="the ROCm clang has no x86-64 ASan runtime here")
+
+
+@needs_asan
+def test_the_stand_in_covers_every_runtime_call_libptmi_makes():
+    """No call of the library may fall through to the real runtime in the child process: every hip* / __hip* symbol libptmi.so imports is
+    one the stand-in defines (so a new runtime call in csrc/ fails HERE until the stand-in knows it)."""
+    pkg = graft.load_package()
+    lib = pkg._build.build_lib()
+    wanted = {s for s in dynamic_symbols(lib, True) if s.startswith("hip") or s.startswith("__hip")}
+    assert len(wanted) >= 30, wanted
+    missing = wanted - dynamic_symbols(build_stub(), False)
+    assert not missing, "tests/cxx/hip_stub.cpp lacks %s" % sorted(missing)
+    assert not any("nccl" in s.lower() for s in dynamic_symbols(lib, True))      # RCCL is resolved with dlopen: the RCCL stand-in serves it
+
+
+@needs_asan
+def test_host_side_is_clean_under_asan_and_ubsan_at_every_failure_point():
+    import test_gpu_group_rccl_stub as rccl
+    pkg = graft.load_package()
+    stub = build_stub()
+    rccl_dir = os.path.dirname(rccl.build_stub())
+    lib = pkg._build.build_lib(out=SANITIZED, extra_flags=HOST_SANITIZE)
+    assert "__asan_init" in dynamic_symbols(lib, True)              # the host code really is instrumented
+    env = dict(os.environ, PTMI_HIPSTUB=stub, PTMI_SANITIZED_LIB=lib, LD_PRELOAD="%s %s" % (asan_runtime(), stub),
+               LD_LIBRARY_PATH=rccl_dir + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    env.pop("PTMI_HOSTSAN_ONLY", None)
+    env.pop("PTMI_HOSTSAN_STRIDE", None)
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hostsan_driver.py")], capture_output=True, text=True, env=env, timeout=900)
+    out = run.stdout + run.stderr
+    assert "runtime error" not in out and "AddressSanitizer" not in out and "HIPSTUB:" not in out, out[-4000:]
+    assert run.returncode == 0 and "sanitized host side: done" in run.stdout, out[-4000:]
+    reports = [line for line in run.stdout.splitlines() if line.startswith("hostsan ")]
+    assert len(reports) == 8, reports
+    walked = sum(int(line.split("'failure_points_walked': ")[1].split(",")[0]) for line in reports)
+    assert walked >= 2000, walked
+    print("\n".join(reports))
+
+
+@pytest.mark.skipif(runtime("tsan") is None or not os.path.exists(CLANG), reason="the ROCm clang has no x86-64 TSan runtime here")
+def test_host_threads_are_clean_under_tsan():
+    """The same, with the host code under ThreadSanitizer, on the scenarios in which host threads meet: four application threads on one
+    context through the chained closure (calls, fetches, releases, resident renders), a group's per-member threads, the pinned ring's
+    workers.  (The setup does report a race when there is one: checked by hand with a deliberately racy library under the same preload.)"""
+    import test_gpu_group_rccl_stub as rccl
+    pkg = graft.load_package()
+    out = os.path.join(ROOT, "build", "hip_stub_tsan")
+    stub = build_stub(os.path.join(out, "libhipstub.so"), "thread")
+    rccl_dir = os.path.dirname(rccl.build_stub())
+    lib = pkg._build.build_lib(out=os.path.join(out, "libptmi_tsan.so"), extra_flags=["-Xarch_host", "-fsanitize=thread", "-fno-omit-frame-pointer", "-g", "-shared-libsan"])
+    assert "__tsan_init" in dynamic_symbols(lib, True)
+    env = dict(os.environ, PTMI_HIPSTUB=stub, PTMI_SANITIZED_LIB=lib, LD_PRELOAD="%s %s" % (runtime("tsan"), stub),
+               LD_LIBRARY_PATH=rccl_dir + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""),
+               TSAN_OPTIONS="halt_on_error=0:exitcode=24:report_signal_unsafe=0", PTMI_HOSTSAN_ONLY="threads,staged,group", PTMI_HOSTSAN_STRIDE="1000000")
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hostsan_driver.py")], capture_output=True, text=True, env=env, timeout=900)
+    out_text = run.stdout + run.stderr
+    assert "ThreadSanitizer" not in out_text and "HIPSTUB:" not in out_text, out_text[-4000:]
+    assert run.returncode == 0 and "sanitized host side: done" in run.stdout, out_text[-4000:]
