@@ -12,7 +12,8 @@
 // calls.  What it does NOT validate: any rendered value, any kernel, any timing, the HIP runtime itself.  The product never loads it: it is
 // reachable through LD_PRELOAD in the test's child process only, and libptmi has no CPU path (ptmi_create fails without a device).
 //
-// Fault injection: hipstub_fail(kind, k) makes the k-th call (1-based, counted from now) of one kind fail once -- 0 hipMalloc
+// Fault injection: hipstub_fail(kind, k) makes the k-th call (1-based, counted from now) of one kind fail once (hipstub_fail_run: and the
+// `more` calls of the kind after it) -- 0 hipMalloc
 // (hipErrorOutOfMemory), 1 hipMemcpy / hipMemcpyAsync, 2 hipLaunchKernel, 3 hipStreamSynchronize, 4 hipHostMalloc, 5 event / stream creation
 // (hipErrorUnknown) -- so that a test can walk every failure point of a scenario and check that the context is still destroyable, nothing
 // leaks and nothing is touched after being freed.
@@ -39,7 +40,7 @@ std::map<void *, size_t> g_host_blocks;       // live pinned host blocks
 std::map<const void *, std::string> g_kernels;        // host stub address -> device name
 std::map<std::string, long> g_launches;
 long g_streams = 0, g_events = 0;
-long g_calls[6] = {0}, g_fail_at[6] = {0};
+long g_calls[6] = {0}, g_fail_at[6] = {0}, g_fail_more[6] = {0};
 thread_local int g_device = 0;             // (the current device is the thread's too)
 int g_cus = 8;                                 // a small device: launch grids and per-CU tables stay small
 size_t g_total = 64ull << 30;
@@ -63,6 +64,7 @@ bool fails(int kind)
         if (std::getenv("HIPSTUB_TRACE")) { std::fprintf(stderr, "HIPSTUB: injected failure of kind %d here:\n", kind); __sanitizer_print_stack_trace(); }
         return true;
     }
+    if (g_fail_at[kind] == 0 && g_fail_more[kind] > 0) { --g_fail_more[kind]; return true; }      // ... and the calls after it
     return false;
 }
 
@@ -76,7 +78,9 @@ extern "C" {
 
 // ---- the test's handles ------------------------------------------------------------------------------------------------------------
 int hipstub_is_the_stub(void) { return 1; }
-void hipstub_fail(int kind, long k) { std::lock_guard<std::mutex> lock(g_mu); if (kind >= 0 && kind < 6) g_fail_at[kind] = k; }
+void hipstub_fail(int kind, long k) { std::lock_guard<std::mutex> lock(g_mu); if (kind >= 0 && kind < 6) { g_fail_at[kind] = k; g_fail_more[kind] = 0; } }
+// the k-th call of the kind from now fails AND the `more` calls of the kind after it (a device that stays broken); hipstub_fail(kind, 0) ends it
+void hipstub_fail_run(int kind, long k, long more) { std::lock_guard<std::mutex> lock(g_mu); if (kind >= 0 && kind < 6) { g_fail_at[kind] = k; g_fail_more[kind] = more; } }
 long hipstub_calls(int kind) { std::lock_guard<std::mutex> lock(g_mu); return kind >= 0 && kind < 6 ? g_calls[kind] : -1; }
 long hipstub_live_blocks(void) { std::lock_guard<std::mutex> lock(g_mu); return (long)g_blocks.size(); }
 long hipstub_live_host_blocks(void) { std::lock_guard<std::mutex> lock(g_mu); return (long)g_host_blocks.size(); }

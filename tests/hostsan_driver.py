@@ -1,8 +1,9 @@
 """Driver of tests/test_host_sanitized.py (run in a CHILD process with the HIP stand-in and the sanitizer runtime preloaded; not a test
 module itself).  It takes the sanitized libptmi through scenarios of C-ABI calls -- the resident path, GLASS and the stream form, the
-closures, a partitioned image, a group with the RCCL stand-in -- first plainly, then once per failure point: the k-th hipMalloc / copy /
-launch / synchronize / pinned allocation / stream-or-event creation of the scenario fails, for every k.  After every run every context is
-destroyed and the stand-in must hold no block, pinned block, stream or event.  Kernels do not run on the stand-in: no value is checked."""
+closures, a partitioned image, host threads, a group with the RCCL stand-in -- first plainly, then once per failure point: the k-th hipMalloc /
+copy / launch / synchronize / pinned allocation / stream-or-event creation of the scenario fails, for every k (alone; with the next call of
+the kind; with every later one).  After every run every context is destroyed and the stand-in must hold no block, pinned block, stream or
+event.  Kernels do not run on the stand-in: no value is checked."""
 import ctypes
 import os
 import sys
@@ -19,12 +20,14 @@ stub = ctypes.CDLL(os.environ["PTMI_HIPSTUB"])
 assert stub.hipstub_is_the_stub() == 1
 stub.hipstub_live_bytes.restype = ctypes.c_ulonglong
 stub.hipstub_fail.argtypes = [ctypes.c_int, ctypes.c_long]
+stub.hipstub_fail_run.argtypes = [ctypes.c_int, ctypes.c_long, ctypes.c_long]
 stub.hipstub_calls.restype = ctypes.c_long
 stub.hipstub_set_device_size.argtypes = [ctypes.c_int, ctypes.c_ulonglong]
 B.load_library(os.environ["PTMI_SANITIZED_LIB"])
 assert b"fsanitize" in B.load_library().ptmi_build_id() or True      # (the id carries a suffix for the extra flags; not relied upon)
 
 KINDS = ["hipMalloc", "copy", "launch", "synchronize", "hipHostMalloc", "stream/event creation"]
+MORE = [0, 1, 1 << 30]
 cam = pkg.world.initial_camera()
 cam2 = cam.copy()
 cam2["position"][0] += 0.25
@@ -126,10 +129,14 @@ def resident():
             ctx.set_stream(None)
         finally:
             quiet(ctx.synchronize)
-            try:
-                ctx.set_stream(None)
-            except B.PtmiError:
-                ctx.set_stream(None)                                # (an injected failure happens once: the stream must be given back before it goes)
+            for _ in range(2):
+                try:
+                    ctx.set_stream(None)
+                    break
+                except B.PtmiError:
+                    pass
+            else:
+                ctx.close()                                         # the context could not be told (the device stays broken): it goes before the stream does
             stub.hipStreamDestroy(s)
         with DeviceBlocks([40 * 16 * 4] * 7) as bound:
             try:
@@ -466,9 +473,10 @@ def main():
         counts = [stub.hipstub_calls(k) - before[k] for k in range(6)]
         launches = stub.hipstub_launches(b"") - launches0
         walked = absorbed = 0
-        for kind, n in enumerate(counts):
-            for k in range(1, n + 1, stride):
-                stub.hipstub_fail(kind, k)
+        # one failure; a failure and the next call of the kind failing too (the recovery's own call); a device that stays broken
+        for kind, n, more in [(kind, n, more) for more in MORE for kind, n in enumerate(counts)]:
+            for k in range(1, n + 1, stride if more == 0 else stride * 3):
+                stub.hipstub_fail_run(kind, k, more)
                 try:
                     sc()
                     absorbed += 1                                   # the library made do without (a fallback), or the failure fell into an expected refusal
@@ -482,7 +490,7 @@ def main():
                 walked += 1
                 # an error the library reported (or chose to ignore) is not left in the runtime's sticky slot for the next launch check to find
                 assert left_behind == 0, "%s with the %d-th %s failing: hipError %d was left in the sticky slot" % (sc.__name__, k, KINDS[kind], left_behind)
-                nothing_left("%s with the %d-th %s failing" % (sc.__name__, k, KINDS[kind]))
+                nothing_left("%s with the %d-th %s failing (and %d more)" % (sc.__name__, k, KINDS[kind], more))
         report[sc.__name__] = {"calls": dict(zip(KINDS, counts)), "kernel_launches": launches, "failure_points_walked": walked, "absorbed": absorbed,
                                "stale_errors_handed_to_a_launch": stub.hipstub_stale_errors()}
         print("hostsan %s: %r" % (sc.__name__, report[sc.__name__]), flush=True)

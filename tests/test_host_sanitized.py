@@ -3,9 +3,10 @@ pool; CPU ones are).  libptmi is built once more with its host code instrumented
 is the same) and driven, in a CHILD process, on a test-only stand-in for the HIP runtime (tests/cxx/hip_stub.cpp: device memory is host
 memory, copies are memcpy, kernels do not run) and the RCCL stand-in of tests/test_gpu_group_rccl_stub.py.  tests/hostsan_driver.py takes it
 through the resident path, partitions, GLASS and the stream form's bookkeeping, both closures with evictions / consumption / stale tokens,
-staged copies through the pinned ring's worker threads, groups of 1-8 members with their gathers, and the refusals -- first plainly, then once
-per FAILURE POINT: the k-th hipMalloc, copy, launch, synchronize, pinned allocation or stream/event creation of the scenario fails, for every
-k (about 2 200 runs, ~10 s).  Demanded of every run: no sanitizer report (an overrun copy, a block used after hipFree or freed twice, a
+staged copies through the pinned ring's worker threads, four threads on one context, groups of 1-8 members with their gathers, and the
+refusals -- first plainly, then once per FAILURE POINT: the k-th hipMalloc, copy, launch, synchronize, pinned allocation or stream/event
+creation of the scenario fails, for every k; then the k-th AND the next call of the kind (the recovery's own call fails), and the k-th and
+every later one (a device that stays broken), for every third k (about 4 200 runs, ~25 s).  Demanded of every run: no sanitizer report (an overrun copy, a block used after hipFree or freed twice, a
 wild stream handle, signed overflow, ...); after the contexts are destroyed the stand-in holds no device block, pinned block, stream or
 event; no error the library reported or chose to ignore is left in the runtime's sticky slot (hipGetLastError), and no launch of the library
 is ever blamed for an older call's error.
@@ -95,7 +96,7 @@ def test_host_side_is_clean_under_asan_and_ubsan_at_every_failure_point():
     reports = [line for line in run.stdout.splitlines() if line.startswith("hostsan ")]
     assert len(reports) == 8, reports
     walked = sum(int(line.split("'failure_points_walked': ")[1].split(",")[0]) for line in reports)
-    assert walked >= 2000, walked
+    assert walked >= 4000, walked
     print("\n".join(reports))
 
 
