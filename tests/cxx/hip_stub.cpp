@@ -32,13 +32,24 @@ extern "C" void __sanitizer_print_stack_trace(void);
 
 namespace {
 
-std::mutex g_mu;
-std::map<void *, size_t> g_blocks;            // live "device" blocks
-std::map<void *, long> g_block_seq;           // ... and the how-manieth hipMalloc of the process each was
+// Made on first use and never destroyed: a hipcc-compiled object registers its kernels from a static constructor, which may run before
+// this library's own (the library preloaded into a program that links libptmi directly) and unregisters them from a destructor after it.
+struct State {
+    std::mutex mu;
+    std::map<void *, size_t> blocks;            // live "device" blocks
+    std::map<void *, long> block_seq;           // ... and the how-manieth hipMalloc of the process each was
+    std::map<void *, size_t> host_blocks;       // live pinned host blocks
+    std::map<const void *, std::string> kernels;        // host stub address -> device name
+    std::map<std::string, long> launches;
+};
+State &S() { static State *state = new State; return *state; }
+#define g_mu (S().mu)
+#define g_blocks (S().blocks)
+#define g_block_seq (S().block_seq)
+#define g_host_blocks (S().host_blocks)
+#define g_kernels (S().kernels)
+#define g_launches (S().launches)
 long g_mallocs = 0;
-std::map<void *, size_t> g_host_blocks;       // live pinned host blocks
-std::map<const void *, std::string> g_kernels;        // host stub address -> device name
-std::map<std::string, long> g_launches;
 long g_streams = 0, g_events = 0;
 long g_calls[6] = {0}, g_fail_at[6] = {0}, g_fail_more[6] = {0};
 thread_local int g_device = 0;             // (the current device is the thread's too)

@@ -119,3 +119,32 @@ def test_host_threads_are_clean_under_tsan():
     out_text = run.stdout + run.stderr
     assert "ThreadSanitizer" not in out_text and "HIPSTUB:" not in out_text, out_text[-4000:]
     assert run.returncode == 0 and "sanitized host side: done" in run.stdout, out_text[-4000:]
+
+
+@needs_asan
+def test_the_cxx_host_mirror_is_clean_under_asan_and_leak_free(ora):
+    """hostcxx/scene.hpp (the C++ mirror of the reference's closure: lazy RenderResults that hold tokens, released by destructors) through the
+    whole flow of tests/cxx/host_mirror_test.cpp -- compileFor's 100 chained calls, reseed, camera move, a RenderResult from the host, the
+    copying closure, the resident flow -- as a NATIVE program under ASan + UBSan + LeakSanitizer (a native program can have leak detection:
+    "device" blocks are heap blocks on the stand-in, so a state or plane never given back is a reported leak).  Its comparisons with the
+    oracle FAIL here by construction (kernels do not run on the stand-in): the GPU test of tests/test_host_cxx.py checks the values."""
+    pkg = graft.load_package()
+    stub = build_stub()
+    lib = pkg._build.build_lib(out=SANITIZED, extra_flags=HOST_SANITIZE)
+    exe = os.path.join(OUT, "host_mirror_sanitized")
+    rt_dir = os.path.dirname(asan_runtime())
+    cmd = [CLANG, "-std=c++17", "-O1", "-g", "-Wall", "-fsanitize=address,undefined", "-shared-libsan", "-fno-omit-frame-pointer",
+           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "haskell-path-tracer_amd", "hostcxx"),
+           os.path.join(ROOT, "tests", "cxx", "host_mirror_test.cpp"), "-o", exe, lib, ora.LIB,
+           "-Wl,-rpath," + OUT, "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-Wl,-rpath," + rt_dir, "-Wl,--allow-shlib-undefined", "-fopenmp"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    supp = os.path.join(OUT, "lsan.supp")
+    with open(supp, "w") as fh:
+        fh.write("leak:libomp\nleak:libgomp\n")                    # (the OpenMP runtime's own, under the oracle)
+    env = dict(os.environ, LD_PRELOAD="%s %s" % (asan_runtime(), stub), ASAN_OPTIONS="detect_leaks=1:exitcode=23",
+               LSAN_OPTIONS="suppressions=%s:print_suppressions=0" % supp, UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    run = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
+    out = run.stdout + run.stderr
+    assert "Sanitizer" not in out and "runtime error" not in out and "HIPSTUB:" not in out, out[-4000:]
+    assert run.returncode == 1 and "host mirror FAILED" in out, out[-2000:]       # the flow ran to its end; values are the GPU test's business
