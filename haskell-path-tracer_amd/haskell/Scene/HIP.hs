@@ -168,6 +168,8 @@ pokeCamera p Camera{..} = do
   pokeArray (castPtr p) [px, py, pz, rx, ry, rz :: Float]
   pokeByteOff p 24 (fromIntegral _cameraFov :: Int64)
 
+-- (ptmi_last_error hands out the calling OS thread's own message, or -- an unbound Haskell thread may have moved between the two calls -- a
+-- copy of the context's latest one: never a pointer another thread's failure can free.)
 check :: Ptr PtmiCtx -> CInt -> IO ()
 check ctx rc = when (rc /= 0) $ do
   msg <- c_last_error ctx >>= peekCString

@@ -5,7 +5,8 @@
 //
 // What it is: "device memory" is host memory (calloc: a fresh block reads as zeros), copies are memcpy, memsets are memset, streams and
 // events are small heap objects and everything is synchronous.  KERNELS DO NOT RUN: hipLaunchKernel counts the launch under the kernel's
-// name and returns success.  Whatever a real kernel would have written stays as it was (zeros in a fresh block).
+// name and returns success.  Whatever a real kernel would have written stays as it was (zeros in a fresh block) -- except the few counter
+// words a test places into a read-back with hipstub_poke, to send the host down the paths that depend on what a kernel counted.
 //
 // What a test on it validates: memory safety and error handling of the host code (a copy past the end of a block is a heap overflow ASan
 // sees; a block freed twice or used after hipFree likewise; a block never freed shows in hipstub_live_blocks), and the SEQUENCE of runtime
@@ -27,6 +28,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <vector>
 
 extern "C" void __sanitizer_print_stack_trace(void);
 
@@ -41,6 +43,8 @@ struct State {
     std::map<void *, size_t> host_blocks;       // live pinned host blocks
     std::map<const void *, std::string> kernels;        // host stub address -> device name
     std::map<std::string, long> launches;
+    struct Poke { std::string kernel; long nth; size_t offset; unsigned int value; bool armed; };
+    std::vector<Poke> pokes;
 };
 State &S() { static State *state = new State; return *state; }
 #define g_mu (S().mu)
@@ -112,6 +116,14 @@ long hipstub_launches(const char *name_part)          // launches of kernels who
         if (!name_part || !*name_part || k.first.find(name_part) != std::string::npos) total += k.second;
     return total;
 }
+// Kernels do not run, so the counters the host reads back after a launch are zeros.  A test can say what they "were": after the nth launch
+// (from now) of a kernel whose name contains `kernel_part`, the first device-to-host copy large enough gets `value` at byte `offset`.
+void hipstub_poke(const char *kernel_part, long nth, unsigned long long offset, unsigned int value)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    S().pokes.push_back(State::Poke{kernel_part ? kernel_part : "", nth, (size_t)offset, value, false});
+}
+void hipstub_clear_pokes(void) { std::lock_guard<std::mutex> lock(g_mu); S().pokes.clear(); }
 void hipstub_print_live(void)                     // which hipMalloc calls of the process made the blocks that are still alive
 {
     std::lock_guard<std::mutex> lock(g_mu);
@@ -152,7 +164,10 @@ hipError_t hipLaunchKernel(const void *function, dim3 grid, dim3 block, void **a
         return set(hipErrorInvalidConfiguration);
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_kernels.find(function);
-    ++g_launches[it == g_kernels.end() ? std::string("<unregistered>") : it->second];
+    const std::string name = it == g_kernels.end() ? std::string("<unregistered>") : it->second;
+    ++g_launches[name];
+    for (State::Poke &p : S().pokes)
+        if (!p.armed && name.find(p.kernel) != std::string::npos && --p.nth == 0) p.armed = true;
     g_launch_seq = ++g_seq;
     return hipSuccess;
 }
@@ -253,11 +268,21 @@ hipError_t hipHostFree(void *p)
     std::free(p);
     return hipSuccess;
 }
-hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind)
+hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
 {
     if (fails(1)) return set(hipErrorUnknown);
     if (bytes && (!dst || !src)) return set(hipErrorInvalidValue);
     std::memmove(dst, src, bytes);                           // (instrumented: a span past either block's end is ASan's to report)
+    if (kind == hipMemcpyDeviceToHost) {                     // what a kernel "would have counted": the test's words, into the first read-back that holds them
+        std::lock_guard<std::mutex> lock(g_mu);
+        std::vector<State::Poke> &pokes = S().pokes;
+        for (size_t i = 0; i < pokes.size();) {
+            if (pokes[i].armed && pokes[i].offset + sizeof(unsigned int) <= bytes) {
+                std::memcpy(static_cast<char *>(dst) + pokes[i].offset, &pokes[i].value, sizeof(unsigned int));
+                pokes.erase(pokes.begin() + (long)i);
+            } else ++i;
+        }
+    }
     return hipSuccess;
 }
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t stream)

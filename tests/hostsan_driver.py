@@ -23,11 +23,15 @@ stub.hipstub_fail.argtypes = [ctypes.c_int, ctypes.c_long]
 stub.hipstub_fail_run.argtypes = [ctypes.c_int, ctypes.c_long, ctypes.c_long]
 stub.hipstub_calls.restype = ctypes.c_long
 stub.hipstub_set_device_size.argtypes = [ctypes.c_int, ctypes.c_ulonglong]
+stub.hipstub_poke.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_ulonglong, ctypes.c_uint]
+stub.hipstub_launches.argtypes = [ctypes.c_char_p]
+stub.hipstub_launches.restype = ctypes.c_long
 B.load_library(os.environ["PTMI_SANITIZED_LIB"])
 assert b"fsanitize" in B.load_library().ptmi_build_id() or True      # (the id carries a suffix for the extra flags; not relied upon)
 
 KINDS = ["hipMalloc", "copy", "launch", "synchronize", "hipHostMalloc", "stream/event creation"]
 MORE = [0, 1, 1 << 30]
+PLAIN = True                                                        # False while a failure is being injected: a scenario's own expectations hold for the plain run only
 cam = pkg.world.initial_camera()
 cam2 = cam.copy()
 cam2["position"][0] += 0.25
@@ -375,6 +379,93 @@ def threads():
         raise errors[0]
 
 
+def layout():
+    """Where the stream form keeps its counters (csrc/ptmi_kernels.h): line L of the block is word L * kCounterStride."""
+    import re
+    text = open(os.path.join(ROOT, "haskell-path-tracer_amd", "csrc", "ptmi_kernels.h")).read()
+    k = {}
+    for stmt in re.findall(r"constexpr int ([^;]+);", text):
+        for part in re.split(r",\s*(?=k[A-Z])", stmt):
+            m = re.match(r"\s*(k\w+)\s*=\s*([^,;/]+)", part)
+            if m:
+                try:
+                    k[m.group(1)] = int(eval(m.group(2), {}, dict(k)))
+                except Exception:                                     # noqa: BLE001  (constants this function has no use for)
+                    pass
+    return k
+
+
+def stream_overflow():
+    """The stream form's host loop acts on what its kernels counted -- children left in the overflow stream (another LEVEL is launched), children
+    that found it full (the call is REDONE with longer streams, the planes put back).  Kernels do not run here, so the counts are placed
+    into the read-backs (hipstub_poke)."""
+    k = layout()
+    line = lambda n: n * k["kCounterStride"] * 4                   # noqa: E731  byte offset of counter line n
+    level_line = lambda lv, i: line(k["kLvCursor"] + k["kLvPerLevel"] * lv + i)      # noqa: E731
+    split, level = b"streams_split_kernel", b"streams_level_kernel"
+    sp, pl = pkg.world.glass_scene()
+    stub.hipstub_clear_pokes()
+    try:
+        with pkg.Context(0) as ctx:
+            ctx.set_scene(sp, pl)
+            ctx.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)
+            ctx.resize(160, 96)
+            ctx.init_output(3)
+            ctx.render(cam, 8, 4, pkg.STREAMS)
+            count = lambda name: stub.hipstub_launches(name)       # noqa: E731
+            # 1. the split kernel left 3 children in its overflow stream: one level is launched for them
+            n_split, n_level = count(split), count(level)
+            ctx.reset_stats()
+            stub.hipstub_poke(split, 1, level_line(0, 0), 3)        # the stream's cursor
+            stub.hipstub_poke(split, 1, level_line(0, 2), 3)        # the children stored (shard 0)
+            ctx.render(cam, 8, 4, pkg.STREAMS)
+            if PLAIN:
+                assert (count(split) - n_split, count(level) - n_level) == (1, 1)
+                assert ctx.stats()["stream_rays_overflowed"] == 3, ctx.stats()
+            # 2. ... and that level leaves 2 of its own: a second level
+            n_split, n_level = count(split), count(level)
+            stub.hipstub_poke(split, 1, level_line(0, 0), 3)
+            stub.hipstub_poke(split, 1, level_line(0, 3), 3)        # (another shard)
+            stub.hipstub_poke(level, 1, level_line(1, 0), 2)
+            stub.hipstub_poke(level, 1, level_line(1, 2), 2)
+            ctx.render(cam, 8, 4, pkg.STREAMS)
+            if PLAIN:
+                assert (count(split) - n_split, count(level) - n_level) == (1, 2)
+            # 3. five children found the stream full: longer streams, the planes put back, the launch once more -- nothing is dropped
+            n_split = count(split)
+            ctx.reset_stats()
+            stub.hipstub_poke(split, 1, line(k["kLvDropped"]), 5)
+            ctx.render(cam, 8, 4, pkg.STREAMS)
+            if PLAIN:
+                assert count(split) - n_split == 2
+                assert ctx.stats()["stream_rays_dropped"] == 0, ctx.stats()
+            # ... twice in one call
+            n_split = count(split)
+            stub.hipstub_poke(split, 1, line(k["kLvDropped"]), 5)
+            stub.hipstub_poke(split, 2, line(k["kLvDropped"]), 1)
+            ctx.render(cam, 8, 4, pkg.STREAMS)
+            if PLAIN:
+                assert count(split) - n_split == 3
+            # 4. with the streams at their longest the drops stand, counted
+            ctx.set_option(B.OPT_STREAM_CAPACITY, 64)
+            n_split = count(split)
+            ctx.reset_stats()
+            stub.hipstub_poke(split, 1, line(k["kLvDropped"]), 9)
+            ctx.render(cam, 8, 4, pkg.STREAMS)
+            if PLAIN:
+                assert count(split) - n_split == 1
+                assert ctx.stats()["stream_rays_dropped"] == 9, ctx.stats()
+            # 5. a smaller image afterwards, and the scene losing its GLASS (the colour backup goes)
+            ctx.resize(64, 32)
+            ctx.init_output(4)
+            stub.hipstub_poke(split, 1, line(k["kLvDropped"]), 2)
+            ctx.render(cam, 8, 4, pkg.STREAMS)
+            ctx.set_scene(*pkg.world.scene16())
+            ctx.render(cam, 8, 4, pkg.STREAMS)
+    finally:
+        stub.hipstub_clear_pokes()
+
+
 def group():
     sp, pl = pkg.world.scene16()
     for devices, stripe, (w, h) in (([0, 0, 0], 4, (40, 30)), ([0, 0], 0, (32, 16)), ([0] * 8, 2, (16, 9)), ([0], 8, (24, 24))):
@@ -448,7 +539,7 @@ def refusals():
             pass
 
 
-SCENARIOS = [resident, partitioned, glass, closures, staged, threads, group, refusals]
+SCENARIOS = [resident, partitioned, glass, stream_overflow, closures, staged, threads, group, refusals]
 
 
 def nothing_left(where):
@@ -459,6 +550,7 @@ def nothing_left(where):
 
 
 def main():
+    global PLAIN
     only = os.environ.get("PTMI_HOSTSAN_ONLY")
     stride = int(os.environ.get("PTMI_HOSTSAN_STRIDE", "1"))
     stub.hipstub_set_device_size(8, 4 << 30)
@@ -468,7 +560,9 @@ def main():
             continue
         before = [stub.hipstub_calls(k) for k in range(6)]
         launches0 = stub.hipstub_launches(b"")
+        PLAIN = True
         sc()
+        PLAIN = False
         nothing_left(sc.__name__)
         counts = [stub.hipstub_calls(k) - before[k] for k in range(6)]
         launches = stub.hipstub_launches(b"") - launches0

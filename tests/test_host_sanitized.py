@@ -2,7 +2,8 @@
 pool; CPU ones are).  libptmi is built once more with its host code instrumented (-Xarch_host -fsanitize=address,undefined; the gfx950 code
 is the same) and driven, in a CHILD process, on a test-only stand-in for the HIP runtime (tests/cxx/hip_stub.cpp: device memory is host
 memory, copies are memcpy, kernels do not run) and the RCCL stand-in of tests/test_gpu_group_rccl_stub.py.  tests/hostsan_driver.py takes it
-through the resident path, partitions, GLASS and the stream form's bookkeeping, both closures with evictions / consumption / stale tokens,
+through the resident path, partitions, GLASS and the stream form's bookkeeping (with the counts its kernels would have read back PLACED
+into the read-backs: overflow levels, the redo with longer streams, drops that stand), both closures with evictions / consumption / stale tokens,
 staged copies through the pinned ring's worker threads, four threads on one context, groups of 1-8 members with their gathers, and the
 refusals -- first plainly, then once per FAILURE POINT: the k-th hipMalloc, copy, launch, synchronize, pinned allocation or stream/event
 creation of the scenario fails, for every k; then the k-th AND the next call of the kind (the recovery's own call fails), and the k-th and
@@ -94,7 +95,7 @@ def test_host_side_is_clean_under_asan_and_ubsan_at_every_failure_point():
     assert "runtime error" not in out and "AddressSanitizer" not in out and "HIPSTUB:" not in out, out[-4000:]
     assert run.returncode == 0 and "sanitized host side: done" in run.stdout, out[-4000:]
     reports = [line for line in run.stdout.splitlines() if line.startswith("hostsan ")]
-    assert len(reports) == 8, reports
+    assert len(reports) == 9, reports
     walked = sum(int(line.split("'failure_points_walked': ")[1].split(",")[0]) for line in reports)
     assert walked >= 4000, walked
     print("\n".join(reports))
