@@ -1173,10 +1173,14 @@ int ptmi_set_scene(ptmi_ctx *c, const ptmi_sphere *spheres, int n_spheres, const
     std::vector<float4> packed;
     pack_scene(spheres, n_spheres, planes, n_planes, packed);
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->d_scene) { (void)hipFree(c->d_scene); c->d_scene = nullptr; }
-    PTMI_HIP(c, hipMalloc(&c->d_scene, packed.size() * sizeof(float4)));
-    PTMI_HIP(c, hipMemcpyAsync(c->d_scene, packed.data(), packed.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    PTMI_HIP(c, hipStreamSynchronize(c->stream));               // `packed` dies at return
+    // the new scene stands complete before the old one goes: a failure here leaves the context with the scene (and the counts) it had
+    void *fresh = nullptr;
+    PTMI_HIP(c, hipMalloc(&fresh, packed.size() * sizeof(float4)));
+    hipError_t e = hipMemcpyAsync(fresh, packed.data(), packed.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // `packed` dies at return
+    if (e != hipSuccess) { (void)hipFree(fresh); PTMI_HIP(c, e); }
+    if (c->d_scene) (void)hipFree(c->d_scene);
+    c->d_scene = static_cast<float4 *>(fresh);
     c->n_spheres = n_spheres; c->n_planes = n_planes;
     ++c->scene_version;
     c->has_glass = false;
@@ -1205,15 +1209,22 @@ int ptmi_resize(ptmi_ctx *c, int width, int height)
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
     if (c->owned_block) { (void)hipFree(c->owned_block); c->owned_block = nullptr; }
     if (c->colour_backup) { (void)hipFree(c->colour_backup); c->colour_backup = nullptr; c->colour_backup_bytes = 0; }   // (sized by the old image)
-    c->width = width; c->height = height;
-    c->rows_local = rows_of_part(height, effective_stripe(c), c->n_parts, c->part);
+    // The old planes are gone (first: the new ones may need their room).  Until the new ones stand the context is UNSIZED -- a failure below
+    // must not leave it pointing into the block just freed: every call that needs planes then answers PTMI_ESTATE.
+    c->owned = Planes{};
+    c->width = c->height = c->rows_local = 0;
     c->use_bound = false;
-    const size_t n = (size_t)c->rows_local * (size_t)width;
+    const int rows_local = rows_of_part(height, effective_stripe(c), c->n_parts, c->part);
+    const size_t n = (size_t)rows_local * (size_t)width;
     const size_t bytes = planes_bytes(n > 0 ? n : 1);
-    PTMI_HIP(c, hipMalloc(&c->owned_block, bytes));
-    PTMI_HIP(c, hipMemsetAsync(c->owned_block, 0, bytes, c->stream));   // ordered before anything launched on the stream
-    PTMI_HIP(c, hipStreamSynchronize(c->stream));
-    c->owned = carve(c->owned_block, n > 0 ? n : 1);
+    void *block = nullptr;
+    PTMI_HIP(c, hipMalloc(&block, bytes));
+    hipError_t e = hipMemsetAsync(block, 0, bytes, c->stream);         // ordered before anything launched on the stream
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipFree(block); PTMI_HIP(c, e); }
+    c->owned_block = block;
+    c->owned = carve(block, n > 0 ? n : 1);
+    c->width = width; c->height = height; c->rows_local = rows_local;
     return PTMI_OK;
 }
 

@@ -207,11 +207,24 @@ int ptmi_group_resize(ptmi_group *g, int width, int height)
     if (!g) return PTMI_EINVAL;
     std::lock_guard<std::mutex> lock(g->mu);
     release_gather(g);
-    for (size_t i = 0; i < g->members.size(); ++i)
+    g->width = g->height = 0;                                // unsized until EVERY member stands at the new size: a failure half-way leaves members of
+    for (size_t i = 0; i < g->members.size(); ++i)           // two sizes (and one of none), and the read-outs below go by the group's
         if (int rc = ptmi_resize(g->members[i], width, height)) return member_fail(g, (int)i, rc);
     g->width = width; g->height = height;
     return PTMI_OK;
 }
+
+namespace {
+// The rows member i holds -- which must be the rows the GROUP's size deals it (a member resized on its own, or left unsized by a failure,
+// would have the read-outs copy by one size into buffers of another).
+int member_rows(ptmi_group *g, int i, int *rows)
+{
+    *rows = ptmi_local_rows(g->members[(size_t)i]);
+    if (*rows < 0 || *rows != ptmi_partition_rows(g->height, g->stripe_rows, (int)g->members.size(), i))
+        return gfail(g, PTMI_ESTATE, "member " + std::to_string(i) + " is not sized as the group is (ptmi_group_resize sizes the members)");
+    return PTMI_OK;
+}
+}  // namespace
 
 int ptmi_group_init_output(ptmi_group *g, uint64_t seed0)
 {
@@ -291,12 +304,18 @@ int ptmi_group_download_color(ptmi_group *g, float *r, float *gp, float *b)
     const int n = (int)g->members.size();
     const size_t w = (size_t)g->width;
     if (n == 1) {
+        int rows = 0;
+        if (int rc = member_rows(g, 0, &rows)) return rc;
         if (int rc = ptmi_download_color(g->members[0], r, gp, b)) return member_fail(g, 0, rc);
         return PTMI_OK;
     }
     // every member's planes into its slice of the scratch, all members at once; then the stripes into place
     std::vector<size_t> offset((size_t)n + 1, 0);
-    for (int i = 0; i < n; ++i) offset[(size_t)i + 1] = offset[(size_t)i] + 3 * (size_t)ptmi_local_rows(g->members[(size_t)i]) * w;
+    std::vector<int> rows_of((size_t)n, 0);
+    for (int i = 0; i < n; ++i) {
+        if (int rc = member_rows(g, i, &rows_of[(size_t)i])) return rc;
+        offset[(size_t)i + 1] = offset[(size_t)i] + 3 * (size_t)rows_of[(size_t)i] * w;
+    }
     g->host_scratch.resize(offset[(size_t)n]);
     std::vector<int> rcs((size_t)n, PTMI_OK);
     std::vector<std::thread> threads;
@@ -304,7 +323,7 @@ int ptmi_group_download_color(ptmi_group *g, float *r, float *gp, float *b)
     for (int i = 0; i < n; ++i) {
         threads.emplace_back([&, i]() {
             ptmi_ctx *c = g->members[(size_t)i];
-            const int rows = ptmi_local_rows(c);
+            const int rows = rows_of[(size_t)i];
             float *base = g->host_scratch.data() + offset[(size_t)i];
             const size_t plane = (size_t)rows * w;
             rcs[(size_t)i] = ptmi_download_color(c, base, base + plane, base + 2 * plane);
@@ -353,8 +372,10 @@ int ptmi_group_gather_color(ptmi_group *g, int root, float *r_dev, float *g_dev,
         }
     }
     std::vector<size_t> floats((size_t)n), offset((size_t)n + 1, 0);
+    std::vector<int> rows_of((size_t)n, 0);
     for (int i = 0; i < n; ++i) {
-        floats[(size_t)i] = 3 * (size_t)ptmi_local_rows(g->members[(size_t)i]) * w;
+        if (int rc = member_rows(g, i, &rows_of[(size_t)i])) return rc;
+        floats[(size_t)i] = 3 * (size_t)rows_of[(size_t)i] * w;
         offset[(size_t)i + 1] = offset[(size_t)i] + floats[(size_t)i];
     }
     if (g->send_snap.empty() || g->recv_root != root || g->recv_floats != offset[(size_t)n]) {
@@ -399,7 +420,7 @@ int ptmi_group_gather_color(ptmi_group *g, int root, float *r_dev, float *g_dev,
                                     hipMemcpyDeviceToDevice, g->comm_streams[(size_t)root]));
     // 3. stitch the stripes into the caller's [H][W] planes on the root
     for (int i = 0; i < n; ++i) {
-        const int rows = ptmi_local_rows(g->members[(size_t)i]);
+        const int rows = rows_of[(size_t)i];
         if (rows <= 0) continue;
         GROUP_HIP(g, ptmi::launch_stitch(recv + offset[(size_t)i], rows, g->width, g->stripe_rows, n, i, r_dev, g_dev, b_dev, g->comm_streams[(size_t)root]));
     }

@@ -124,7 +124,11 @@ void        ptmi_destroy(ptmi_ctx *ctx);
  * `ctx`, the context's latest message whoever saw it.  The text stays valid until the same thread's next failing call or next ptmi_last_error:
  * threads that share a context never read each other's strings.  A HIP error reported through a return code is taken out of the runtime's
  * own sticky slot (hipGetLastError) -- the caller's next launch check does not find it again -- and an error another library left there
- * is neither mistaken for this library's nor cleared by it. */
+ * is neither mistaken for this library's nor cleared by it.
+ * After a failure the context stays usable and consistent: a failed ptmi_set_scene keeps the scene it had; a failed ptmi_resize leaves the
+ * context UNSIZED (calls that need planes answer PTMI_ESTATE until a ptmi_resize succeeds; ptmi_group_resize likewise for the group); a
+ * render call that fails with PTMI_EHIP / PTMI_ENOMEM half-way leaves the CONTENT of the planes unspecified (re-initialise them), never a
+ * dangling pointer.  tests/test_host_sanitized.py walks every failure point under AddressSanitizer. */
 const char *ptmi_last_error(const ptmi_ctx *ctx);
 
 /* ---- configuration ----------------------------------------------------------- */

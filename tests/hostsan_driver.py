@@ -466,6 +466,152 @@ def stream_overflow():
         stub.hipstub_clear_pokes()
 
 
+def monkey(seed=0, steps=1500):
+    """A seeded random walk over the C ABI on one context and one group: any order of calls with any arguments, valid or not, and now and then
+    an injected runtime failure.  A refusal (PtmiError) is an answer; a sanitizer report, a hang or a leak is not."""
+    r = np.random.default_rng(seed)
+    scenes = [pkg.world.scene16(), pkg.world.main_scene(), pkg.world.glass_scene()]
+    sizes = [(8, 8), (64, 16), (72, 40), (136, 24), (33, 7), (1, 1), (256, 64), (320, 240)]       # (the last: copies go through the pinned ring)
+    k = layout()
+    state = {"w": 0, "h": 0, "tokens": [], "glass": False}
+    cams = [cam, cam2]
+
+    def pick(xs):
+        return xs[int(r.integers(0, len(xs)))]
+
+    def wh():
+        return (state["w"], state["h"]) if state["w"] and r.random() < 0.8 else pick(sizes)
+
+    def wild_token():
+        return int(r.integers(1, 1 << 50)) if r.random() < 0.5 else 0
+
+    stream = ctypes.c_void_p()
+    if stub.hipStreamCreateWithFlags(ctypes.byref(stream), 1) != 0:
+        stub.hipstub_clear_error()
+        return
+    with DeviceBlocks([320 * 240 * 4] * 7) as mine, pkg.Context(0) as ctx, pkg.Group([0] * int(r.integers(1, 5)), int(pick([0, 2, 8]))) as g:
+        def bind():
+            if r.random() < 0.5:
+                ctx._check(ctx._lib.ptmi_bind_planes(ctx._h, *[ctypes.c_void_p(p) for p in mine]))
+            else:
+                ctx.unbind()
+
+        def streams():
+            ctx.set_stream(stream.value if r.random() < 0.5 else None)
+
+        def poke():                                                 # what the stream form's kernels "counted", for the next read-back
+            which = pick([k["kLvDropped"], k["kLvCursor"], k["kLvCursor"] + 2, k["kLvCursor"] + k["kLvPerLevel"] + 2, k["kLvSplitPixels"], k["kLvDeepest"]])
+            stub.hipstub_poke(pick([b"streams_split_kernel", b"streams_level_kernel", b"streams_primary_kernel"]), 1,
+                              which * k["kCounterStride"] * 4, int(pick([1, 3, 64, 5000, 1 << 31, 0xffffffff])))
+
+        def stream_form():
+            ctx.set_option(B.OPT_STREAMS_FORM, int(pick([B.FORM_STREAM, B.FORM_STREAM, B.FORM_AUTO, B.FORM_PIXEL])))
+
+        def set_scene():
+            k = int(r.integers(0, len(scenes)))
+            ctx.set_scene(*scenes[k]); state["glass"] = k == 2
+
+        def resize():
+            w, h = pick(sizes)
+            ctx.resize(w, h); state["w"], state["h"] = w, h
+
+        def partition():
+            n = int(pick([1, 2, 3, 8])); ctx.set_partition(int(pick([1, 2, 8, 16])), n, int(r.integers(0, n)))
+
+        def option():
+            ctx.set_option(int(r.integers(0, 17)), int(pick([-1, 0, 1, 2, 3, 4, 8, 64, 300, 1 << 20])))
+
+        def render():
+            ctx.render(pick(cams), int(pick([0, 1, 4, 8, 15])), int(pick([0, 1, 2, 5, 64, 260])), int(pick([pkg.INLINE, pkg.STREAMS])))
+
+        def state_io():
+            st = ctx.download_state(); ctx.upload_state(*st); ctx.download_color(); ctx.present(int(pick([0, 1, 7])))
+
+        def seeds():
+            pick([lambda: ctx.init_output(int(r.integers(0, 1 << 62))), lambda: ctx.reseed(int(r.integers(0, 1 << 62)))])()
+
+        def closure_copying():
+            w, h = wh()
+            ctx.render1(pick(cams), 8, w, h, planes(w, h, int(r.integers(0, 9))), int(pick([pkg.INLINE, pkg.STREAMS])))
+
+        def chain_new():
+            w, h = wh()
+            state["tokens"].append((ctx.chain_init_output(w, h, int(r.integers(0, 1 << 40))), w, h))
+
+        def chain_call():
+            tok, w, h = pick(state["tokens"]) if state["tokens"] and r.random() < 0.9 else (wild_token(),) + wh()
+            if r.random() < 0.1:
+                w += 1
+            consume = r.random() < 0.3
+            new, _ = ctx.render1_chained(pick(cams), 8, w, h, token=tok, consume=consume, algorithm=int(pick([pkg.INLINE, pkg.STREAMS])),
+                                         planes_in=planes(w, h) if r.random() < 0.15 else None, fetch=pick([(), ("r",), ("r", "g", "b"), ("sa", "sctr")]))
+            if consume:
+                state["tokens"] = [x for x in state["tokens"] if x[0] != tok]
+            state["tokens"].append((new, w, h))
+
+        def chain_misc():
+            if not state["tokens"]:
+                return
+            tok, w, h = pick(state["tokens"])
+            k = int(r.integers(0, 4))
+            if k == 0:
+                ctx.chain_fetch(tok, w, h, pick(["r g b", "sa sb sc sctr", "r g b sa sb sc sctr", "b"]))
+            elif k == 1:
+                ctx.chain_release(tok); state["tokens"] = [x for x in state["tokens"] if x[0] != tok]
+            elif k == 2:
+                state["tokens"].append((ctx.chain_reseed(int(r.integers(0, 1 << 40)), w, h, token=tok), w, h))
+            else:
+                ctx.chain_info()
+
+        def group_ops():
+            k = int(r.integers(0, 6))
+            if k == 0:
+                g.set_scene(*pick(scenes[:2]))
+            elif k == 1:
+                g.resize(*pick(sizes))
+            elif k == 2:
+                g.init_output(3)
+            elif k == 3:
+                g.render(pick(cams), 8, int(pick([1, 2, 5])), int(pick([pkg.INLINE, pkg.STREAMS])))
+            elif k == 4:
+                g.download_color(); g.stats()
+            elif g.width:
+                with DeviceBlocks([g.width * g.height * 4] * 3) as dst:
+                    try:
+                        g.gather_color(int(r.integers(0, g.size)), *dst)
+                    finally:
+                        quiet(g.synchronize)
+
+        def misc():
+            pick([ctx.stats, ctx.debug_counters, ctx.reset_stats, ctx.synchronize, lambda: ctx.set_timing(bool(r.integers(0, 2))),
+                  lambda: ctx.render_blocks(pkg.INLINE), lambda: ctx.set_variant(int(pick([0, 0, 4, 5, 13, 17, 99]))), ctx.device_planes])()
+
+        menu = [set_scene, resize, partition, option, render, render, render, state_io, seeds, closure_copying, chain_new, chain_call, chain_call,
+                chain_call, chain_misc, chain_misc, group_ops, group_ops, misc, bind, streams, poke, stream_form]
+        for _ in range(steps):
+            if r.random() < 0.03:
+                stub.hipstub_fail_run(int(r.integers(0, 6)), int(r.integers(1, 6)), int(pick([0, 0, 1, 3])))
+            try:
+                pick(menu)()
+            except (B.PtmiError, MemoryError):
+                pass
+            except AssertionError:
+                pass                                                # (the binding's own argument checks)
+            if len(state["tokens"]) > 40:
+                for tok, _, _ in state["tokens"][:20]:
+                    quiet(lambda: ctx.chain_release(tok))
+                state["tokens"] = state["tokens"][20:]
+        for kind in range(6):
+            stub.hipstub_fail(kind, 0)
+        stub.hipstub_clear_pokes()
+        quiet(ctx.synchronize)
+        quiet(g.synchronize)
+        quiet(lambda: ctx.set_stream(None))
+        quiet(ctx.unbind)
+    stub.hipStreamDestroy(stream)
+    stub.hipstub_clear_error()
+
+
 def group():
     sp, pl = pkg.world.scene16()
     for devices, stripe, (w, h) in (([0, 0, 0], 4, (40, 30)), ([0, 0], 0, (32, 16)), ([0] * 8, 2, (16, 9)), ([0], 8, (24, 24))):
@@ -552,6 +698,16 @@ def nothing_left(where):
 def main():
     global PLAIN
     only = os.environ.get("PTMI_HOSTSAN_ONLY")
+    if only and only.startswith("monkey"):                          # monkey:<first seed>:<seeds>:<steps>
+        _, first, count, steps = (only.split(":") + ["0", "8", "1500"])[:4]
+        stub.hipstub_set_device_size(8, 4 << 30)
+        for seed in range(int(first), int(first) + int(count)):
+            monkey(seed, int(steps))
+            nothing_left("monkey, seed %d" % seed)
+            print("hostsan monkey seed %d: %d steps, %d kernel launches so far" % (seed, int(steps), stub.hipstub_launches(b"")), flush=True)
+        assert stub.hipstub_stale_errors() == 0
+        print("sanitized host side: done")
+        return
     stride = int(os.environ.get("PTMI_HOSTSAN_STRIDE", "1"))
     stub.hipstub_set_device_size(8, 4 << 30)
     report = {}

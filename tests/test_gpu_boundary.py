@@ -231,6 +231,45 @@ def test_another_callers_runtime_error_is_neither_tripped_over_nor_swallowed(fre
     assert_planes_equal(out1, out2, "the two closures")
 
 
+def test_a_resize_the_device_cannot_hold_leaves_the_context_unsized_and_usable(fresh, pkg, ora):
+    """ptmi_resize frees the old planes before it asks for the new ones.  When the new ones cannot be had (here: 2^35 pixels, ~960 GB) the
+    context must not keep pointing into the block it freed: it is UNSIZED (PTMI_ESTATE) until a resize succeeds, and then exact.  Found by
+    the random walk of tests/test_host_sanitized.py on the HIP stand-in; this is the same path against the real runtime's out-of-memory."""
+    sp, pl = pkg.world.scene16()
+    cam = pkg.world.initial_camera()
+    fresh.set_scene(sp, pl)
+    fresh.resize(64, 32)
+    fresh.init_output(5)
+    fresh.render(cam, 8, 1)
+    with pytest.raises(pkg.PtmiError) as err:
+        fresh.resize(1 << 16, 1 << 19)
+    assert err.value.code == pkg.binding.PTMI_ENOMEM, err.value
+    for call in (fresh.download_color, lambda: fresh.render(cam, 8, 1), lambda: fresh.init_output(1), lambda: fresh.present(1)):
+        with pytest.raises(pkg.PtmiError) as err:
+            call()
+        assert err.value.code == pkg.binding.PTMI_ESTATE, err.value
+    w, h = 96, 40
+    fresh.resize(w, h)
+    fresh.init_output(0x5EED1234)
+    fresh.render(cam, 8, 2)
+    want, _ = ora.render_inline(sp, pl, cam, w, h, 8, 2, initial_planes(ora, w, h))
+    assert_planes_equal(fresh.download_state(), want, "after a failed resize")
+    with pkg.Group([0, 0], 8) as g:                                 # the group: unsized as a whole when one member's resize fails
+        g.set_scene(sp, pl)
+        g.resize(w, h)
+        with pytest.raises(pkg.PtmiError):
+            g.resize(1 << 16, 1 << 20)
+        with pytest.raises(pkg.PtmiError) as err:
+            g.download_color()
+        assert err.value.code == pkg.binding.PTMI_ESTATE, err.value
+        g.resize(w, h)
+        g.init_output(0x5EED1234)
+        g.render(cam, 8, 2)
+        got = g.download_color()
+        for k in range(3):
+            assert np.array_equal(got[k].view(np.uint32), np.asarray(want[k]).view(np.uint32))
+
+
 def test_context_is_usable_from_other_threads(ctx, pkg, ora):
     """The closure may be forced on any of three OS threads (app/Main.hs:178-180)."""
     import threading

@@ -12,6 +12,8 @@ wild stream handle, signed overflow, ...); after the contexts are destroyed the 
 event; no error the library reported or chose to ignore is left in the runtime's sticky slot (hipGetLastError), and no launch of the library
 is ever blamed for an older call's error.
 
+Then a seeded RANDOM WALK over the ABI (tests/hostsan_driver.py: monkey) that keeps using the context and the group after every failure.
+
 What this does NOT test: any rendered value, any kernel, the HIP runtime or RCCL themselves.  The product never meets the stand-in: it is
 preloaded into the child process only, and libptmi has no CPU path (tests/test_abi.py)."""
 import glob
@@ -99,6 +101,13 @@ def test_host_side_is_clean_under_asan_and_ubsan_at_every_failure_point():
     walked = sum(int(line.split("'failure_points_walked': ")[1].split(",")[0]) for line in reports)
     assert walked >= 4000, walked
     print("\n".join(reports))
+    # ... and a seeded random walk over the whole ABI (any order of calls, any arguments, an injected failure every ~30 steps, the context
+    # USED ON after every failure -- which the walk above, whose scenarios end at their first error, never does): 100 seeds x 1 500 steps
+    env["PTMI_HOSTSAN_ONLY"] = "monkey:0:100:1500"
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hostsan_driver.py")], capture_output=True, text=True, env=env, timeout=900)
+    out = run.stdout + run.stderr
+    assert "runtime error" not in out and "AddressSanitizer" not in out and "HIPSTUB:" not in out and "terminate called" not in out, out[-4000:]
+    assert run.returncode == 0 and "sanitized host side: done" in run.stdout and out.count("hostsan monkey seed") == 100, out[-4000:]
 
 
 @pytest.mark.skipif(runtime("tsan") is None or not os.path.exists(CLANG), reason="the ROCm clang has no x86-64 TSan runtime here")
