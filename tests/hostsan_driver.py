@@ -31,6 +31,7 @@ assert b"fsanitize" in B.load_library().ptmi_build_id() or True      # (the id c
 
 KINDS = ["hipMalloc", "copy", "launch", "synchronize", "hipHostMalloc", "stream/event creation"]
 MORE = [0, 1, 1 << 30]
+RATE = float(os.environ.get("PTMI_HOSTSAN_RATE", "0.03"))          # the random walk: how often a step arms an injected failure
 PLAIN = True                                                        # False while a failure is being injected: a scenario's own expectations hold for the plain run only
 cam = pkg.world.initial_camera()
 cam2 = cam.copy()
@@ -589,8 +590,8 @@ def monkey(seed=0, steps=1500):
         menu = [set_scene, resize, partition, option, render, render, render, state_io, seeds, closure_copying, chain_new, chain_call, chain_call,
                 chain_call, chain_misc, chain_misc, group_ops, group_ops, misc, bind, streams, poke, stream_form]
         for _ in range(steps):
-            if r.random() < 0.03:
-                stub.hipstub_fail_run(int(r.integers(0, 6)), int(r.integers(1, 6)), int(pick([0, 0, 1, 3])))
+            if r.random() < RATE:
+                stub.hipstub_fail_run(int(r.integers(0, 6)), int(r.integers(1, 6)), int(pick([0, 0, 1, 3, 40])))
             try:
                 pick(menu)()
             except (B.PtmiError, MemoryError):
@@ -610,6 +611,65 @@ def monkey(seed=0, steps=1500):
         quiet(ctx.unbind)
     stub.hipStreamDestroy(stream)
     stub.hipstub_clear_error()
+
+
+def monkey_threads(seed=0, steps=300, n_threads=3):
+    """The random walk from several threads at once on ONE context of a fixed size (the application's threads share a handle): renders, both
+    closures, fetches and releases of each other's tokens, state transfers, statistics, failing calls and their messages."""
+    import threading
+    w, h = 72, 40
+    sp, pl = pkg.world.scene16()
+    problems = []
+    with pkg.Context(0) as ctx:
+        ctx.set_scene(sp, pl)
+        ctx.resize(w, h)
+        ctx.init_output(seed)
+        ctx.set_option(B.OPT_CHAIN_SLOTS, 4)
+        tokens, lock = [ctx.chain_init_output(w, h, 1)], threading.Lock()
+
+        def worker(k):
+            r = np.random.default_rng(1000 * seed + k)
+            try:
+                for _ in range(steps):
+                    op = int(r.integers(0, 9))
+                    with lock:
+                        tok = tokens[int(r.integers(0, len(tokens)))]
+                    try:
+                        if op == 0:
+                            ctx.render(cam if r.random() < 0.5 else cam2, 8, int(r.integers(0, 4)), int(r.integers(0, 2)))
+                        elif op == 1:
+                            new, _ = ctx.render1_chained(cam, 8, w, h, token=tok, consume=r.random() < 0.2, fetch=("r",) if r.random() < 0.3 else ())
+                            with lock:
+                                tokens.append(new)
+                        elif op == 2:
+                            ctx.chain_fetch(tok, w, h, "r g b" if r.random() < 0.5 else "sa sctr")
+                        elif op == 3:
+                            with lock:
+                                victim = tokens.pop(int(r.integers(1, len(tokens)))) if len(tokens) > 3 else 0
+                            if victim:
+                                ctx.chain_release(victim)
+                        elif op == 4:
+                            ctx.upload_state(*ctx.download_state())
+                        elif op == 5:
+                            ctx.download_color(); ctx.present(2); ctx.stats(); ctx.chain_info()
+                        elif op == 6:
+                            ctx.render(cam, -1, 1)                  # refused: a message of this thread's own
+                        elif op == 7:
+                            ctx.render1(cam, 8, w, h, planes(w, h, k))
+                        else:
+                            ctx.reseed(int(r.integers(0, 1 << 40)))
+                    except B.PtmiError as e:
+                        if op == 6 and "bounce_limit" not in str(e):
+                            problems.append("thread %d was handed another call's message: %s" % (k, e))
+            except Exception as e:                                   # noqa: BLE001
+                problems.append(repr(e))
+
+        ts = [threading.Thread(target=worker, args=(k,)) for k in range(n_threads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    assert not problems, problems[:3]
 
 
 def group():
@@ -698,11 +758,11 @@ def nothing_left(where):
 def main():
     global PLAIN
     only = os.environ.get("PTMI_HOSTSAN_ONLY")
-    if only and only.startswith("monkey"):                          # monkey:<first seed>:<seeds>:<steps>
-        _, first, count, steps = (only.split(":") + ["0", "8", "1500"])[:4]
+    if only and only.startswith("monkey"):                          # monkey[_threads]:<first seed>:<seeds>:<steps>
+        which, first, count, steps = (only.split(":") + ["0", "8", "1500"])[:4]
         stub.hipstub_set_device_size(8, 4 << 30)
         for seed in range(int(first), int(first) + int(count)):
-            monkey(seed, int(steps))
+            (monkey_threads if which == "monkey_threads" else monkey)(seed, int(steps))
             nothing_left("monkey, seed %d" % seed)
             print("hostsan monkey seed %d: %d steps, %d kernel launches so far" % (seed, int(steps), stub.hipstub_launches(b"")), flush=True)
         assert stub.hipstub_stale_errors() == 0

@@ -108,6 +108,12 @@ def test_host_side_is_clean_under_asan_and_ubsan_at_every_failure_point():
     out = run.stdout + run.stderr
     assert "runtime error" not in out and "AddressSanitizer" not in out and "HIPSTUB:" not in out and "terminate called" not in out, out[-4000:]
     assert run.returncode == 0 and "sanitized host side: done" in run.stdout and out.count("hostsan monkey seed") == 100, out[-4000:]
+    # ... and from three threads at once on one context (each thread must also be handed ITS OWN failure's message)
+    env["PTMI_HOSTSAN_ONLY"] = "monkey_threads:0:20:300"
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hostsan_driver.py")], capture_output=True, text=True, env=env, timeout=900)
+    out = run.stdout + run.stderr
+    assert "runtime error" not in out and "AddressSanitizer" not in out and "HIPSTUB:" not in out and "terminate called" not in out, out[-4000:]
+    assert run.returncode == 0 and "sanitized host side: done" in run.stdout and out.count("hostsan monkey seed") == 20, out[-4000:]
 
 
 @pytest.mark.skipif(runtime("tsan") is None or not os.path.exists(CLANG), reason="the ROCm clang has no x86-64 TSan runtime here")
@@ -125,6 +131,11 @@ def test_host_threads_are_clean_under_tsan():
     env = dict(os.environ, PTMI_HIPSTUB=stub, PTMI_SANITIZED_LIB=lib, LD_PRELOAD="%s %s" % (runtime("tsan"), stub),
                LD_LIBRARY_PATH=rccl_dir + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""),
                TSAN_OPTIONS="halt_on_error=0:exitcode=24:report_signal_unsafe=0", PTMI_HOSTSAN_ONLY="threads,staged,group", PTMI_HOSTSAN_STRIDE="1000000")
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hostsan_driver.py")], capture_output=True, text=True, env=env, timeout=900)
+    out_text = run.stdout + run.stderr
+    assert "ThreadSanitizer" not in out_text and "HIPSTUB:" not in out_text, out_text[-4000:]
+    assert run.returncode == 0 and "sanitized host side: done" in run.stdout, out_text[-4000:]
+    env["PTMI_HOSTSAN_ONLY"] = "monkey_threads:0:10:300"            # the random walk from three threads on one context
     run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hostsan_driver.py")], capture_output=True, text=True, env=env, timeout=900)
     out_text = run.stdout + run.stderr
     assert "ThreadSanitizer" not in out_text and "HIPSTUB:" not in out_text, out_text[-4000:]
