@@ -1039,6 +1039,13 @@ int chain_download(ptmi_ctx *c, const ptmi_ctx::ChainState &st, void *const dst[
 
 }  // namespace
 
+void ptmi::context_size(const ptmi_ctx *cc, int *width, int *height)
+{
+    ptmi_ctx *c = const_cast<ptmi_ctx *>(cc);
+    std::lock_guard<std::mutex> lock(c->mu);
+    *width = c->width; *height = c->height;
+}
+
 extern "C" {
 
 int ptmi_version(void) { return PTMI_VERSION; }

@@ -219,8 +219,10 @@ namespace {
 // would have the read-outs copy by one size into buffers of another).
 int member_rows(ptmi_group *g, int i, int *rows)
 {
+    int width = 0, height = 0;
+    ptmi::context_size(g->members[(size_t)i], &width, &height);
     *rows = ptmi_local_rows(g->members[(size_t)i]);
-    if (*rows < 0 || *rows != ptmi_partition_rows(g->height, g->stripe_rows, (int)g->members.size(), i))
+    if (width != g->width || height != g->height || *rows < 0 || *rows != ptmi_partition_rows(g->height, g->stripe_rows, (int)g->members.size(), i))
         return gfail(g, PTMI_ESTATE, "member " + std::to_string(i) + " is not sized as the group is (ptmi_group_resize sizes the members)");
     return PTMI_OK;
 }

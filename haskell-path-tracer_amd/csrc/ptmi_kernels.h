@@ -10,7 +10,12 @@
 
 #include "ptmi_core.h"
 
+struct ptmi_ctx;
+
 namespace ptmi {
+
+// (between the C ABI's two units: the image size a context stands at, 0 x 0 while it is unsized -- ptmi_group.cpp checks its members with it)
+void context_size(const ptmi_ctx *ctx, int *width, int *height);
 
 // Scene as staged into LDS, one float4 stream (see pack_scene in ptmi_api.cpp):
 //   [0, ns)                 sphere geometry   (cx, cy, cz, r*r)

@@ -26,7 +26,7 @@ stub.hipstub_set_device_size.argtypes = [ctypes.c_int, ctypes.c_ulonglong]
 stub.hipstub_poke.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_ulonglong, ctypes.c_uint]
 stub.hipstub_launches.argtypes = [ctypes.c_char_p]
 stub.hipstub_launches.restype = ctypes.c_long
-B.load_library(os.environ["PTMI_SANITIZED_LIB"])
+B.load_library(os.environ["PTMI_SANITIZED_LIB"], check_build_id=os.environ.get("PTMI_HOSTSAN_FOREIGN_BUILD") != "1")     # (1: a gcov build made by hand)
 assert b"fsanitize" in B.load_library().ptmi_build_id() or True      # (the id carries a suffix for the extra flags; not relied upon)
 
 KINDS = ["hipMalloc", "copy", "launch", "synchronize", "hipHostMalloc", "stream/event creation"]
@@ -683,6 +683,10 @@ def group():
             g.render(cam, 8, 2)
             g.render(cam, 8, 2, pkg.STREAMS)
             g.set_option(B.OPT_SPP_CHUNKS, 2)
+            g.set_option(B.OPT_STREAMS_FORM, B.FORM_STREAM)          # the stream form reads stream lengths back while it runs: a host thread per member
+            g.render(cam, 8, 2, pkg.STREAMS)
+            g.set_option(B.OPT_STREAMS_FORM, B.FORM_AUTO)
+            g.set_variant(0)
             g.reseed(4)
             g.synchronize()
             g.download_color()
@@ -696,6 +700,18 @@ def group():
                     g.init_output(5)
                     g.render(cam, 8, 1)
                     g.gather_color(0, *dst)
+                    if len(devices) > 1:                             # a member resized behind the group's back: the read-outs refuse, nothing is copied
+                        for other in ((g.width + 8, g.height + 16), (g.width - 8, g.height)):    # (another height: other rows; another width only: the same rows)
+                            g.member(1).resize(*other)
+                            for read in (g.download_color, lambda: g.gather_color(0, *dst)):
+                                try:
+                                    read()
+                                    raise AssertionError("a member of another size was read out by the group's size")
+                                except B.PtmiError as e:
+                                    assert e.code == B.PTMI_ESTATE or not PLAIN, e
+                        g.resize(w, h)                               # the group's resize puts every member right again
+                        g.init_output(6)
+                        g.download_color()
                 finally:
                     quiet(g.synchronize)
 

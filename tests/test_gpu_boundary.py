@@ -268,6 +268,10 @@ def test_a_resize_the_device_cannot_hold_leaves_the_context_unsized_and_usable(f
         got = g.download_color()
         for k in range(3):
             assert np.array_equal(got[k].view(np.uint32), np.asarray(want[k]).view(np.uint32))
+        g.member(1).resize(w - 8, h)                                # a member sized behind the group's back (same rows, another width)
+        with pytest.raises(pkg.PtmiError) as err:
+            g.download_color()                                      # ... is not copied by the group's size
+        assert err.value.code == pkg.binding.PTMI_ESTATE, err.value
 
 
 def test_context_is_usable_from_other_threads(ctx, pkg, ora):
