@@ -219,6 +219,9 @@ Planes carve(void *block, size_t n)
     return p;
 }
 size_t planes_bytes(size_t n) { return 7 * (((n * 4 + 255) / 256) * 256); }
+// (two ints multiply to 2^62: seven planes of that would wrap a size_t.  2^40 pixels are 28 TB of planes -- beyond any device, within size_t)
+constexpr unsigned long long kMaxPixels = 1ull << 40;
+bool too_many_pixels(int width, int height) { return (unsigned long long)width * (unsigned long long)height > kMaxPixels; }
 
 Planes &active(ptmi_ctx *c) { return c->use_bound ? c->bound : c->owned; }
 
@@ -954,6 +957,7 @@ void chain_drop(ptmi_ctx *c, int idx)
 int chain_begin(ptmi_ctx *c, int width, int height, uint64_t token_in, int flags, const void *const *planes_in, bool colour_only, int *out_idx)
 {
     if (width <= 0 || height <= 0) return fail(c, PTMI_EINVAL, "width and height must be positive");
+    if (too_many_pixels(width, height)) return fail(c, PTMI_ELIMIT, "image too large");
     if (flags & ~PTMI_CHAIN_CONSUME) return fail(c, PTMI_EINVAL, "unknown flag");
     const size_t n = (size_t)width * height, bytes = planes_bytes(n);
     int in = chain_find(c, token_in);
@@ -1212,6 +1216,7 @@ int ptmi_resize(ptmi_ctx *c, int width, int height)
     if (!c) return PTMI_EINVAL;
     std::lock_guard<std::mutex> lock(c->mu);
     if (width <= 0 || height <= 0) return fail(c, PTMI_EINVAL, "width and height must be positive");
+    if (too_many_pixels(width, height)) return fail(c, PTMI_ELIMIT, "image too large");
     PTMI_HIP(c, hipSetDevice(c->device));
     PTMI_HIP(c, hipStreamSynchronize(c->stream));
     if (c->owned_block) { (void)hipFree(c->owned_block); c->owned_block = nullptr; }
@@ -1550,6 +1555,7 @@ int ptmi_render1(ptmi_ctx *c, const ptmi_camera *camera, int algorithm, int boun
     std::lock_guard<std::mutex> lock(c->mu);
     if (int rc = check_render_args(c, camera, algorithm, bounce_limit, 1)) return rc;
     if (width <= 0 || height <= 0) return fail(c, PTMI_EINVAL, "width and height must be positive");
+    if (too_many_pixels(width, height)) return fail(c, PTMI_ELIMIT, "image too large");
     if (!r_in || !g_in || !b_in || !sa_in || !sb_in || !sc_in || !sctr_in ||
         !r_out || !g_out || !b_out || !sa_out || !sb_out || !sc_out || !sctr_out)
         return fail(c, PTMI_EINVAL, "a plane pointer is NULL");
@@ -1613,6 +1619,7 @@ int ptmi_chain_init_output(ptmi_ctx *c, int width, int height, uint64_t seed0, u
     if (!token_out) return fail(c, PTMI_EINVAL, "token_out is NULL");
     *token_out = 0;
     if (width <= 0 || height <= 0) return fail(c, PTMI_EINVAL, "width and height must be positive");
+    if (too_many_pixels(width, height)) return fail(c, PTMI_ELIMIT, "image too large");
     PTMI_HIP(c, hipSetDevice(c->device));
     ptmi_ctx::ChainState fresh;
     fresh.width = width; fresh.height = height;

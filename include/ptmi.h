@@ -49,7 +49,7 @@ enum {
     PTMI_EHIP      = -3,   /* a HIP runtime call failed; message in ptmi_last_error          */
     PTMI_ENOMEM    = -4,   /* device or host allocation failed                                */
     PTMI_ESTATE    = -5,   /* call order violated (render before set_scene / resize ...)     */
-    PTMI_ELIMIT    = -6,   /* scene larger than PTMI_MAX_PRIMITIVES                           */
+    PTMI_ELIMIT    = -6,   /* scene larger than PTMI_MAX_PRIMITIVES; an image of more than 2^40 pixels (or beyond the stream form's limits) */
     PTMI_ESTALE    = -7    /* a token names no state this context holds (released, consumed, or another context's) */
 };
 

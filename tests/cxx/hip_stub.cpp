@@ -216,6 +216,7 @@ hipError_t hipMalloc(void **p, size_t bytes)
 {
     if (!p) return set(hipErrorInvalidValue);
     if (fails(0)) { *p = nullptr; return set(hipErrorOutOfMemory); }
+    if (bytes > g_total) { *p = nullptr; return set(hipErrorOutOfMemory); }      // more than the "device" has (hipstub_set_device_size)
     void *block = std::calloc(bytes ? bytes : 1, 1);
     if (!block) { *p = nullptr; return set(hipErrorOutOfMemory); }
     std::lock_guard<std::mutex> lock(g_mu);

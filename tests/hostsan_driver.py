@@ -473,6 +473,7 @@ def monkey(seed=0, steps=1500):
     r = np.random.default_rng(seed)
     scenes = [pkg.world.scene16(), pkg.world.main_scene(), pkg.world.glass_scene()]
     sizes = [(8, 8), (64, 16), (72, 40), (136, 24), (33, 7), (1, 1), (256, 64), (320, 240)]       # (the last: copies go through the pinned ring)
+    absurd = [(2 ** 31 - 1, 2 ** 31 - 1), (1 << 20, 1 << 21), (2 ** 31 - 1, 1 << 12)]               # refused by count, or more than the device has: never wrapped
     k = layout()
     state = {"w": 0, "h": 0, "tokens": [], "glass": False}
     cams = [cam, cam2]
@@ -513,6 +514,13 @@ def monkey(seed=0, steps=1500):
             ctx.set_scene(*scenes[k]); state["glass"] = k == 2
 
         def resize():
+            if r.random() < 0.1:
+                try:
+                    ctx.resize(*pick(absurd))
+                    raise RuntimeError("an absurd size was accepted")
+                except (B.PtmiError, MemoryError):
+                    state["w"] = state["h"] = 0                     # (the old planes went first: the context is unsized now)
+                    return
             w, h = pick(sizes)
             ctx.resize(w, h); state["w"], state["h"] = w, h
 

@@ -244,6 +244,9 @@ def test_a_resize_the_device_cannot_hold_leaves_the_context_unsized_and_usable(f
     with pytest.raises(pkg.PtmiError) as err:
         fresh.resize(1 << 16, 1 << 19)
     assert err.value.code == pkg.binding.PTMI_ENOMEM, err.value
+    with pytest.raises(pkg.PtmiError) as err:
+        fresh.resize(2 ** 31 - 1, 2 ** 31 - 1)                      # seven planes of 2^62 pixels would wrap a size_t: refused by count
+    assert err.value.code == pkg.binding.PTMI_ELIMIT, err.value
     for call in (fresh.download_color, lambda: fresh.render(cam, 8, 1), lambda: fresh.init_output(1), lambda: fresh.present(1)):
         with pytest.raises(pkg.PtmiError) as err:
             call()
