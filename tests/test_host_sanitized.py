@@ -7,7 +7,7 @@ into the read-backs: overflow levels, the redo with longer streams, drops that s
 staged copies through the pinned ring's worker threads, four threads on one context, groups of 1-8 members with their gathers, and the
 refusals -- first plainly, then once per FAILURE POINT: the k-th hipMalloc, copy, launch, synchronize, pinned allocation or stream/event
 creation of the scenario fails, for every k; then the k-th AND the next call of the kind (the recovery's own call fails), and the k-th and
-every later one (a device that stays broken), for every third k (about 4 200 runs, ~25 s).  Demanded of every run: no sanitizer report (an overrun copy, a block used after hipFree or freed twice, a
+every later one (a device that stays broken), for every third k (about 4 800 runs, ~30 s).  Demanded of every run: no sanitizer report (an overrun copy, a block used after hipFree or freed twice, a
 wild stream handle, signed overflow, ...); after the contexts are destroyed the stand-in holds no device block, pinned block, stream or
 event; no error the library reported or chose to ignore is left in the runtime's sticky slot (hipGetLastError), and no launch of the library
 is ever blamed for an older call's error.
