@@ -4,7 +4,7 @@
 // no GPU, under AddressSanitizer + UndefinedBehaviorSanitizer (GPU sanitizers are not available on the pool, CPU ones are).
 //
 // What it is: "device memory" is host memory (calloc: a fresh block reads as zeros), copies are memcpy, memsets are memset, streams and
-// events are small heap objects and everything is synchronous.  KERNELS DO NOT RUN: hipLaunchKernel counts the launch under the kernel's
+// events are small heap objects and everything is synchronous -- or, after hipstub_set_deferred(1), as asynchronous as the real thing: see Op.  KERNELS DO NOT RUN: hipLaunchKernel counts the launch under the kernel's
 // name and returns success.  Whatever a real kernel would have written stays as it was (zeros in a fresh block) -- except the few counter
 // words a test places into a read-back with hipstub_poke, to send the host down the paths that depend on what a kernel counted.
 //
@@ -25,7 +25,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
+#include <set>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -33,6 +35,23 @@
 extern "C" void __sanitizer_print_stack_trace(void);
 
 namespace {
+
+constexpr int kStreamMagic = 0x57e4a3, kEventMagic = 0xe7e47;
+struct Stream;
+struct Event { int magic; std::chrono::steady_clock::time_point t; Stream *recorded_on = nullptr; bool pending = false; };
+// DEFERRED mode (hipstub_set_deferred): what a real stream does LATER is done later here too -- at the next synchronisation that covers it --
+// so that host code which reads a result, reuses a pinned buffer or returns a borrowed one before it has synchronised meets stale bytes
+// (the tests compare round trips of copies) or, if the memory has gone in between, AddressSanitizer.  As on the real runtime a copy
+// from or to PAGEABLE host memory is finished with that memory when the call returns (staged on the way in, synchronous on the way out);
+// only pinned memory (hipHostMalloc), device-to-device copies, fills and kernels are truly asynchronous.
+struct Op {
+    enum Type { Copy, Fill, Fill32, Record, Wait, Nop } type;
+    void *dst; const void *src; size_t bytes; int value; Event *event;
+    std::vector<char> staged;                  // a pageable source, taken at call time
+};
+struct Stream { int magic; std::deque<Op> queue; };
+bool g_deferred = false;
+std::recursive_mutex g_queue_mu;               // one lock over every queue: worker threads enqueue while another thread synchronises
 
 // Made on first use and never destroyed: a hipcc-compiled object registers its kernels from a static constructor, which may run before
 // this library's own (the library preloaded into a program that links libptmi directly) and unregisters them from a destructor after it.
@@ -45,6 +64,8 @@ struct State {
     std::map<std::string, long> launches;
     struct Poke { std::string kernel; long nth; size_t offset; unsigned int value; bool armed; };
     std::vector<Poke> pokes;
+    Stream null_stream{kStreamMagic, {}};
+    std::set<Stream *> streams;                 // live streams (deferred mode: hipFree and hipMemcpy synchronise with all of them / the NULL one)
 };
 State &S() { static State *state = new State; return *state; }
 #define g_mu (S().mu)
@@ -64,9 +85,6 @@ thread_local hipError_t g_last = hipSuccess;
 thread_local long g_seq = 0, g_last_seq = 0, g_launch_seq = 0;      // the thread's call numbers: of the call that set g_last, of its latest launch
 std::atomic<long> g_stale{0};                  // hipGetLastError calls that handed out an error OLDER than the thread's latest (successful) launch
 
-struct Stream { int magic; };
-struct Event { int magic; std::chrono::steady_clock::time_point t; };
-constexpr int kStreamMagic = 0x57e4a3, kEventMagic = 0xe7e47;
 
 struct Config { dim3 grid, block; size_t shmem; hipStream_t stream; };
 thread_local Config t_config{};
@@ -86,6 +104,57 @@ bool fails(int kind)
 hipError_t set(hipError_t e) { if (e != hipSuccess) { g_last = e; g_last_seq = ++g_seq; } return e; }
 
 bool stream_ok(hipStream_t s) { return s == nullptr || reinterpret_cast<Stream *>(s)->magic == kStreamMagic; }   // (ASan sees a freed or wild one)
+Stream *stream_of(hipStream_t s) { return s ? reinterpret_cast<Stream *>(s) : &S().null_stream; }
+
+void apply_pokes(void *dst, size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    std::vector<State::Poke> &pokes = S().pokes;
+    for (size_t i = 0; i < pokes.size();) {
+        if (pokes[i].armed && pokes[i].offset + sizeof(unsigned int) <= bytes) {
+            std::memcpy(static_cast<char *>(dst) + pokes[i].offset, &pokes[i].value, sizeof(unsigned int));
+            pokes.erase(pokes.begin() + (long)i);
+        } else ++i;
+    }
+}
+
+void flush(Stream *st, Event *upto = nullptr);
+void run(Op &op)
+{
+    switch (op.type) {
+    case Op::Copy: std::memmove(op.dst, op.staged.empty() ? op.src : op.staged.data(), op.bytes); break;     // (instrumented: memory that has gone in between is ASan's to report)
+    case Op::Fill: std::memset(op.dst, op.value, op.bytes); break;
+    case Op::Fill32: for (size_t i = 0; i < op.bytes; ++i) static_cast<int *>(op.dst)[i] = op.value; break;
+    case Op::Record: op.event->t = std::chrono::steady_clock::now(); op.event->pending = false; break;
+    case Op::Wait: if (op.event->pending && op.event->recorded_on) flush(op.event->recorded_on, op.event); break;
+    case Op::Nop: break;
+    }
+}
+// everything `st` has queued, in order -- or up to and including the record of `upto`
+void flush(Stream *st, Event *upto)
+{
+    std::lock_guard<std::recursive_mutex> lock(g_queue_mu);
+    while (!st->queue.empty()) {
+        Op op = std::move(st->queue.front());
+        st->queue.pop_front();
+        run(op);
+        if (upto && op.type == Op::Record && op.event == upto) return;
+    }
+}
+void flush_all()
+{
+    std::lock_guard<std::recursive_mutex> lock(g_queue_mu);
+    flush(&S().null_stream);
+    for (Stream *st : S().streams) flush(st);
+}
+bool is_pinned(const void *p)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_host_blocks.upper_bound(const_cast<void *>(p));
+    if (it == g_host_blocks.begin()) return false;
+    --it;
+    return static_cast<const char *>(p) < static_cast<const char *>(it->first) + it->second;
+}
 
 }  // namespace
 
@@ -124,6 +193,14 @@ void hipstub_poke(const char *kernel_part, long nth, unsigned long long offset, 
     S().pokes.push_back(State::Poke{kernel_part ? kernel_part : "", nth, (size_t)offset, value, false});
 }
 void hipstub_clear_pokes(void) { std::lock_guard<std::mutex> lock(g_mu); S().pokes.clear(); }
+void hipstub_set_deferred(int on) { flush_all(); g_deferred = on != 0; }
+long hipstub_queued(void)                         // operations waiting for a synchronisation (deferred mode)
+{
+    std::lock_guard<std::recursive_mutex> lock(g_queue_mu);
+    long n = (long)S().null_stream.queue.size();
+    for (Stream *st : S().streams) n += (long)st->queue.size();
+    return n;
+}
 void hipstub_print_live(void)                     // which hipMalloc calls of the process made the blocks that are still alive
 {
     std::lock_guard<std::mutex> lock(g_mu);
@@ -230,6 +307,7 @@ hipError_t hipMalloc(void **p, size_t bytes)
 hipError_t hipFree(void *p)
 {
     if (!p) return hipSuccess;
+    if (g_deferred) flush_all();                             // (the real hipFree waits for the device)
     {
         std::lock_guard<std::mutex> lock(g_mu);
         auto it = g_blocks.find(p);
@@ -257,6 +335,7 @@ hipError_t hipHostMalloc(void **p, size_t bytes, unsigned int)
 hipError_t hipHostFree(void *p)
 {
     if (!p) return hipSuccess;
+    if (g_deferred) flush_all();
     {
         std::lock_guard<std::mutex> lock(g_mu);
         auto it = g_host_blocks.find(p);
@@ -269,41 +348,58 @@ hipError_t hipHostFree(void *p)
     std::free(p);
     return hipSuccess;
 }
+namespace {
+hipError_t copy_now(void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    std::memmove(dst, src, bytes);                           // (instrumented: a span past either block's end is ASan's to report)
+    if (kind == hipMemcpyDeviceToHost) apply_pokes(dst, bytes);      // what a kernel "would have counted": into the first read-back that holds the words
+    return hipSuccess;
+}
+}  // namespace
 hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
 {
     if (fails(1)) return set(hipErrorUnknown);
     if (bytes && (!dst || !src)) return set(hipErrorInvalidValue);
-    std::memmove(dst, src, bytes);                           // (instrumented: a span past either block's end is ASan's to report)
-    if (kind == hipMemcpyDeviceToHost) {                     // what a kernel "would have counted": the test's words, into the first read-back that holds them
-        std::lock_guard<std::mutex> lock(g_mu);
-        std::vector<State::Poke> &pokes = S().pokes;
-        for (size_t i = 0; i < pokes.size();) {
-            if (pokes[i].armed && pokes[i].offset + sizeof(unsigned int) <= bytes) {
-                std::memcpy(static_cast<char *>(dst) + pokes[i].offset, &pokes[i].value, sizeof(unsigned int));
-                pokes.erase(pokes.begin() + (long)i);
-            } else ++i;
-        }
-    }
-    return hipSuccess;
+    if (g_deferred) flush(&S().null_stream);                 // (synchronous, on the NULL stream; the library's streams are non-blocking ones)
+    return copy_now(dst, src, bytes, kind);
 }
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t stream)
 {
     if (!stream_ok(stream)) return set(hipErrorInvalidHandle);
-    return hipMemcpy(dst, src, bytes, kind);
+    if (fails(1)) return set(hipErrorUnknown);
+    if (bytes && (!dst || !src)) return set(hipErrorInvalidValue);
+    if (!g_deferred) return copy_now(dst, src, bytes, kind);
+    std::lock_guard<std::recursive_mutex> lock(g_queue_mu);
+    Stream *st = stream_of(stream);
+    if (kind == hipMemcpyDeviceToHost && !is_pinned(dst)) {  // to pageable memory: in stream order, and done when the call returns
+        flush(st);
+        return copy_now(dst, src, bytes, kind);
+    }
+    Op op{Op::Copy, dst, src, bytes, 0, nullptr, {}};
+    if (kind == hipMemcpyHostToDevice && !is_pinned(src)) op.staged.assign(static_cast<const char *>(src), static_cast<const char *>(src) + bytes);     // from pageable memory: taken now
+    st->queue.push_back(std::move(op));
+    return hipSuccess;
 }
 hipError_t hipMemsetAsync(void *dst, int value, size_t bytes, hipStream_t stream)
 {
     if (!stream_ok(stream)) return set(hipErrorInvalidHandle);
     if (bytes && !dst) return set(hipErrorInvalidValue);
-    std::memset(dst, value, bytes);
+    if (!g_deferred) { std::memset(dst, value, bytes); return hipSuccess; }
+    std::lock_guard<std::recursive_mutex> lock(g_queue_mu);
+    stream_of(stream)->queue.push_back(Op{Op::Fill, dst, nullptr, bytes, value, nullptr, {}});
     return hipSuccess;
 }
 hipError_t hipMemsetD32Async(hipDeviceptr_t dst, int value, size_t count, hipStream_t stream)
 {
     if (!stream_ok(stream)) return set(hipErrorInvalidHandle);
     if (count && !dst) return set(hipErrorInvalidValue);
-    int *p = static_cast<int *>(dst);
-    for (size_t i = 0; i < count; ++i) p[i] = value;
+    if (!g_deferred) {
+        int *p = static_cast<int *>(dst);
+        for (size_t i = 0; i < count; ++i) p[i] = value;
+        return hipSuccess;
+    }
+    std::lock_guard<std::recursive_mutex> lock(g_queue_mu);
+    stream_of(stream)->queue.push_back(Op{Op::Fill32, dst, nullptr, count, value, nullptr, {}});
     return hipSuccess;
 }
 
@@ -311,7 +407,9 @@ hipError_t hipMemsetD32Async(hipDeviceptr_t dst, int value, size_t count, hipStr
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned int)
 {
     if (fails(5)) { *s = nullptr; return set(hipErrorUnknown); }
-    *s = reinterpret_cast<hipStream_t>(new Stream{kStreamMagic});
+    Stream *st = new Stream{kStreamMagic, {}};
+    *s = reinterpret_cast<hipStream_t>(st);
+    { std::lock_guard<std::recursive_mutex> qlock(g_queue_mu); S().streams.insert(st); }
     std::lock_guard<std::mutex> lock(g_mu);
     ++g_streams;
     return hipSuccess;
@@ -321,6 +419,7 @@ hipError_t hipStreamDestroy(hipStream_t s)
 {
     if (!s || !stream_ok(s)) return set(hipErrorInvalidHandle);
     Stream *p = reinterpret_cast<Stream *>(s);
+    { std::lock_guard<std::recursive_mutex> qlock(g_queue_mu); flush(p); S().streams.erase(p); }      // (the real call lets the queued work finish)
     p->magic = 0;
     delete p;
     std::lock_guard<std::mutex> lock(g_mu);
@@ -331,12 +430,13 @@ hipError_t hipStreamSynchronize(hipStream_t s)
 {
     if (!stream_ok(s)) return set(hipErrorInvalidHandle);
     if (fails(3)) return set(hipErrorUnknown);
+    flush(stream_of(s));
     return hipSuccess;
 }
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned int)
 {
     if (fails(5)) { *e = nullptr; return set(hipErrorUnknown); }
-    *e = reinterpret_cast<hipEvent_t>(new Event{kEventMagic, std::chrono::steady_clock::now()});
+    *e = reinterpret_cast<hipEvent_t>(new Event{kEventMagic, std::chrono::steady_clock::now(), nullptr, false});
     std::lock_guard<std::mutex> lock(g_mu);
     ++g_events;
     return hipSuccess;
@@ -346,6 +446,13 @@ hipError_t hipEventDestroy(hipEvent_t e)
 {
     Event *p = reinterpret_cast<Event *>(e);
     if (!p || p->magic != kEventMagic) return set(hipErrorInvalidHandle);
+    {   // (the real call defers the destruction until the record has happened; a wait for an event that has happened is no wait)
+        std::lock_guard<std::recursive_mutex> qlock(g_queue_mu);
+        if (p->pending && p->recorded_on) flush(p->recorded_on, p);
+        auto forget = [&](Stream *st) { for (Op &op : st->queue) if (op.type == Op::Wait && op.event == p) op.type = Op::Nop; };
+        forget(&S().null_stream);
+        for (Stream *st : S().streams) forget(st);
+    }
     p->magic = 0;
     delete p;
     std::lock_guard<std::mutex> lock(g_mu);
@@ -356,25 +463,36 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s)
 {
     Event *p = reinterpret_cast<Event *>(e);
     if (!p || p->magic != kEventMagic || !stream_ok(s)) return set(hipErrorInvalidHandle);
-    p->t = std::chrono::steady_clock::now();
+    if (!g_deferred) { p->t = std::chrono::steady_clock::now(); return hipSuccess; }
+    std::lock_guard<std::recursive_mutex> lock(g_queue_mu);
+    if (p->pending && p->recorded_on) flush(p->recorded_on, p);      // (recorded again before the first record happened: keep it simple)
+    p->recorded_on = stream_of(s); p->pending = true;
+    p->recorded_on->queue.push_back(Op{Op::Record, nullptr, nullptr, 0, 0, p, {}});
     return hipSuccess;
 }
 hipError_t hipEventSynchronize(hipEvent_t e)
 {
     Event *p = reinterpret_cast<Event *>(e);
-    return (!p || p->magic != kEventMagic) ? set(hipErrorInvalidHandle) : hipSuccess;
+    if (!p || p->magic != kEventMagic) return set(hipErrorInvalidHandle);
+    if (p->pending && p->recorded_on) flush(p->recorded_on, p);
+    return hipSuccess;
 }
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
 {
     Event *pa = reinterpret_cast<Event *>(a), *pb = reinterpret_cast<Event *>(b);
     if (!pa || !pb || pa->magic != kEventMagic || pb->magic != kEventMagic) return set(hipErrorInvalidHandle);
+    if (pa->pending || pb->pending) return hipErrorNotReady;
     *ms = std::chrono::duration<float, std::milli>(pb->t - pa->t).count();
     return hipSuccess;
 }
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned int)
 {
     Event *p = reinterpret_cast<Event *>(e);
-    return (!p || p->magic != kEventMagic || !stream_ok(s)) ? set(hipErrorInvalidHandle) : hipSuccess;
+    if (!p || p->magic != kEventMagic || !stream_ok(s)) return set(hipErrorInvalidHandle);
+    if (!g_deferred) return hipSuccess;
+    std::lock_guard<std::recursive_mutex> lock(g_queue_mu);
+    if (p->pending) stream_of(s)->queue.push_back(Op{Op::Wait, nullptr, nullptr, 0, 0, p, {}});       // (an event that has happened already is no wait)
+    return hipSuccess;
 }
 
 }  // extern "C"

@@ -31,6 +31,7 @@ assert b"fsanitize" in B.load_library().ptmi_build_id() or True      # (the id c
 
 KINDS = ["hipMalloc", "copy", "launch", "synchronize", "hipHostMalloc", "stream/event creation"]
 MORE = [0, 1, 1 << 30]
+MORE_STRIDE = int(os.environ.get("PTMI_HOSTSAN_MORE_STRIDE", "3"))
 RATE = float(os.environ.get("PTMI_HOSTSAN_RATE", "0.03"))          # the random walk: how often a step arms an injected failure
 PLAIN = True                                                        # False while a failure is being injected: a scenario's own expectations hold for the plain run only
 cam = pkg.world.initial_camera()
@@ -378,6 +379,65 @@ def threads():
             quiet(g.synchronize)
     if errors:
         raise errors[0]
+
+
+def same(got, want, what):
+    for a, b in zip(got, want):
+        assert np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32)), what
+
+
+def roundtrips():
+    """What CAN be checked for value on the stand-in: everything that is copies only.  Kernels do not run, so a state that was uploaded, copied on
+    the "device", moved to host memory and back, or snapshotted must come down as it went up -- in deferred mode (main: PTMI_HOSTSAN_DEFERRED)
+    only if the library really synchronises before it reads a result, reuses a pinned buffer or returns a borrowed one."""
+    sp, pl = pkg.world.scene16()
+    for (w, h) in ((48, 20), (320, 240)):                           # (the second: through the pinned ring and its worker threads)
+        with pkg.Context(0) as ctx:
+            ctx.set_scene(sp, pl)
+            ctx.resize(w, h)
+            p = planes(w, h, 5)
+            p[0][:] = np.arange(w * h, dtype=np.float32).reshape(h, w)
+            p[1][:] = 2.5; p[2][:] = -1.0
+            ctx.upload_state(*p)
+            same(ctx.download_state(), p, "upload_state / download_state")
+            same(ctx.download_color(), p[:3], "download_color")
+            q = planes(w, h, 6)
+            ctx.upload_state(sa=q[3], sctr=q[6])                    # two planes only
+            same(ctx.download_state(), p[:3] + [q[3], p[4], p[5], q[6]], "partial upload")
+            with DeviceBlocks([3 * w * h * 4]) as (dst,):
+                ctx._check(ctx._lib.ptmi_snapshot_color(ctx._h, ctypes.c_void_p(dst), None))
+                ctx.synchronize()
+                back = np.empty((3, h, w), np.float32)
+                if stub.hipMemcpy(back.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(dst), ctypes.c_size_t(back.nbytes), 2) != 0:
+                    stub.hipstub_clear_error()
+                    raise MemoryError("stand-in hipMemcpy (injected)")
+                same(list(back), p[:3], "ptmi_snapshot_color")
+            # the chained closure with kernels that do nothing: every state equals the planes the chain began with
+            ctx.set_option(B.OPT_CHAIN_SLOTS, 2)
+            t1, got = ctx.render1_chained(cam, 8, w, h, planes_in=p, fetch="r g b sa sb sc sctr".split())
+            same([got[k] for k in "r g b sa sb sc sctr".split()], p, "chained: planes out of the uploading call")
+            t2, _ = ctx.render1_chained(cam, 8, w, h, token=t1)
+            t3, _ = ctx.render1_chained(cam, 8, w, h, token=t2)     # t1 moves to host memory
+            assert ctx.chain_info()["states_on_host"] >= 1
+            for t in (t1, t2, t3):
+                same(ctx.chain_fetch(t, w, h), p, "chain_fetch")
+            t4, _ = ctx.render1_chained(cam, 8, w, h, token=t1, consume=True)     # back from host memory, in place
+            same(ctx.chain_fetch(t4, w, h), p, "consumed evicted state")
+            t5 = ctx.chain_reseed(3, w, h, colour_in=p[:3])
+            same(ctx.chain_fetch(t5, w, h, "r g b"), p[:3], "chain_reseed from host colour")
+            same(ctx.render1(cam, 8, w, h, p), p, "copying closure")
+    with pkg.Group([0, 0, 0], 4) as g:                              # the group's host read-out stitches what the members hold
+        w, h = 40, 30
+        g.set_scene(sp, pl)
+        g.resize(w, h)
+        whole = [np.random.default_rng(k).random((h, w), dtype=np.float32) for k in range(3)]
+        for i in range(g.size):
+            m = g.member(i)
+            rows = m.global_rows()
+            z = [np.zeros((rows.size, w), np.uint32)] * 4
+            m.width, m.height = w, h
+            m.upload_state(*[a[rows] for a in whole], *z)
+        same(g.download_color(), whole, "group download_color")
 
 
 def layout():
@@ -769,7 +829,7 @@ def refusals():
             pass
 
 
-SCENARIOS = [resident, partitioned, glass, stream_overflow, closures, staged, threads, group, refusals]
+SCENARIOS = [resident, roundtrips, partitioned, glass, stream_overflow, closures, staged, threads, group, refusals]
 
 
 def nothing_left(where):
@@ -793,6 +853,8 @@ def main():
         print("sanitized host side: done")
         return
     stride = int(os.environ.get("PTMI_HOSTSAN_STRIDE", "1"))
+    if os.environ.get("PTMI_HOSTSAN_DEFERRED") == "1":              # asynchronous work happens at the next synchronisation that covers it
+        stub.hipstub_set_deferred(1)
     stub.hipstub_set_device_size(8, 4 << 30)
     report = {}
     for sc in SCENARIOS:
@@ -809,7 +871,7 @@ def main():
         walked = absorbed = 0
         # one failure; a failure and the next call of the kind failing too (the recovery's own call); a device that stays broken
         for kind, n, more in [(kind, n, more) for more in MORE for kind, n in enumerate(counts)]:
-            for k in range(1, n + 1, stride if more == 0 else stride * 3):
+            for k in range(1, n + 1, stride if more == 0 else stride * MORE_STRIDE):
                 stub.hipstub_fail_run(kind, k, more)
                 try:
                     sc()

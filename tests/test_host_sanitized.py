@@ -7,12 +7,14 @@ into the read-backs: overflow levels, the redo with longer streams, drops that s
 staged copies through the pinned ring's worker threads, four threads on one context, groups of 1-8 members with their gathers, and the
 refusals -- first plainly, then once per FAILURE POINT: the k-th hipMalloc, copy, launch, synchronize, pinned allocation or stream/event
 creation of the scenario fails, for every k; then the k-th AND the next call of the kind (the recovery's own call fails), and the k-th and
-every later one (a device that stays broken), for every third k (about 4 800 runs, ~30 s).  Demanded of every run: no sanitizer report (an overrun copy, a block used after hipFree or freed twice, a
+every later one (a device that stays broken), for every fifth k (about 3 500 runs, ~25 s).  Demanded of every run: no sanitizer report (an overrun copy, a block used after hipFree or freed twice, a
 wild stream handle, signed overflow, ...); after the contexts are destroyed the stand-in holds no device block, pinned block, stream or
 event; no error the library reported or chose to ignore is left in the runtime's sticky slot (hipGetLastError), and no launch of the library
 is ever blamed for an older call's error.
 
 Then a seeded RANDOM WALK over the ABI (tests/hostsan_driver.py: monkey) that keeps using the context and the group after every failure.
+What IS checked for value: everything that is copies only (`roundtrips`: uploads, downloads, the closures with kernels that do nothing,
+evictions to host memory and back, snapshots, the group's stitched read-out) -- also with the stand-in's streams asynchronous.
 
 What this does NOT test: any rendered value, any kernel, the HIP runtime or RCCL themselves.  The product never meets the stand-in: it is
 preloaded into the child process only, and libptmi has no CPU path (tests/test_abi.py)."""
@@ -92,28 +94,44 @@ def test_host_side_is_clean_under_asan_and_ubsan_at_every_failure_point():
                ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     env.pop("PTMI_HOSTSAN_ONLY", None)
     env.pop("PTMI_HOSTSAN_STRIDE", None)
+    env["PTMI_HOSTSAN_MORE_STRIDE"] = "5"                          # (every k alone; every fifth k with the next / with all later calls failing too)
     run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hostsan_driver.py")], capture_output=True, text=True, env=env, timeout=900)
     out = run.stdout + run.stderr
     assert "runtime error" not in out and "AddressSanitizer" not in out and "HIPSTUB:" not in out, out[-4000:]
     assert run.returncode == 0 and "sanitized host side: done" in run.stdout, out[-4000:]
     reports = [line for line in run.stdout.splitlines() if line.startswith("hostsan ")]
-    assert len(reports) == 9, reports
+    assert len(reports) == 10, reports
     walked = sum(int(line.split("'failure_points_walked': ")[1].split(",")[0]) for line in reports)
-    assert walked >= 4000, walked
+    assert walked >= 3000, walked
     print("\n".join(reports))
     # ... and a seeded random walk over the whole ABI (any order of calls, any arguments, an injected failure every ~30 steps, the context
-    # USED ON after every failure -- which the walk above, whose scenarios end at their first error, never does): 100 seeds x 1 500 steps
-    env["PTMI_HOSTSAN_ONLY"] = "monkey:0:100:1500"
+    # USED ON after every failure -- which the walk above, whose scenarios end at their first error, never does): 60 seeds x 1 500 steps
+    env["PTMI_HOSTSAN_ONLY"] = "monkey:0:60:1500"
     run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hostsan_driver.py")], capture_output=True, text=True, env=env, timeout=900)
     out = run.stdout + run.stderr
     assert "runtime error" not in out and "AddressSanitizer" not in out and "HIPSTUB:" not in out and "terminate called" not in out, out[-4000:]
-    assert run.returncode == 0 and "sanitized host side: done" in run.stdout and out.count("hostsan monkey seed") == 100, out[-4000:]
+    assert run.returncode == 0 and "sanitized host side: done" in run.stdout and out.count("hostsan monkey seed") == 60, out[-4000:]
+    # ... and all of it once more with the stand-in's streams truly ASYNCHRONOUS (hipstub_set_deferred: a pinned copy, a device-to-device copy, a
+    # fill happen at the next synchronisation that covers them): the value-checked round trips of the `roundtrips` scenario then hold only if the
+    # library synchronises before it reads a result, reuses a slot of its pinned ring or returns a borrowed buffer
+    env["PTMI_HOSTSAN_DEFERRED"] = "1"
+    for only, stride, want in ((None, "4", 10), ("monkey:200:30:1500", "1", 30)):
+        env.pop("PTMI_HOSTSAN_ONLY", None)
+        if only:
+            env["PTMI_HOSTSAN_ONLY"] = only
+        env["PTMI_HOSTSAN_STRIDE"] = stride
+        run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hostsan_driver.py")], capture_output=True, text=True, env=env, timeout=900)
+        out = run.stdout + run.stderr
+        assert "runtime error" not in out and "AddressSanitizer" not in out and "HIPSTUB:" not in out and "terminate called" not in out, out[-4000:]
+        assert run.returncode == 0 and "sanitized host side: done" in run.stdout and len([x for x in run.stdout.splitlines() if x.startswith("hostsan ")]) == want, out[-4000:]
+    env.pop("PTMI_HOSTSAN_DEFERRED")
+    env.pop("PTMI_HOSTSAN_STRIDE")
     # ... and from three threads at once on one context (each thread must also be handed ITS OWN failure's message)
-    env["PTMI_HOSTSAN_ONLY"] = "monkey_threads:0:20:300"
+    env["PTMI_HOSTSAN_ONLY"] = "monkey_threads:0:10:300"
     run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hostsan_driver.py")], capture_output=True, text=True, env=env, timeout=900)
     out = run.stdout + run.stderr
     assert "runtime error" not in out and "AddressSanitizer" not in out and "HIPSTUB:" not in out and "terminate called" not in out, out[-4000:]
-    assert run.returncode == 0 and "sanitized host side: done" in run.stdout and out.count("hostsan monkey seed") == 20, out[-4000:]
+    assert run.returncode == 0 and "sanitized host side: done" in run.stdout and out.count("hostsan monkey seed") == 10, out[-4000:]
 
 
 @pytest.mark.skipif(runtime("tsan") is None or not os.path.exists(CLANG), reason="the ROCm clang has no x86-64 TSan runtime here")
